@@ -1,0 +1,139 @@
+/*
+ * rtmi.h -- C ABI of librtmi.so: MI355X (gfx950) ray propagation for the
+ * shooting-method hot path of neyuru/RayTracing's RT_bench.py.
+ *
+ * This header is the drop-in boundary.  The reference has no FFI layer; its
+ * seam is the Python call surface, so each entry point below names the
+ * reference interface (RT_bench.py file:line) it stands in for.  Plain
+ * pointers and sizes only; every function returns 0 on success or a negative
+ * rtmi_status, never throws, and rtmi_last_error() describes the last failure
+ * on the calling thread.  Handles are not thread-safe (the reference's trazar
+ * is not re-entrant either: RT_bench.py:73, 646-648).
+ *
+ * There is NO CPU fallback behind this ABI: with no HIP device the calls fail
+ * with RTMI_ERR_HIP.  The CPU restatement used by the tests lives in oracle/.
+ */
+#ifndef RTMI_H
+#define RTMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTMI_ABI_VERSION 1
+
+typedef enum {
+    RTMI_OK = 0,
+    RTMI_ERR_ARG = -1,      /* bad argument (null pointer, size, enum out of range) */
+    RTMI_ERR_HIP = -2,      /* a HIP runtime call failed / no device */
+    RTMI_ERR_ALLOC = -3,    /* device or host allocation failed */
+    RTMI_ERR_STATE = -4,    /* call not valid in the handle's state */
+    RTMI_ERR_UNSUPPORTED = -5
+} rtmi_status;
+
+/* scenario <-> user_choice "1".."4" (RT_bench.py:1565-1580); 4 reuses field 3 with gamma=3 (:1579) */
+typedef enum { RTMI_INTERFACE = 1, RTMI_FISHEYE = 2, RTMI_VERT_HETEROGENEOUS = 3, RTMI_ANISOTROPY = 4 } rtmi_scenario;
+
+/* method m <-> step function op<m> (RT_bench.py:469-764; menus :1238-1264 and :1286-1291) */
+typedef enum { RTMI_OP_MIN = 1, RTMI_OP_MAX = 11 } rtmi_method_range;
+
+typedef enum { RTMI_F64 = 0, RTMI_F32 = 1 } rtmi_dtype;
+
+typedef struct rtmi_field rtmi_field;   /* z + grd of interpolacion() (:435-464), resident in HBM */
+typedef struct rtmi_batch rtmi_batch;   /* one trazar() call's ray batch (:766-948), resident in HBM */
+
+/* ------------------------------------------------------------------ library */
+int rtmi_abi_version(void);
+const char *rtmi_last_error(void);
+/* Select the HIP device for subsequent creates on this thread (one process per GPU: pass LOCAL_RANK). */
+int rtmi_set_device(int device);
+int rtmi_device_count(int *count);
+
+/* -------------------------------------------------------------------- field
+ * rtmi_field_build == genZ(xi,xs,yi,ys) (:412-433) followed by interpolacion() (:435-464):
+ * samples the scenario's n(x,y) on linspace(xi-3, xs+3, int((xs-xi+6)/delta+1)) x likewise in y,
+ * np.gradient(Z, delta, edge_order=2) (:450), bilinear n and not-a-knot bicubic fits of the two
+ * gradient components (:455-457), all on the device.  The Hessian fits (:459-462) are never read by
+ * the path and are not built.  `stream` is a hipStream_t (NULL = default stream). */
+int rtmi_field_build(int scenario, double xi, double xs, double yi, double ys, double delta,
+                     int dtype, void *stream, rtmi_field **out);
+/* interpolacion(x, y, Z, X, Y) (:435) for caller-provided samples Z[qy][qx] (host pointers).
+ * x and y must be the linspace axes genZ produces (checked bit for bit). */
+int rtmi_field_from_samples(const double *x, int qx, const double *y, int qy, const double *Z,
+                            double delta, int dtype, void *stream, rtmi_field **out);
+int rtmi_field_dims(const rtmi_field *f, int *qx, int *qy);
+/* Copy the fp64 build products to host buffers (any may be NULL): axes, n samples, and the spline
+ * coefficients of GradX (=d/dy) and GradY (=d/dx), each [qy][qx] -- what get_coeffs() returns. */
+int rtmi_field_read(const rtmi_field *f, double *x, double *y, double *Z, double *coef_dy, double *coef_dx);
+/* n_gradient(vector, grd, z) (:141-156) for npts host points -> n, dn/dx, dn/dy (host buffers). */
+int rtmi_field_eval(const rtmi_field *f, int64_t npts, const double *x, const double *y,
+                    double *n, double *gx, double *gy);
+void rtmi_field_destroy(rtmi_field *f);
+
+/* -------------------------------------------------------------------- batch */
+typedef struct {
+    int32_t method;          /* 1..11 -> op1..op11 */
+    int32_t dtype;           /* must equal the field's dtype */
+    double gamma;            /* trazar's local gamma from constants() (:793) */
+    double gamma_step;       /* module-global gamma read by op10/op11 (:725, :758); normally == gamma */
+    double step;             /* DELTA_S */
+    int32_t max_size;        /* rows incl. row 0: int(ceil(s/step)+1) (:799) or N*divisor (:797) */
+    int32_t record_stride;   /* 0: keep no trajectory; s>=1: store rows i with i % s == 0 (1 = reference layout) */
+    int64_t rec_rows;        /* rows allocated for s_ray/n_ray (row r holds step r*stride); 0 -> derived from max_size */
+    double box[4];           /* limx_i, limx_s, limy_i, limy_s (:878) */
+    int32_t launch_mode;     /* 0: one lane per ray to completion; 1: persistent waves with lane refill */
+    int32_t block_size;      /* 0 -> default */
+    /* optional caller-owned DEVICE buffers (e.g. torch tensors); NULL -> the library allocates */
+    void *ext_s_ray;         /* [rec_rows][6][R] of dtype: x, y, p_x, p_y, T, theta (:802, :871-875) */
+    void *ext_n_ray;         /* [rec_rows][R]   of dtype: coef*n (:803, :873) */
+} rtmi_params;
+
+/* Upload R launch conditions (host pointers; x0/y0 per ray -- pos_x[k], -2 or the fisheye start, :809-813),
+ * run the initial conditions (:814-826) on the device and write row 0. */
+int rtmi_batch_create(const rtmi_field *f, const rtmi_params *p, int64_t R, const double *x0, const double *y0,
+                      const double *theta0, void *stream, rtmi_batch **out);
+/* Back to row 0 with the same launch conditions (re-runs the initial conditions; clears trajectories). */
+int rtmi_batch_reset(rtmi_batch *b);
+/* One launch that advances every live ray by at most nsteps DELTA_S steps (the body of the loop at :866-879;
+ * nsteps = 1 is exactly one call of selected_func + store_update_results per ray). */
+int rtmi_step(rtmi_batch *b, int32_t nsteps);
+/* Run every ray to termination (:866-879 to exhaustion/break). */
+int rtmi_run(rtmi_batch *b);
+/* Block until the batch's stream is idle. */
+int rtmi_sync(rtmi_batch *b);
+
+/* d_ray[3][R] (:801, :888-890): expected arclength, simulated arclength, last written row i. Host buffer, fp64. */
+int rtmi_read_d_ray(rtmi_batch *b, double *d_ray);
+/* final[9][R] fp64: x, y, theta, n, dn/dx, dn/dy, p_x, p_y, T of each ray's last written row. */
+int rtmi_read_final(rtmi_batch *b, double *final9);
+/* Copy recorded rows [row0, row0+nrows) to host as fp64: s_ray[nrows][6][R] and/or n_ray[nrows][R] (may be NULL). */
+int rtmi_read_rows(rtmi_batch *b, int64_t row0, int64_t nrows, double *s_ray, double *n_ray);
+
+typedef struct {
+    void *s_ray, *n_ray;                 /* device, dtype, layouts above */
+    void *x, *y, *theta, *n, *gx, *gy;   /* device SoA ray state, dtype, length R */
+    void *dist_sim, *dist_real, *T;
+    int32_t *istep;                      /* device, last written row per ray */
+    int64_t R, rec_rows;
+    int32_t dtype, record_stride;
+} rtmi_device_view;
+/* Raw device pointers for zero-copy consumers (torch / RCCL gather of the read-back). */
+int rtmi_batch_view(rtmi_batch *b, rtmi_device_view *v);
+
+typedef struct {
+    uint64_t ray_steps;      /* sum over rays of steps taken since create/reset */
+    uint64_t live_rays;      /* rays that would still step */
+    double kernel_ms;        /* sum of advance-kernel durations since create/reset (HIP events on the batch's stream) */
+    uint32_t launches;       /* advance-kernel launches since create/reset */
+    uint32_t vgprs, sgprs, lds_bytes;   /* of the advance kernel in use */
+} rtmi_stats;
+/* Synchronises the stream, then fills *s. */
+int rtmi_batch_stats(rtmi_batch *b, rtmi_stats *s);
+void rtmi_batch_destroy(rtmi_batch *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTMI_H */

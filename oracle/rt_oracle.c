@@ -1,0 +1,523 @@
+/*
+ * rt_oracle.c -- CPU restatement of neyuru/RayTracing's per-ray shooting-method
+ * propagation path (RT_bench.py: trazar -> opN -> n_gradient).
+ *
+ * THIS FILE IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The
+ * product path (raytracing_amd/ -> librtmi.so -> HIP kernels) never calls it.
+ *
+ * Parity status: PINNED.  Every function below is checked against golden
+ * vectors captured from the unmodified reference (oracle/gen_golden.py, run in
+ * the build container where /root/reference exists) -- tests/test_oracle_golden.py.
+ *
+ * Arithmetic notes (why some lines look odd).  The reference is scalar numpy
+ * on 2-element arrays.  To stay within an ulp of it this restatement keeps the
+ * reference's evaluation order and reproduces three library behaviours that
+ * were measured against numpy 2.2.6 / scipy 1.15.3 in the build container:
+ *   - np.dot / np.linalg.norm on 2-vectors round as fma(a1,b1, a0*b0)
+ *     (OpenBLAS ddot tail loop) -> DOT2 below;
+ *   - `x**2` on a numpy float64 scalar is libm pow(x, 2.0), not x*x -> SQ();
+ *   - np.sin/np.cos/np.sqrt equal glibc's; np.arctan2 and np.exp do not
+ *     (<= 1 ulp apart), so atan2-based methods match to ~1e-15, not bit for bit.
+ * Build with -ffp-contract=off so the compiler adds no fusions of its own.
+ *
+ * Third-party arithmetic restated here (absent from /root/reference):
+ *   scipy FITPACK (scipy 1.15.3 in the build container; README of the reference
+ *   lists 1.12.0; no lock file pins it): regrid with s=0 (interpolating
+ *   not-a-knot knots, fpregr.f/fpgrre.f), bispev/fpbisp/fpbspl evaluation;
+ *   numpy: linspace, meshgrid, gradient(edge_order=2).
+ *   Reference call sites: RT_bench.py:429-432 (grid), 450 (gradient),
+ *   455-457 (fits), 153-155 (evaluation).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdint.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define RTO_API __attribute__((visibility("default")))
+
+/* ---- constants: RT_bench.py:59-66 ---------------------------------------- */
+static const double THCK_PARAM = 0.005;                 /* :59 */
+static const double GOLD_TOL = 1.4901161193847656e-08;  /* sqrt(eps) = 2^-26, :66 */
+#define DELTA_G (M_PI / 2)                               /* :64 */
+static double gold_ratio(void) { return (sqrt(5.0) - 1.0) / 2.0; } /* :65 */
+
+static inline double SQ(double x) { return pow(x, 2.0); }           /* numpy scalar x**2 */
+static inline double DOT2(double a0, double a1, double b0, double b1) {
+    return fma(a1, b1, a0 * b0);                                    /* np.dot, 2 elements */
+}
+static inline double NORM2(double a0, double a1) { return sqrt(DOT2(a0, a1, a0, a1)); }
+
+/* ---- scenario fields: RT_bench.py:106-116 -------------------------------- */
+enum { SC_INTERFACE = 1, SC_FISHEYE = 2, SC_VERT = 3, SC_ANISO = 4 };
+
+static double scenario_n(int sc, double a, double b) {
+    switch (sc) {
+    case SC_INTERFACE: /* :107 */
+        return sqrt(2.0) - (sqrt(2.0) - 1.0) / (1.0 + exp(-b / THCK_PARAM));
+    case SC_FISHEYE:   /* :111, np.power(a,2) on arrays is an exact square */
+        return 1.0 / (1.0 + a * a + b * b);
+    default: {         /* :115-116, scenario 4 reuses it (:1579) */
+        double v = 18.0 + 2.0 * b;
+        return 1.0 / v;
+    }
+    }
+}
+
+/* anisotropy(theta, gamma): RT_bench.py:118-119 */
+static inline double anisotropy_sc(double s, double c, double gamma) {
+    return sqrt(SQ(gamma * s) + SQ(c));
+}
+
+/* ---- field ---------------------------------------------------------------- */
+typedef struct {
+    int qx, qy;
+    double *x, *y;       /* grid axes (genZ :429) */
+    double *Z;           /* [qy][qx] samples == bilinear coefficients (:455) */
+    double *cdy, *cdx;   /* bicubic coefficients of GradX (d/dy) and GradY (d/dx) (:456-457) */
+    double *tx3, *ty3;   /* cubic knot vectors, len qx+4 / qy+4 */
+    double *tx1, *ty1;   /* linear knot vectors, len qx+2 / qy+2 */
+} rto_field;
+
+/* numpy.linspace(a, b, n): y = arange(n)*step + a, y[-1] = b */
+static void np_linspace(double a, double b, int n, double *out) {
+    double step = (b - a) / (double)(n - 1);
+    for (int i = 0; i < n; i++) out[i] = (double)i * step + a;
+    out[n - 1] = b;
+}
+
+/* numpy.gradient(f, dx, edge_order=2) along one axis of a [n0][n1] array.
+ * axis 0: stride n1, axis 1: stride 1. */
+static void np_gradient_axis(const double *f, int n0, int n1, int axis, double dx, double *out) {
+    int n = axis == 0 ? n0 : n1, m = axis == 0 ? n1 : n0;
+    long sa = axis == 0 ? n1 : 1, sm = axis == 0 ? 1 : n1;
+    double a0 = -1.5 / dx, b0 = 2.0 / dx, c0 = -0.5 / dx;
+    double a1 = 0.5 / dx, b1 = -2.0 / dx, c1 = 1.5 / dx;
+    for (int j = 0; j < m; j++) {
+        const double *p = f + j * sm;
+        double *o = out + j * sm;
+        for (int i = 1; i < n - 1; i++) o[i * sa] = (p[(i + 1) * sa] - p[(i - 1) * sa]) / (2.0 * dx);
+        o[0] = a0 * p[0] + b0 * p[sa] + c0 * p[2 * sa];
+        o[(n - 1) * sa] = a1 * p[(n - 3) * sa] + b1 * p[(n - 2) * sa] + c1 * p[(n - 1) * sa];
+    }
+}
+
+/* FITPACK fpbspl: the k+1 non-zero B-splines of degree k at x, t[l] <= x < t[l+1]
+ * (l is the 0-based index of the interval's left knot). */
+static void fpbspl(const double *t, int k, double x, int l, double *h) {
+    double hh[6];
+    h[0] = 1.0;
+    for (int j = 1; j <= k; j++) {
+        for (int i = 0; i < j; i++) hh[i] = h[i];
+        h[0] = 0.0;
+        for (int i = 0; i < j; i++) {
+            int li = l + 1 + i, lj = li - j;
+            double f = hh[i] / (t[li] - t[lj]);
+            h[i] = h[i] + f * (t[li] - x);
+            h[i + 1] = f * (x - t[lj]);
+        }
+    }
+}
+
+/* interval search of fpbisp: clamp, then walk from l=k while x >= t[l+1]. n = knot count. */
+static int fp_interval(const double *t, int n, int k, double *x) {
+    double tb = t[k], te = t[n - k - 1];
+    if (*x < tb) *x = tb;
+    if (*x > te) *x = te;
+    int l = k;
+    while (*x >= t[l + 1] && l != n - k - 2) l++;
+    return l;
+}
+
+/* interpolating knots of regrid(s=0): fpregr.f -- k odd: t = [x0 x (k+1), x[(k+1)/2 .. m-1-(k+1)/2], x[m-1] x (k+1)] */
+static void interp_knots(const double *x, int m, int k, double *t) {
+    int n = m + k + 1, k3 = k / 2;
+    for (int i = 0; i <= k; i++) { t[i] = x[0]; t[n - 1 - i] = x[m - 1]; }
+    for (int i = k + 1, j = k3 + 1; i < n - k - 1; i++, j++) t[i] = x[j];
+}
+
+/* Solve the collocation system  sum_j c_j B_j(x_i) = d_i  (cubic, not-a-knot knots)
+ * for `nrhs` right-hand sides laid out with stride (rs between i, cs between rhs).
+ * The matrix has bandwidth 2/2; Gaussian elimination without pivoting (totally
+ * positive matrix).  Equals FITPACK's Givens-QR result to rounding (1.3e-15
+ * measured in SURVEY.md 8.a4 and pinned by tests/golden/field_*.npz). */
+static void collocation_solve(const double *x, int m, const double *t, double *d, long rs, long cs, int nrhs) {
+    /* band storage A[i][0..4] = columns i-2..i+2 */
+    double (*A)[5] = calloc((size_t)m, sizeof *A);
+    for (int i = 0; i < m; i++) {
+        double xv = x[i], h[4];
+        int l = fp_interval(t, m + 4, 3, &xv);
+        fpbspl(t, 3, xv, l, h);
+        for (int q = 0; q < 4; q++) {
+            int j = l - 3 + q, off = j - i + 2;
+            if (off >= 0 && off < 5) A[i][off] = h[q];
+            /* entries outside the band are exactly zero (B_{l}(t_l)=0) */
+        }
+    }
+    /* LU in place, no pivoting; L multipliers stored in A[i][0..1] */
+    for (int i = 0; i < m; i++) {
+        for (int r = i + 1; r <= i + 2 && r < m; r++) {
+            int off = i - r + 2; /* column i in row r */
+            double mlt = A[r][off] / A[i][2];
+            A[r][off] = mlt;
+            for (int q = 1; q <= 2; q++) {
+                if (off + q < 5) A[r][off + q] -= mlt * A[i][2 + q];
+            }
+        }
+    }
+    for (int r0 = 0; r0 < nrhs; r0++) {
+        double *b = d + r0 * cs;
+        for (int i = 0; i < m; i++) { /* forward */
+            double v = b[i * rs];
+            if (i >= 1) v -= A[i][1] * b[(i - 1) * rs];
+            if (i >= 2) v -= A[i][0] * b[(i - 2) * rs];
+            b[i * rs] = v;
+        }
+        for (int i = m - 1; i >= 0; i--) { /* back */
+            double v = b[i * rs];
+            if (i + 1 < m) v -= A[i][3] * b[(i + 1) * rs];
+            if (i + 2 < m) v -= A[i][4] * b[(i + 2) * rs];
+            b[i * rs] = v / A[i][2];
+        }
+    }
+    free(A);
+}
+
+RTO_API void rto_field_free(rto_field *f) {
+    if (!f) return;
+    free(f->x); free(f->y); free(f->Z); free(f->cdy); free(f->cdx);
+    free(f->tx3); free(f->ty3); free(f->tx1); free(f->ty1); free(f);
+}
+
+/* interpolacion(): RT_bench.py:435-464 (Hessian splines :459-462 are never read -> skipped) */
+RTO_API rto_field *rto_field_from_samples(const double *x, int qx, const double *y, int qy,
+                                          const double *Z, double delta) {
+    rto_field *f = calloc(1, sizeof *f);
+    size_t nz = (size_t)qx * qy;
+    f->qx = qx; f->qy = qy;
+    f->x = malloc(qx * sizeof(double)); memcpy(f->x, x, qx * sizeof(double));
+    f->y = malloc(qy * sizeof(double)); memcpy(f->y, y, qy * sizeof(double));
+    f->Z = malloc(nz * sizeof(double)); memcpy(f->Z, Z, nz * sizeof(double));
+    f->cdy = malloc(nz * sizeof(double)); f->cdx = malloc(nz * sizeof(double));
+    /* :450  GradX = d/d(axis0) = d/dy, GradY = d/d(axis1) = d/dx, both scaled by DELTA (quirk Q1) */
+    np_gradient_axis(Z, qy, qx, 0, delta, f->cdy);
+    np_gradient_axis(Z, qy, qx, 1, delta, f->cdx);
+    f->tx3 = malloc((qx + 4) * sizeof(double)); f->ty3 = malloc((qy + 4) * sizeof(double));
+    f->tx1 = malloc((qx + 2) * sizeof(double)); f->ty1 = malloc((qy + 2) * sizeof(double));
+    interp_knots(x, qx, 3, f->tx3); interp_knots(y, qy, 3, f->ty3);
+    interp_knots(x, qx, 1, f->tx1); interp_knots(y, qy, 1, f->ty1);
+    /* :456-457 separable interpolation: along axis 1 (x) for every row, then axis 0 (y) */
+    collocation_solve(x, qx, f->tx3, f->cdy, 1, qx, qy);
+    collocation_solve(y, qy, f->ty3, f->cdy, qx, 1, qx);
+    collocation_solve(x, qx, f->tx3, f->cdx, 1, qx, qy);
+    collocation_solve(y, qy, f->ty3, f->cdx, qx, 1, qx);
+    return f;
+}
+
+/* genZ(): RT_bench.py:412-433, then interpolacion() */
+RTO_API rto_field *rto_field_build(int scenario, double xi, double xs, double yi, double ys, double delta) {
+    int qx = (int)((xs - xi + 6) / delta + 1);  /* :426 */
+    int qy = (int)((ys - yi + 6) / delta + 1);  /* :427 */
+    double *x = malloc(qx * sizeof(double)), *y = malloc(qy * sizeof(double));
+    np_linspace(xi - 3, xs + 3, qx, x);         /* :429 */
+    np_linspace(yi - 3, ys + 3, qy, y);
+    double *Z = malloc((size_t)qx * qy * sizeof(double));
+    for (int i = 0; i < qy; i++)
+        for (int j = 0; j < qx; j++) Z[(size_t)i * qx + j] = scenario_n(scenario, x[j], y[i]); /* :430-432 */
+    rto_field *f = rto_field_from_samples(x, qx, y, qy, Z, delta);
+    free(x); free(y); free(Z);
+    return f;
+}
+
+RTO_API void rto_field_dims(const rto_field *f, int *qx, int *qy) { *qx = f->qx; *qy = f->qy; }
+RTO_API void rto_field_get(const rto_field *f, double *x, double *y, double *Z, double *cdy, double *cdx) {
+    size_t nz = (size_t)f->qx * f->qy;
+    if (x) memcpy(x, f->x, f->qx * sizeof(double));
+    if (y) memcpy(y, f->y, f->qy * sizeof(double));
+    if (Z) memcpy(Z, f->Z, nz * sizeof(double));
+    if (cdy) memcpy(cdy, f->cdy, nz * sizeof(double));
+    if (cdx) memcpy(cdx, f->cdx, nz * sizeof(double));
+}
+
+/* fpbisp single-point evaluation; first spline argument is y (splines are built (y, x, .), :455) */
+static double bisp_eval(const double *ty, int ny, const double *tx, int nx, const double *c, int k,
+                        double yv, double xv) {
+    double wy[4], wx[4];
+    int ly = fp_interval(ty, ny, k, &yv); fpbspl(ty, k, yv, ly, wy);
+    int lx = fp_interval(tx, nx, k, &xv); fpbspl(tx, k, xv, lx, wx);
+    int ncx = nx - k - 1;
+    double sp = 0.0;
+    for (int i1 = 0; i1 <= k; i1++)
+        for (int j1 = 0; j1 <= k; j1++)
+            sp += c[(size_t)(ly - k + i1) * ncx + (lx - k + j1)] * wy[i1] * wx[j1];
+    return sp;
+}
+
+/* n_gradient(vector, grd, z): RT_bench.py:141-156 -> (n, [dn/dx, dn/dy]) (quirks Q2-Q4) */
+RTO_API void rto_n_gradient(const rto_field *f, double x, double y, double *n, double *gx, double *gy) {
+    *n = bisp_eval(f->ty1, f->qy + 2, f->tx1, f->qx + 2, f->Z, 1, y, x);     /* :153 */
+    *gx = bisp_eval(f->ty3, f->qy + 4, f->tx3, f->qx + 4, f->cdx, 3, y, x);  /* :154 grd[1] */
+    *gy = bisp_eval(f->ty3, f->qy + 4, f->tx3, f->qx + 4, f->cdy, 3, y, x);  /* :155 grd[0] */
+}
+
+RTO_API void rto_n_gradient_many(const rto_field *f, int npts, const double *x, const double *y,
+                                 double *n, double *gx, double *gy) {
+    for (int i = 0; i < npts; i++) rto_n_gradient(f, x[i], y[i], n + i, gx + i, gy + i);
+}
+
+/* ---- one-step numerics ---------------------------------------------------- */
+typedef struct {
+    double x, y, theta, n, gx, gy, coef, ux, uy;
+    double mx, my;               /* momenta (output only) */
+    double dist_sim, dist_real, T, nray;
+    double hx[3], hy[3];         /* op7: previous positions, oldest first (VECTOR_LIST, Q11) */
+} rto_state;
+
+typedef struct {
+    const rto_field *f;
+    int method;                  /* 1..11 */
+    double gamma;                /* trazar's local gamma (:793) */
+    double gamma_step;           /* module-global gamma read by op10/op11 (Q12) */
+    double step, step2;          /* step, pow(step,2) */
+} rto_ctx;
+
+/* moment(): :217-230 ; o0/o1 as built in moments() :245 */
+static double moment_f(double n, double s, double c, double gamma, double o0, double o1) {
+    double coef = anisotropy_sc(s, c, gamma);
+    double g2m1 = gamma * gamma - 1.0; /* python int arithmetic, exact */
+    return n * coef * o0 * (1.0 + o1 * g2m1 / SQ(coef));
+}
+static void moments_f(double n, double s, double c, double ux, double uy, double gamma, double *mx, double *my) {
+    *mx = moment_f(n, s, c, gamma, ux, -SQ(uy));
+    *my = moment_f(n, s, c, gamma, uy, SQ(ux));
+}
+
+static inline double impulse_t(double a, double b, double step) { return step * (a + b) / 2.0; } /* :214 */
+
+/* golden(): :175-199 (Q13: both cost values recomputed every iteration) */
+typedef double (*cost_fn)(double, const void *);
+static double golden(cost_fn fn, const void *env, double a, double b) {
+    const double GR = gold_ratio();
+    double c = b - (b - a) * GR, d = a + (b - a) * GR;
+    while (fabs(c - d) > GOLD_TOL) {
+        if (fn(c, env) < fn(d, env)) b = d; else a = c;
+        c = b - (b - a) * GR;
+        d = a + (b - a) * GR;
+    }
+    return (b + a) / 2.0;
+}
+
+typedef struct { double fn, n, ux, uy, ix, iy; } iso_env;
+static double cost_iso(double t, const void *e_) { /* :595 / :697 */
+    const iso_env *e = e_;
+    return SQ(e->fn * cos(t) - e->n * e->ux - e->ix) + SQ(e->fn * sin(t) - e->n * e->uy - e->iy);
+}
+typedef struct { double fn, gamma, mix, miy, cgx, cgy, fgx, fgy, step; } aniso_env;
+static double cost_aniso(double t, const void *e_) { /* :728 / :761 */
+    const aniso_env *e = e_;
+    double s = sin(t), c = cos(t);
+    double a = anisotropy_sc(s, c, e->gamma);
+    double mx = moment_f(e->fn, s, c, e->gamma, c, -SQ(s));
+    double my = moment_f(e->fn, s, c, e->gamma, s, SQ(c));
+    return SQ(mx - e->mix - impulse_t(e->cgx, a * e->fgx, e->step)) +
+           SQ(my - e->miy - impulse_t(e->cgy, a * e->fgy, e->step));
+}
+
+/* advancement. returns flag for curvature_t (Q14: true == curvature NOT negligible) */
+static void adv_first(const rto_state *s, double step, double *fx, double *fy) { /* :312 */
+    *fx = s->x + s->ux * step; *fy = s->y + s->uy * step;
+}
+static void adv_second(const rto_state *s, const rto_ctx *c, double *fx, double *fy) { /* :330 */
+    double d = DOT2(s->gx, s->gy, s->ux, s->uy);
+    *fx = (s->x + s->ux * c->step) + (s->gx - d * s->ux) * c->step2 / (2.0 * s->n);
+    *fy = (s->y + s->uy * c->step) + (s->gy - d * s->uy) * c->step2 / (2.0 * s->n);
+}
+static int adv_curv(const rto_state *s, const rto_ctx *c, double *fx, double *fy) { /* :335-365 */
+    double d = DOT2(s->gx, s->gy, s->ux, s->uy);
+    double curv = NORM2(s->gx - d * s->ux, s->gy - d * s->uy) / s->n;
+    if (curv < GOLD_TOL) { adv_first(s, c->step, fx, fy); return 0; }
+    double dc = curv * c->step, th = s->theta;
+    if (s->gx * s->uy - s->gy * s->ux > 0) { /* np.cross 2-D, :360 */
+        *fx = s->x + (sin(th) - sin(th - dc)) / curv;
+        *fy = s->y + (cos(th - dc) - cos(th)) / curv;
+    } else {
+        *fx = s->x + (sin(th + dc) - sin(th)) / curv;
+        *fy = s->y + (-cos(th + dc) + cos(th)) / curv;
+    }
+    return 1;
+}
+/* angle determination */
+static double ang_rk2(const rto_state *s, double step, double fn, double fgx, double fgy) { /* :389-391 */
+    double k1 = step * (cos(s->theta) * s->gy - sin(s->theta) * s->gx) / s->n;
+    double k2 = step * (cos(s->theta + k1) * fgy - sin(s->theta + k1) * fgx) / fn;
+    return s->theta + (k1 + k2) / 2.0;
+}
+static double ang_cost(const rto_state *s, double step, double fgx, double fgy) { /* :407 */
+    return atan2(s->n * sin(s->theta) + impulse_t(s->gy, fgy, step),
+                 s->n * cos(s->theta) + impulse_t(s->gx, fgx, step));
+}
+static double ang_golden_iso(const rto_state *s, double step, double fn, double fgx, double fgy) {
+    iso_env e = { fn, s->n, s->ux, s->uy, impulse_t(s->gx, fgx, step), impulse_t(s->gy, fgy, step) };
+    return golden(cost_iso, &e, s->theta - DELTA_G, s->theta + DELTA_G);
+}
+static double ang_golden_aniso(const rto_state *s, const rto_ctx *c, double fn, double fgx, double fgy) {
+    double sn = sin(s->theta), cs = cos(s->theta), g = c->gamma_step;
+    aniso_env e;
+    e.fn = fn; e.gamma = g; e.step = c->step;
+    e.mix = moment_f(s->n, sn, cs, g, s->ux, -SQ(s->uy)); /* :725 / :758 */
+    e.miy = moment_f(s->n, sn, cs, g, s->uy, SQ(s->ux));
+    e.cgx = s->coef * s->gx; e.cgy = s->coef * s->gy; e.fgx = fgx; e.fgy = fgy;
+    return golden(cost_aniso, &e, s->theta - DELTA_G, s->theta + DELTA_G);
+}
+
+/* opN: RT_bench.py:469-764.  out: final position/angle/n/grad */
+static void op_step(const rto_ctx *c, const rto_state *s, double *fx, double *fy, double *fth,
+                    double *fn, double *fgx, double *fgy) {
+    int m = c->method, flag = 1;
+    switch (m) {
+    case 1: case 2: adv_first(s, c->step, fx, fy); break;
+    case 3: case 4: case 5: case 10: flag = adv_curv(s, c, fx, fy); break;
+    default: adv_second(s, c, fx, fy); break; /* 6,7,8,9,11 */
+    }
+    rto_n_gradient(c->f, *fx, *fy, fn, fgx, fgy);
+    switch (m) {
+    case 1: case 8: *fth = ang_cost(s, c->step, *fgx, *fgy); break;
+    case 2: case 6: *fth = ang_rk2(s, c->step, *fn, *fgx, *fgy); break;
+    case 3: *fth = flag ? ang_rk2(s, c->step, *fn, *fgx, *fgy) : s->theta; break;
+    case 4: *fth = flag ? ang_cost(s, c->step, *fgx, *fgy) : s->theta; break;
+    case 5: *fth = flag ? ang_golden_iso(s, c->step, *fn, *fgx, *fgy) : s->theta; break;
+    case 9: *fth = ang_golden_iso(s, c->step, *fn, *fgx, *fgy); break;
+    case 10: *fth = flag ? ang_golden_aniso(s, c, *fn, *fgx, *fgy) : s->theta; break;
+    case 11: *fth = ang_golden_aniso(s, c, *fn, *fgx, *fgy); break;
+    case 7: { /* :646-648 finite_diff :370-372 */
+        double vx = 11 * *fx - 18 * s->hx[2] + 9 * s->hx[1] - 2 * s->hx[0];
+        double vy = 11 * *fy - 18 * s->hy[2] + 9 * s->hy[1] - 2 * s->hy[0];
+        *fth = atan2(vy, vx);
+        break;
+    }
+    }
+}
+
+/* store_update_results (:783-790) + row bookkeeping (:871-875) */
+static void store_update(const rto_ctx *c, rto_state *s, double fx, double fy, double fth, double fn,
+                         double fgx, double fgy) {
+    double dist = NORM2(s->x - fx, s->y - fy);
+    s->dist_sim += dist;
+    s->dist_real += c->step;                                   /* Q16 */
+    double cs = cos(fth), sn = sin(fth);
+    double coef_f = anisotropy_sc(sn, cs, c->gamma);
+    moments_f(fn, sn, cs, cs, sn, c->gamma, &s->mx, &s->my);
+    /* op7 history shifts (VECTOR_LIST.pop(0) after append) */
+    s->hx[0] = s->hx[1]; s->hx[1] = s->hx[2]; s->hx[2] = fx;
+    s->hy[0] = s->hy[1]; s->hy[1] = s->hy[2]; s->hy[2] = fy;
+    s->x = fx; s->y = fy; s->theta = fth; s->n = fn; s->gx = fgx; s->gy = fgy;
+    s->coef = coef_f; s->ux = cs; s->uy = sn;
+    double nray = coef_f * fn;                                 /* :873 */
+    s->T = s->T + dist * (s->nray + nray) / 2.0;               /* :874, Q6 */
+    s->nray = nray;
+}
+
+static void state_init(const rto_ctx *c, rto_state *s, double x0, double y0, double th0) { /* :809-826 */
+    memset(s, 0, sizeof *s);
+    s->x = x0; s->y = y0; s->theta = th0;
+    s->ux = cos(th0); s->uy = sin(th0);
+    rto_n_gradient(c->f, x0, y0, &s->n, &s->gx, &s->gy);
+    s->coef = anisotropy_sc(s->uy, s->ux, c->gamma);
+    moments_f(s->n, s->uy, s->ux, s->ux, s->uy, c->gamma, &s->mx, &s->my);
+    s->nray = s->coef * s->n;
+    s->hx[2] = x0; s->hy[2] = y0;
+}
+
+/* Single step from an explicit state; used for the per-method fixtures.
+ * st[] = x,y,theta,n,gx,gy,coef ; hist[] = 3 previous positions (x0,y0,x1,y1,x2,y2, oldest first,
+ * the newest equals (x,y)); out[] = fx,fy,ftheta,fn,fgx,fgy */
+RTO_API void rto_single_step(const rto_field *f, int method, double gamma, double step,
+                             const double *st, const double *hist, double *out) {
+    rto_ctx c = { f, method, gamma, gamma, step, pow(step, 2.0) };
+    rto_state s; memset(&s, 0, sizeof s);
+    s.x = st[0]; s.y = st[1]; s.theta = st[2]; s.n = st[3]; s.gx = st[4]; s.gy = st[5]; s.coef = st[6];
+    s.ux = cos(s.theta); s.uy = sin(s.theta);
+    if (hist) for (int i = 0; i < 3; i++) { s.hx[i] = hist[2 * i]; s.hy[i] = hist[2 * i + 1]; }
+    op_step(&c, &s, out + 0, out + 1, out + 2, out + 3, out + 4, out + 5);
+}
+
+/* ---- trazar: RT_bench.py:766-948 ------------------------------------------ */
+typedef struct {
+    int method;
+    double gamma, gamma_step;
+    double step;
+    int max_size;            /* rows incl. row 0 (:797/:799) */
+    double box[4];           /* limx_i, limx_s, limy_i, limy_s */
+    int record_stride;       /* 0: no trajectory; s>=1: rows i with i % s == 0 plus nothing else */
+    long rec_rows;           /* rows allocated in s_ray/n_ray (recorded row r holds step r*stride) */
+    int nthreads;            /* OpenMP threads over rays (1 = the reference's sequential loop) */
+} rto_params;
+
+static inline void write_row(const rto_params *p, double *s_ray, double *n_ray, long R, long k, long i,
+                             const rto_state *s) {
+    if (!p->record_stride || i % p->record_stride) return;
+    long r = i / p->record_stride;
+    if (r >= p->rec_rows) return;
+    double *row = s_ray + (size_t)r * 6 * R;
+    row[0 * R + k] = s->x; row[1 * R + k] = s->y; row[2 * R + k] = s->mx; row[3 * R + k] = s->my;
+    row[4 * R + k] = s->T; row[5 * R + k] = s->theta;
+    if (n_ray) n_ray[(size_t)r * R + k] = s->nray;
+}
+
+/* final[] is [9][R]: x,y,theta,n,gx,gy,mx,my,T of the last written row; d_ray is [3][R] (:888-890) */
+RTO_API long rto_trazar(const rto_field *f, const rto_params *p, int R, const double *x0, const double *y0,
+                        const double *th0, double *s_ray, double *n_ray, double *d_ray, double *final) {
+    long total = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : total) num_threads(p->nthreads > 0 ? p->nthreads : 1)
+#endif
+    for (int k = 0; k < R; k++) {
+        rto_ctx c = { f, p->method, p->gamma, p->gamma_step, p->step, pow(p->step, 2.0) };
+        rto_state s;
+        state_init(&c, &s, x0[k], y0[k], th0[k]);
+        write_row(p, s_ray, n_ray, R, k, 0, &s);
+        long i = 0, loop_iter = 1;
+        double fx, fy, fth, fn, fgx, fgy;
+        if (p->method == 7) { /* :833-864 bootstrap, no boundary test */
+            loop_iter = 3;
+            for (i = 1; i <= 2 && i < p->max_size; i++) {
+                adv_second(&s, &c, &fx, &fy);
+                rto_n_gradient(f, fx, fy, &fn, &fgx, &fgy);
+                double vx, vy;
+                if (i == 1) { vx = fx - s.hx[2]; vy = fy - s.hy[2]; }               /* :843 */
+                else { vx = 3 * fx - 4 * s.hx[2] + s.hx[1]; vy = 3 * fy - 4 * s.hy[2] + s.hy[1]; } /* :856 */
+                fth = atan2(vy, vx);
+                store_update(&c, &s, fx, fy, fth, fn, fgx, fgy);
+                write_row(p, s_ray, n_ray, R, k, i, &s);
+            }
+            i = 2;
+        }
+        for (long it = loop_iter; it < p->max_size; it++) { /* :866 */
+            i = it;
+            op_step(&c, &s, &fx, &fy, &fth, &fn, &fgx, &fgy);
+            store_update(&c, &s, fx, fy, fth, fn, fgx, fgy);
+            write_row(p, s_ray, n_ray, R, k, i, &s);
+            if (s.x > p->box[1] || s.x < p->box[0] || s.y > p->box[3] || s.y < p->box[2]) break; /* :878 */
+        }
+        d_ray[0 * (size_t)R + k] = s.dist_real;
+        d_ray[1 * (size_t)R + k] = s.dist_sim;
+        d_ray[2 * (size_t)R + k] = (double)i;
+        if (final) {
+            double v[9] = { s.x, s.y, s.theta, s.n, s.gx, s.gy, s.mx, s.my, s.T };
+            for (int q = 0; q < 9; q++) final[(size_t)q * R + k] = v[q];
+        }
+        total += i;
+    }
+    return total;
+}
+
+RTO_API int rto_max_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

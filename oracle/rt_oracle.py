@@ -1,0 +1,127 @@
+"""ctypes binding of oracle/librt_oracle.so (the CPU restatement, rt_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: import this from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from raytracing_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librt_oracle.so")
+
+SCENARIOS = {"interface": 1, "fisheye": 2, "vert_heterogeneous": 3, "anisotropy": 4}
+
+_dp = C.POINTER(C.c_double)
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "rt_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "librt_oracle.so"])
+    return _SO
+
+
+class _Params(C.Structure):
+    _fields_ = [("method", C.c_int), ("gamma", C.c_double), ("gamma_step", C.c_double), ("step", C.c_double),
+                ("max_size", C.c_int), ("box", C.c_double * 4), ("record_stride", C.c_int),
+                ("rec_rows", C.c_long), ("nthreads", C.c_int)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        L.rto_field_build.restype = C.c_void_p
+        L.rto_field_build.argtypes = [C.c_int] + [C.c_double] * 5
+        L.rto_field_from_samples.restype = C.c_void_p
+        L.rto_field_from_samples.argtypes = [_dp, C.c_int, _dp, C.c_int, _dp, C.c_double]
+        L.rto_field_free.argtypes = [C.c_void_p]
+        L.rto_field_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.rto_field_get.argtypes = [C.c_void_p] + [_dp] * 5
+        L.rto_n_gradient_many.argtypes = [C.c_void_p, C.c_int] + [_dp] * 5
+        L.rto_single_step.argtypes = [C.c_void_p, C.c_int, C.c_double, C.c_double, _dp, _dp, _dp]
+        L.rto_trazar.restype = C.c_long
+        L.rto_trazar.argtypes = [C.c_void_p, C.POINTER(_Params), C.c_int] + [_dp] * 7
+        L.rto_max_threads.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(_dp) if a is not None else None
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Field:
+    """genZ + interpolacion (RT_bench.py:412-464) restated on the CPU."""
+
+    def __init__(self, scenario, limits, delta):
+        sc = SCENARIOS[scenario] if isinstance(scenario, str) else int(scenario)
+        self.h = lib().rto_field_build(sc, *[float(v) for v in limits], float(delta))
+        qx, qy = C.c_int(), C.c_int()
+        lib().rto_field_dims(self.h, C.byref(qx), C.byref(qy))
+        self.qx, self.qy = qx.value, qy.value
+
+    def arrays(self):
+        x = np.empty(self.qx); y = np.empty(self.qy)
+        Z = np.empty((self.qy, self.qx)); cdy = np.empty_like(Z); cdx = np.empty_like(Z)
+        lib().rto_field_get(self.h, _p(x), _p(y), _p(Z), _p(cdy), _p(cdx))
+        return x, y, Z, cdy, cdx
+
+    def n_gradient(self, x, y):
+        x = _f64(np.atleast_1d(x)); y = _f64(np.atleast_1d(y))
+        n = np.empty_like(x); gx = np.empty_like(x); gy = np.empty_like(x)
+        lib().rto_n_gradient_many(self.h, len(x), _p(x), _p(y), _p(n), _p(gx), _p(gy))
+        return n, gx, gy
+
+    def __del__(self):
+        if getattr(self, "h", None) and _lib is not None:
+            _lib.rto_field_free(self.h)
+            self.h = None
+
+
+def single_step(field, method, gamma, step, st, hist=None):
+    st = _f64(st); out = np.empty((st.shape[0], 6))
+    hist = _f64(hist) if hist is not None else None
+    for q in range(st.shape[0]):
+        lib().rto_single_step(field.h, method, float(gamma), float(step), _p(st[q]),
+                              _p(hist[q]) if hist is not None else None, _p(out[q]))
+    return out
+
+
+def trazar(field, method, gamma, step, max_size, box, x0, y0, theta0, record_stride=1, rec_rows=None,
+           nthreads=1, gamma_step=None, want_n_ray=False):
+    """RT_bench.py:766-948.  Returns dict(s_ray [rows,6,R] or None, n_ray, d_ray [3,R], final [9,R], steps)."""
+    th = _f64(theta0); R = len(th)
+    x0 = _f64(np.broadcast_to(x0, (R,))); y0 = _f64(np.broadcast_to(y0, (R,)))
+    p = _Params()
+    p.method = int(method); p.gamma = float(gamma)
+    p.gamma_step = float(gamma if gamma_step is None else gamma_step)
+    p.step = float(step); p.max_size = int(max_size)
+    for i in range(4):
+        p.box[i] = float(box[i])
+    p.record_stride = int(record_stride); p.nthreads = int(nthreads)
+    s_ray = n_ray = None
+    if record_stride:
+        rows = int(rec_rows) if rec_rows is not None else (int(max_size) + record_stride - 1) // record_stride
+        p.rec_rows = rows
+        s_ray = np.zeros((rows, 6, R))
+        n_ray = np.zeros((rows, R)) if want_n_ray else None
+    d_ray = np.zeros((3, R)); final = np.zeros((9, R))
+    steps = lib().rto_trazar(field.h, C.byref(p), R, _p(x0), _p(y0), _p(th), _p(s_ray), _p(n_ray), _p(d_ray),
+                             _p(final))
+    return dict(s_ray=s_ray, n_ray=n_ray, d_ray=d_ray, final=final, steps=int(steps))
+
+
+def max_threads():
+    return lib().rto_max_threads()

@@ -1,0 +1,751 @@
+// rtmi.hip -- librtmi.so: HIP kernels + C ABI (include/rtmi.h) for the ray propagation hot path.
+// gfx950 only.  Reference lines are RT_bench.py file:line of neyuru/RayTracing.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rtmi.h"
+#include "rt_device.h"
+
+#define RTMI_EXPORT extern "C" __attribute__((visibility("default")))
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(RTMI_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_) + " (" __FILE__ \
+                                          ":" + std::to_string(__LINE__) + ")");                        \
+    } while (0)
+#define ARG_TRY(cond, msg)                              \
+    do {                                                \
+        if (!(cond)) return fail(RTMI_ERR_ARG, (msg));  \
+    } while (0)
+
+// ------------------------------------------------------------------ handles
+struct rtmi_field {
+    int device = 0;
+    int dtype = RTMI_F64;
+    int qx = 0, qy = 0;
+    double ax = 0, hx = 0, bx = 0, ay = 0, hy = 0, by = 0;
+    // fp64 build products (kept for rtmi_field_read and as the source of the packed arrays)
+    double *dZ = nullptr, *dCdy = nullptr, *dCdx = nullptr;
+    // packed, dtype-typed arrays the trace kernels gather from
+    void *zn = nullptr, *g = nullptr;
+    hipStream_t stream = nullptr;
+};
+
+template <typename T> static rt::FieldDev<T> field_dev(const rtmi_field* f) {
+    rt::FieldDev<T> F;
+    F.zn = (const T*)f->zn;
+    F.g = (const T*)f->g;
+    F.qx = f->qx; F.qy = f->qy;
+    F.ax = (T)f->ax; F.hx = (T)f->hx; F.bx = (T)f->bx; F.inv_hx = (T)(1.0 / f->hx);
+    F.ay = (T)f->ay; F.hy = (T)f->hy; F.by = (T)f->by; F.inv_hy = (T)(1.0 / f->hy);
+    return F;
+}
+
+// ================================================================== field build kernels (fp64)
+__device__ static double scenario_n(int sc, double a, double b) {
+    if (sc == RTMI_INTERFACE)  // :107 (exp overflows to inf for y < -3.55, result sqrt(2): same as numpy)
+        return __dsqrt_rn(2.0) - (__dsqrt_rn(2.0) - 1.0) / (1.0 + exp(-b / 0.005));
+    if (sc == RTMI_FISHEYE)    // :111
+        return 1.0 / (__dadd_rn(__dadd_rn(1.0, __dmul_rn(a, a)), __dmul_rn(b, b)));
+    return 1.0 / __dadd_rn(18.0, __dmul_rn(2.0, b));  // :115-116
+}
+
+__global__ void k_sample(int sc, double* Z, int qx, int qy, double ax, double hx, double bx, double ay, double hy,
+                         double by) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= qx || i >= qy) return;
+    const double x = rt::axis_at<double>(j, qx, ax, hx, bx), y = rt::axis_at<double>(i, qy, ay, hy, by);
+    Z[(size_t)i * qx + j] = scenario_n(sc, x, y);  // meshgrid X[i,j]=x[j], Y[i,j]=y[i] (:430-432)
+}
+
+// np.gradient(Z, delta, edge_order=2) along one axis (:450); numpy's unfused evaluation order.
+__global__ void k_gradient(const double* Z, double* out, int qx, int qy, int axis, double dx) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= qx || i >= qy) return;
+    const int n = axis == 0 ? qy : qx, p = axis == 0 ? i : j;
+    const long s = axis == 0 ? qx : 1;
+    const double* c = Z + (size_t)i * qx + j;
+    double r;
+    if (p == 0) {
+        r = __dadd_rn(__dadd_rn(__dmul_rn(-1.5 / dx, c[0]), __dmul_rn(2.0 / dx, c[s])), __dmul_rn(-0.5 / dx, c[2 * s]));
+    } else if (p == n - 1) {
+        r = __dadd_rn(__dadd_rn(__dmul_rn(0.5 / dx, c[-2 * s]), __dmul_rn(-2.0 / dx, c[-s])), __dmul_rn(1.5 / dx, c[0]));
+    } else {
+        r = (c[s] - c[-s]) / (2.0 * dx);
+    }
+    out[(size_t)i * qx + j] = r;
+}
+
+// Banded (2/2) LU solve of the not-a-knot collocation system, one line per thread.
+// lu: [m][5] factors from the host (L multipliers in 0..1, U in 2..4).
+__global__ void k_solve_lines(double* d, int m, int nlines, long es, long ls, const double* lu) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nlines) return;
+    double* b = d + (size_t)t * ls;
+    double p1 = 0, p2 = 0;  // b[i-1], b[i-2]
+    for (int i = 0; i < m; i++) {
+        double v = b[(size_t)i * es];
+        if (i >= 1) v -= lu[i * 5 + 1] * p1;
+        if (i >= 2) v -= lu[i * 5 + 0] * p2;
+        b[(size_t)i * es] = v;
+        p2 = p1; p1 = v;
+    }
+    double n1 = 0, n2 = 0;  // b[i+1], b[i+2]
+    for (int i = m - 1; i >= 0; i--) {
+        double v = b[(size_t)i * es];
+        if (i + 1 < m) v -= lu[i * 5 + 3] * n1;
+        if (i + 2 < m) v -= lu[i * 5 + 4] * n2;
+        v = v / lu[i * 5 + 2];
+        b[(size_t)i * es] = v;
+        n2 = n1; n1 = v;
+    }
+}
+
+template <typename T> __global__ void k_pack(const double* Z, const double* cdy, const double* cdx, T* zn, T* g, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    zn[i] = (T)Z[i];
+    g[2 * i] = (T)cdx[i];      // d/dx spline = grd[1] (:154)
+    g[2 * i + 1] = (T)cdy[i];  // d/dy spline = grd[0] (:155)
+}
+
+template <typename T>
+__global__ void k_field_eval(rt::FieldDev<T> F, long npts, const double* x, const double* y, double* n, double* gx,
+                             double* gy) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npts) return;
+    T a, b, c;
+    rt::n_gradient<T>(F, (T)x[i], (T)y[i], a, b, c);
+    n[i] = a; gx[i] = b; gy[i] = c;
+}
+
+// ------------------------------------------------------------------ host side of the field build
+namespace {
+// FITPACK fpbspl (k=3) on the host, for the collocation matrix only.
+void host_bspl3(const std::vector<double>& t, double x, int l, double h[4]) {
+    double hh[4];
+    h[0] = 1.0;
+    for (int j = 1; j <= 3; j++) {
+        for (int i = 0; i < j; i++) hh[i] = h[i];
+        h[0] = 0.0;
+        for (int i = 0; i < j; i++) {
+            const int li = l + 1 + i, lj = li - j;
+            const double f = hh[i] / (t[li] - t[lj]);
+            h[i] = h[i] + f * (t[li] - x);
+            h[i + 1] = f * (x - t[lj]);
+        }
+    }
+}
+// LU factors ([m][5]) of the collocation matrix of the interpolating cubic on axis x (not-a-knot knots).
+std::vector<double> collocation_lu(const std::vector<double>& x) {
+    const int m = (int)x.size();
+    std::vector<double> t(m + 4);
+    for (int i = 0; i <= 3; i++) { t[i] = x[0]; t[m + 3 - i] = x[m - 1]; }
+    for (int i = 4, j = 2; i < m; i++, j++) t[i] = x[j];
+    std::vector<double> A((size_t)m * 5, 0.0);
+    for (int i = 0; i < m; i++) {
+        int l = 3;
+        while (x[i] >= t[l + 1] && l != m - 1) l++;
+        double h[4];
+        host_bspl3(t, x[i], l, h);
+        for (int q = 0; q < 4; q++) {
+            const int off = (l - 3 + q) - i + 2;
+            if (off >= 0 && off < 5) A[(size_t)i * 5 + off] = h[q];
+        }
+    }
+    for (int i = 0; i < m; i++)
+        for (int r = i + 1; r <= i + 2 && r < m; r++) {
+            const int off = i - r + 2;
+            const double mlt = A[(size_t)r * 5 + off] / A[(size_t)i * 5 + 2];
+            A[(size_t)r * 5 + off] = mlt;
+            for (int q = 1; q <= 2; q++)
+                if (off + q < 5) A[(size_t)r * 5 + off + q] -= mlt * A[(size_t)i * 5 + 2 + q];
+        }
+    return A;
+}
+std::vector<double> linspace(double a, double b, int n) {
+    std::vector<double> v(n);
+    const double step = (b - a) / (double)(n - 1);
+    for (int i = 0; i < n; i++) v[i] = (double)i * step + a;
+    v[n - 1] = b;
+    return v;
+}
+}  // namespace
+
+static int field_finish(rtmi_field* f, double delta) {
+    const int qx = f->qx, qy = f->qy;
+    const size_t nz = (size_t)qx * qy;
+    hipStream_t st = f->stream;
+    HIP_TRY(hipMalloc(&f->dCdy, nz * sizeof(double)));
+    HIP_TRY(hipMalloc(&f->dCdx, nz * sizeof(double)));
+    dim3 blk(256), grd((qx + 255) / 256, qy);
+    hipLaunchKernelGGL(k_gradient, grd, blk, 0, st, f->dZ, f->dCdy, qx, qy, 0, delta);  // GradX = d/dy (Q2)
+    hipLaunchKernelGGL(k_gradient, grd, blk, 0, st, f->dZ, f->dCdx, qx, qy, 1, delta);  // GradY = d/dx
+    HIP_TRY(hipGetLastError());
+    // separable not-a-knot interpolation (:456-457): along x for every row, then along y for every column
+    const std::vector<double> lux = collocation_lu(linspace(f->ax, f->bx, qx));
+    const std::vector<double> luy = collocation_lu(linspace(f->ay, f->by, qy));
+    double *dlux = nullptr, *dluy = nullptr;
+    HIP_TRY(hipMalloc(&dlux, lux.size() * sizeof(double)));
+    HIP_TRY(hipMalloc(&dluy, luy.size() * sizeof(double)));
+    HIP_TRY(hipMemcpyAsync(dlux, lux.data(), lux.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(dluy, luy.data(), luy.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    for (double* c : {f->dCdy, f->dCdx}) {
+        hipLaunchKernelGGL(k_solve_lines, dim3((qy + 63) / 64), dim3(64), 0, st, c, qx, qy, 1L, (long)qx, dlux);
+        hipLaunchKernelGGL(k_solve_lines, dim3((qx + 63) / 64), dim3(64), 0, st, c, qy, qx, (long)qx, 1L, dluy);
+    }
+    HIP_TRY(hipGetLastError());
+    const size_t esz = f->dtype == RTMI_F64 ? 8 : 4;
+    HIP_TRY(hipMalloc(&f->zn, nz * esz));
+    HIP_TRY(hipMalloc(&f->g, 2 * nz * esz));
+    if (f->dtype == RTMI_F64)
+        hipLaunchKernelGGL(k_pack<double>, dim3((nz + 255) / 256), dim3(256), 0, st, f->dZ, f->dCdy, f->dCdx,
+                           (double*)f->zn, (double*)f->g, nz);
+    else
+        hipLaunchKernelGGL(k_pack<float>, dim3((nz + 255) / 256), dim3(256), 0, st, f->dZ, f->dCdy, f->dCdx,
+                           (float*)f->zn, (float*)f->g, nz);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));  // host vectors / LU buffers go out of scope
+    HIP_TRY(hipFree(dlux));
+    HIP_TRY(hipFree(dluy));
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_abi_version(void) { return RTMI_ABI_VERSION; }
+RTMI_EXPORT const char* rtmi_last_error(void) { return g_err.c_str(); }
+RTMI_EXPORT int rtmi_set_device(int device) {
+    HIP_TRY(hipSetDevice(device));
+    return RTMI_OK;
+}
+RTMI_EXPORT int rtmi_device_count(int* count) {
+    ARG_TRY(count, "rtmi_device_count: null");
+    HIP_TRY(hipGetDeviceCount(count));
+    return RTMI_OK;
+}
+
+RTMI_EXPORT void rtmi_field_destroy(rtmi_field* f) {
+    if (!f) return;
+    (void)hipFree(f->dZ); (void)hipFree(f->dCdy); (void)hipFree(f->dCdx); (void)hipFree(f->zn); (void)hipFree(f->g);
+    delete f;
+}
+
+static int field_alloc(int dtype, int qx, int qy, void* stream, rtmi_field** out) {
+    ARG_TRY(out, "field: out is null");
+    ARG_TRY(dtype == RTMI_F64 || dtype == RTMI_F32, "field: dtype must be RTMI_F64 or RTMI_F32");
+    ARG_TRY(qx >= 8 && qy >= 8, "field: grid must be at least 8x8 (cubic not-a-knot fit)");
+    ARG_TRY((size_t)qx * qy < (1ull << 31), "field: grid too large");
+    rtmi_field* f = new (std::nothrow) rtmi_field();
+    if (!f) return fail(RTMI_ERR_ALLOC, "field: host allocation failed");
+    f->dtype = dtype; f->qx = qx; f->qy = qy; f->stream = (hipStream_t)stream;
+    *out = f;
+    HIP_TRY(hipGetDevice(&f->device));
+    HIP_TRY(hipMalloc(&f->dZ, (size_t)qx * qy * sizeof(double)));
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_field_build(int scenario, double xi, double xs, double yi, double ys, double delta, int dtype,
+                                 void* stream, rtmi_field** out) {
+    ARG_TRY(scenario >= RTMI_INTERFACE && scenario <= RTMI_ANISOTROPY, "rtmi_field_build: scenario must be 1..4");
+    ARG_TRY(delta > 0 && xs > xi && ys > yi, "rtmi_field_build: need delta > 0 and xs > xi, ys > yi");
+    const int qx = (int)((xs - xi + 6) / delta + 1);  // :426
+    const int qy = (int)((ys - yi + 6) / delta + 1);  // :427
+    rtmi_field* f = nullptr;
+    int rc = field_alloc(dtype, qx, qy, stream, &f);
+    if (rc) { rtmi_field_destroy(f); return rc; }
+    f->ax = xi - 3; f->bx = xs + 3; f->hx = (f->bx - f->ax) / (double)(qx - 1);  // :429 linspace
+    f->ay = yi - 3; f->by = ys + 3; f->hy = (f->by - f->ay) / (double)(qy - 1);
+    hipLaunchKernelGGL(k_sample, dim3((qx + 255) / 256, qy), dim3(256), 0, f->stream, scenario, f->dZ, qx, qy, f->ax,
+                       f->hx, f->bx, f->ay, f->hy, f->by);
+    rc = field_finish(f, delta);
+    if (rc) { rtmi_field_destroy(f); return rc; }
+    *out = f;
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_field_from_samples(const double* x, int qx, const double* y, int qy, const double* Z, double delta,
+                                        int dtype, void* stream, rtmi_field** out) {
+    ARG_TRY(x && y && Z, "rtmi_field_from_samples: null input");
+    ARG_TRY(delta > 0, "rtmi_field_from_samples: delta must be > 0");
+    ARG_TRY(qx >= 8 && qy >= 8, "rtmi_field_from_samples: grid must be at least 8x8");
+    const std::vector<double> lx = linspace(x[0], x[qx - 1], qx), ly = linspace(y[0], y[qy - 1], qy);
+    if (memcmp(lx.data(), x, qx * sizeof(double)) || memcmp(ly.data(), y, qy * sizeof(double)))
+        return fail(RTMI_ERR_UNSUPPORTED, "rtmi_field_from_samples: axes must be numpy.linspace grids (genZ, RT_bench.py:429)");
+    rtmi_field* f = nullptr;
+    int rc = field_alloc(dtype, qx, qy, stream, &f);
+    if (rc) { rtmi_field_destroy(f); return rc; }
+    f->ax = x[0]; f->bx = x[qx - 1]; f->hx = (f->bx - f->ax) / (double)(qx - 1);
+    f->ay = y[0]; f->by = y[qy - 1]; f->hy = (f->by - f->ay) / (double)(qy - 1);
+    hipError_t e = hipMemcpyAsync(f->dZ, Z, (size_t)qx * qy * sizeof(double), hipMemcpyHostToDevice, f->stream);
+    if (e != hipSuccess) { rtmi_field_destroy(f); return fail(RTMI_ERR_HIP, hipGetErrorString(e)); }
+    rc = field_finish(f, delta);
+    if (rc) { rtmi_field_destroy(f); return rc; }
+    *out = f;
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_field_dims(const rtmi_field* f, int* qx, int* qy) {
+    ARG_TRY(f && qx && qy, "rtmi_field_dims: null");
+    *qx = f->qx; *qy = f->qy;
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_field_read(const rtmi_field* f, double* x, double* y, double* Z, double* cdy, double* cdx) {
+    ARG_TRY(f, "rtmi_field_read: null field");
+    const size_t nz = (size_t)f->qx * f->qy * sizeof(double);
+    HIP_TRY(hipStreamSynchronize(f->stream));
+    if (x) { auto v = linspace(f->ax, f->bx, f->qx); memcpy(x, v.data(), v.size() * sizeof(double)); }
+    if (y) { auto v = linspace(f->ay, f->by, f->qy); memcpy(y, v.data(), v.size() * sizeof(double)); }
+    if (Z) HIP_TRY(hipMemcpy(Z, f->dZ, nz, hipMemcpyDeviceToHost));
+    if (cdy) HIP_TRY(hipMemcpy(cdy, f->dCdy, nz, hipMemcpyDeviceToHost));
+    if (cdx) HIP_TRY(hipMemcpy(cdx, f->dCdx, nz, hipMemcpyDeviceToHost));
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_field_eval(const rtmi_field* f, int64_t npts, const double* x, const double* y, double* n,
+                                double* gx, double* gy) {
+    ARG_TRY(f && x && y && n && gx && gy, "rtmi_field_eval: null");
+    ARG_TRY(npts >= 0, "rtmi_field_eval: npts < 0");
+    if (npts == 0) return RTMI_OK;
+    double* d = nullptr;
+    const size_t nb = (size_t)npts * sizeof(double);
+    HIP_TRY(hipMalloc(&d, 5 * nb));
+    hipStream_t st = f->stream;
+    int rc = RTMI_OK;
+    do {
+        if (hipMemcpyAsync(d, x, nb, hipMemcpyHostToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d + npts, y, nb, hipMemcpyHostToDevice, st) != hipSuccess) { rc = RTMI_ERR_HIP; break; }
+        const dim3 g((unsigned)((npts + 255) / 256)), b(256);
+        if (f->dtype == RTMI_F64)
+            hipLaunchKernelGGL(k_field_eval<double>, g, b, 0, st, field_dev<double>(f), (long)npts, d, d + npts,
+                               d + 2 * npts, d + 3 * npts, d + 4 * npts);
+        else
+            hipLaunchKernelGGL(k_field_eval<float>, g, b, 0, st, field_dev<float>(f), (long)npts, d, d + npts,
+                               d + 2 * npts, d + 3 * npts, d + 4 * npts);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = RTMI_ERR_HIP; break; }
+        if (hipMemcpy(n, d + 2 * npts, nb, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(gx, d + 3 * npts, nb, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(gy, d + 4 * npts, nb, hipMemcpyDeviceToHost) != hipSuccess) rc = RTMI_ERR_HIP;
+    } while (0);
+    (void)hipFree(d);
+    if (rc) return fail(rc, "rtmi_field_eval: HIP failure");
+    return RTMI_OK;
+}
+
+// ================================================================== ray batch
+template <typename T> struct BatchDev {
+    rt::FieldDev<T> F;
+    rt::Consts<T> K;
+    long R;
+    int max_size;
+    int stride;       // record stride (0 = none)
+    long rec_rows;
+    // SoA state
+    T *x, *y, *th, *n, *gx, *gy, *dsim, *dreal, *tt;
+    T* hist;          // [4][R] (op7 only): hx0, hy0, hx1, hy1
+    int* istep;
+    unsigned char* alive;
+    T *s_ray, *n_ray;
+    unsigned long long* counters;  // [0] ray-steps, [1] live rays (recomputed per launch)
+    const double *x0, *y0, *th0;   // launch conditions (device, fp64)
+};
+
+template <typename T> __device__ __forceinline__ void write_row(const BatchDev<T>& a, long row, long k, const rt::Ray<T>& r) {
+    T* p = a.s_ray + (size_t)row * 6 * a.R + k;
+    p[0] = r.x; p[a.R] = r.y; p[2 * a.R] = r.mx; p[3 * a.R] = r.my; p[4 * a.R] = r.tt; p[5 * a.R] = r.th;
+    if (a.n_ray) a.n_ray[(size_t)row * a.R + k] = r.nray;
+}
+
+// initial conditions (:809-826): one lane per ray
+template <typename T> __global__ void k_init(BatchDev<T> a) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.R) return;
+    rt::Ray<T> r;
+    r.x = (T)a.x0[k]; r.y = (T)a.y0[k]; r.th = (T)a.th0[k];
+    rt::n_gradient<T>(a.F, r.x, r.y, r.n, r.gx, r.gy);
+    rt::derive<T>(a.K, r);
+    r.dsim = 0; r.dreal = 0; r.tt = 0;
+    a.x[k] = r.x; a.y[k] = r.y; a.th[k] = r.th; a.n[k] = r.n; a.gx[k] = r.gx; a.gy[k] = r.gy;
+    a.dsim[k] = 0; a.dreal[k] = 0; a.tt[k] = 0;
+    if (a.hist) { a.hist[k] = 0; a.hist[a.R + k] = 0; a.hist[2 * a.R + k] = 0; a.hist[3 * a.R + k] = 0; }
+    a.istep[k] = 0;
+    a.alive[k] = a.max_size > 1;
+    if (a.stride && a.rec_rows > 0) write_row(a, 0, k, r);
+}
+
+__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// The loop at :866-879: one lane per ray, state in registers for up to nsteps DELTA_S steps.
+template <typename T, int METHOD, bool RECORD>
+__global__ __launch_bounds__(256) void k_advance(BatchDev<T> a, int nsteps) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned done = 0, live = 0;
+    if (k < a.R && a.alive[k]) {
+        rt::Ray<T> r;
+        r.x = a.x[k]; r.y = a.y[k]; r.th = a.th[k]; r.n = a.n[k]; r.gx = a.gx[k]; r.gy = a.gy[k];
+        r.dsim = a.dsim[k]; r.dreal = a.dreal[k]; r.tt = a.tt[k];
+        if (METHOD == 7) { r.hx0 = a.hist[k]; r.hy0 = a.hist[a.R + k]; r.hx1 = a.hist[2 * a.R + k]; r.hy1 = a.hist[3 * a.R + k]; }
+        else { r.hx0 = r.hy0 = r.hx1 = r.hy1 = 0; }
+        rt::derive<T>(a.K, r);
+        int i = a.istep[k];
+        int until = RECORD ? a.stride - (i % a.stride) : 0;  // steps until the next recorded row
+        long row = RECORD ? i / a.stride : 0;
+        bool alive = true;
+        for (int it = 0; it < nsteps && alive; ++it) {
+            ++i;
+            alive = rt::ray_step<T, METHOD>(a.F, a.K, r, i);
+            if (RECORD) {
+                if (--until == 0) {
+                    until = a.stride;
+                    ++row;
+                    if (row < a.rec_rows) write_row(a, row, k, r);
+                }
+            }
+            alive = alive && (i + 1 < a.max_size);
+            ++done;
+        }
+        a.x[k] = r.x; a.y[k] = r.y; a.th[k] = r.th; a.n[k] = r.n; a.gx[k] = r.gx; a.gy[k] = r.gy;
+        a.dsim[k] = r.dsim; a.dreal[k] = r.dreal; a.tt[k] = r.tt;
+        if (METHOD == 7) { a.hist[k] = r.hx0; a.hist[a.R + k] = r.hy0; a.hist[2 * a.R + k] = r.hx1; a.hist[3 * a.R + k] = r.hy1; }
+        a.istep[k] = i;
+        a.alive[k] = alive;
+        live = alive;
+    }
+    done = wave_sum(done);
+    live = wave_sum(live);
+    if ((threadIdx.x & 63) == 0) {
+        if (done) atomicAdd(&a.counters[0], (unsigned long long)done);
+        if (live) atomicAdd(&a.counters[1], (unsigned long long)live);
+    }
+}
+
+template <typename T> __global__ void k_pack_d_ray(BatchDev<T> a, double* out) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.R) return;
+    out[k] = (double)a.dreal[k]; out[a.R + k] = (double)a.dsim[k]; out[2 * a.R + k] = (double)a.istep[k];  // :888-890
+}
+template <typename T> __global__ void k_pack_final(BatchDev<T> a, double* out) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.R) return;
+    rt::Ray<T> r;
+    r.x = a.x[k]; r.y = a.y[k]; r.th = a.th[k]; r.n = a.n[k]; r.gx = a.gx[k]; r.gy = a.gy[k]; r.tt = a.tt[k];
+    rt::derive<T>(a.K, r);
+    const double v[9] = {(double)r.x, (double)r.y, (double)r.th, (double)r.n, (double)r.gx, (double)r.gy,
+                         (double)r.mx, (double)r.my, (double)r.tt};
+#pragma unroll
+    for (int q = 0; q < 9; q++) out[(size_t)q * a.R + k] = v[q];
+}
+__global__ void k_f32_to_f64(const float* in, double* out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (double)in[i];
+}
+
+struct rtmi_batch {
+    const rtmi_field* field = nullptr;
+    rtmi_params p{};
+    int64_t R = 0;
+    size_t esz = 8;
+    hipStream_t stream = nullptr;
+    void* state = nullptr;       // one slab: 9 (+4) dtype arrays
+    int* istep = nullptr;
+    unsigned char* alive = nullptr;
+    void *s_ray = nullptr, *n_ray = nullptr;
+    bool own_s = false, own_n = false;
+    double* launch = nullptr;    // [3][R] x0, y0, theta0
+    unsigned long long* counters = nullptr;  // device [2]
+    unsigned long long* h_counters = nullptr;  // pinned host [2]
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    size_t ev_used = 0;
+    double kernel_ms = 0;
+    uint32_t launches = 0;
+    const void* kfn = nullptr;
+};
+
+template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
+    BatchDev<T> a;
+    a.F = field_dev<T>(b->field);
+    const rtmi_params& p = b->p;
+    a.K.step = (T)p.step;
+    a.K.step2 = (T)std::pow(p.step, 2.0);  // numpy scalar step**2 is libm pow (:330)
+    a.K.gamma = (T)p.gamma; a.K.g2m1 = (T)(p.gamma * p.gamma - 1.0);
+    a.K.gamma_s = (T)p.gamma_step; a.K.g2m1_s = (T)(p.gamma_step * p.gamma_step - 1.0);
+    for (int i = 0; i < 4; i++) a.K.box[i] = (T)p.box[i];
+    a.R = b->R; a.max_size = p.max_size; a.stride = p.record_stride; a.rec_rows = p.rec_rows;
+    T* s = (T*)b->state;
+    const size_t R = (size_t)b->R;
+    a.x = s; a.y = s + R; a.th = s + 2 * R; a.n = s + 3 * R; a.gx = s + 4 * R; a.gy = s + 5 * R;
+    a.dsim = s + 6 * R; a.dreal = s + 7 * R; a.tt = s + 8 * R;
+    a.hist = p.method == 7 ? s + 9 * R : nullptr;
+    a.istep = b->istep; a.alive = b->alive;
+    a.s_ray = (T*)b->s_ray; a.n_ray = (T*)b->n_ray;
+    a.counters = b->counters;
+    a.x0 = b->launch; a.y0 = b->launch + R; a.th0 = b->launch + 2 * R;
+    return a;
+}
+
+template <typename T, bool RECORD> static const void* advance_fn(int m) {
+    switch (m) {
+#define CASE_(M) case M: return (const void*)k_advance<T, M, RECORD>;
+        CASE_(1) CASE_(2) CASE_(3) CASE_(4) CASE_(5) CASE_(6) CASE_(7) CASE_(8) CASE_(9) CASE_(10) CASE_(11)
+#undef CASE_
+    }
+    return nullptr;
+}
+static const void* pick_advance(const rtmi_batch* b) {
+    const bool rec = b->p.record_stride > 0;
+    if (b->p.dtype == RTMI_F64) return rec ? advance_fn<double, true>(b->p.method) : advance_fn<double, false>(b->p.method);
+    return rec ? advance_fn<float, true>(b->p.method) : advance_fn<float, false>(b->p.method);
+}
+
+static int batch_init_state(rtmi_batch* b) {
+    hipStream_t st = b->stream;
+    const size_t R = (size_t)b->R;
+    HIP_TRY(hipMemsetAsync(b->counters, 0, 2 * sizeof(unsigned long long), st));
+    if (b->s_ray) HIP_TRY(hipMemsetAsync(b->s_ray, 0, (size_t)b->p.rec_rows * 6 * R * b->esz, st));  // np.zeros (:802)
+    if (b->n_ray) HIP_TRY(hipMemsetAsync(b->n_ray, 0, (size_t)b->p.rec_rows * R * b->esz, st));
+    const dim3 g((unsigned)((R + 255) / 256)), blk(256);
+    if (b->p.dtype == RTMI_F64) hipLaunchKernelGGL(k_init<double>, g, blk, 0, st, batch_dev<double>(b));
+    else hipLaunchKernelGGL(k_init<float>, g, blk, 0, st, batch_dev<float>(b));
+    HIP_TRY(hipGetLastError());
+    b->kernel_ms = 0; b->launches = 0; b->ev_used = 0;
+    return RTMI_OK;
+}
+
+RTMI_EXPORT void rtmi_batch_destroy(rtmi_batch* b) {
+    if (!b) return;
+    (void)hipStreamSynchronize(b->stream);
+    (void)hipFree(b->state); (void)hipFree(b->istep); (void)hipFree(b->alive); (void)hipFree(b->launch);
+    (void)hipFree(b->counters);
+    if (b->h_counters) (void)hipHostFree(b->h_counters);
+    if (b->own_s) (void)hipFree(b->s_ray);
+    if (b->own_n) (void)hipFree(b->n_ray);
+    for (auto& e : b->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    delete b;
+}
+
+RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int64_t R, const double* x0,
+                                  const double* y0, const double* theta0, void* stream, rtmi_batch** out) {
+    ARG_TRY(f && p && x0 && y0 && theta0 && out, "rtmi_batch_create: null argument");
+    ARG_TRY(R > 0 && R < (1ll << 31), "rtmi_batch_create: R must be in [1, 2^31)");
+    ARG_TRY(p->method >= RTMI_OP_MIN && p->method <= RTMI_OP_MAX, "rtmi_batch_create: method must be 1..11");
+    ARG_TRY(p->dtype == f->dtype, "rtmi_batch_create: params.dtype differs from the field's dtype");
+    ARG_TRY(p->step > 0 && std::isfinite(p->step), "rtmi_batch_create: step must be finite and > 0");
+    ARG_TRY(p->gamma > 0 && p->gamma_step > 0, "rtmi_batch_create: gamma must be > 0");
+    ARG_TRY(p->max_size >= 2, "rtmi_batch_create: max_size must be >= 2");
+    ARG_TRY(p->method != 7 || p->max_size >= 4, "rtmi_batch_create: op7 needs max_size >= 4 (two bootstrap rows)");
+    ARG_TRY(p->record_stride >= 0, "rtmi_batch_create: record_stride < 0");
+    ARG_TRY(p->box[1] > p->box[0] && p->box[3] > p->box[2], "rtmi_batch_create: empty box");
+    ARG_TRY(p->launch_mode == 0, "rtmi_batch_create: unknown launch_mode");
+    rtmi_batch* b = new (std::nothrow) rtmi_batch();
+    if (!b) return fail(RTMI_ERR_ALLOC, "rtmi_batch_create: host allocation failed");
+    b->field = f; b->p = *p; b->R = R; b->esz = p->dtype == RTMI_F64 ? 8 : 4; b->stream = (hipStream_t)stream;
+    if (b->p.record_stride > 0 && b->p.rec_rows <= 0)
+        b->p.rec_rows = ((int64_t)p->max_size + p->record_stride - 1) / p->record_stride;
+    if (b->p.record_stride == 0) b->p.rec_rows = 0;
+    int rc = RTMI_OK;
+    auto body = [&]() -> int {
+        const size_t Rz = (size_t)R;
+        const int narr = p->method == 7 ? 13 : 9;
+        HIP_TRY(hipMalloc(&b->state, narr * Rz * b->esz));
+        HIP_TRY(hipMalloc(&b->istep, Rz * sizeof(int)));
+        HIP_TRY(hipMalloc(&b->alive, Rz));
+        HIP_TRY(hipMalloc(&b->launch, 3 * Rz * sizeof(double)));
+        HIP_TRY(hipMalloc(&b->counters, 2 * sizeof(unsigned long long)));
+        HIP_TRY(hipHostMalloc(&b->h_counters, 2 * sizeof(unsigned long long)));
+        if (b->p.record_stride > 0) {
+            if (p->ext_s_ray) b->s_ray = p->ext_s_ray;
+            else { HIP_TRY(hipMalloc(&b->s_ray, (size_t)b->p.rec_rows * 6 * Rz * b->esz)); b->own_s = true; }
+            if (p->ext_n_ray) b->n_ray = p->ext_n_ray;
+            else { HIP_TRY(hipMalloc(&b->n_ray, (size_t)b->p.rec_rows * Rz * b->esz)); b->own_n = true; }
+        }
+        HIP_TRY(hipMemcpyAsync(b->launch, x0, Rz * 8, hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipMemcpyAsync(b->launch + Rz, y0, Rz * 8, hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipMemcpyAsync(b->launch + 2 * Rz, theta0, Rz * 8, hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));  // caller's host buffers may go away
+        b->kfn = pick_advance(b);
+        return batch_init_state(b);
+    };
+    rc = body();
+    if (rc) { rtmi_batch_destroy(b); return rc; }
+    *out = b;
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_batch_reset(rtmi_batch* b) {
+    ARG_TRY(b, "rtmi_batch_reset: null");
+    return batch_init_state(b);
+}
+
+static int fold_events(rtmi_batch* b) {
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    for (size_t i = 0; i < b->ev_used; i++) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, b->events[i].first, b->events[i].second));
+        b->kernel_ms += ms;
+    }
+    b->ev_used = 0;
+    return RTMI_OK;
+}
+
+template <typename T> static void launch_advance(const rtmi_batch* b, int nsteps) {
+    BatchDev<T> a = batch_dev<T>(b);
+    void* args[] = {&a, &nsteps};
+    const int bs = b->p.block_size > 0 ? b->p.block_size : 256;
+    const dim3 g((unsigned)((b->R + bs - 1) / bs)), blk(bs);
+    (void)hipLaunchKernel(b->kfn, g, blk, args, 0, b->stream);
+}
+
+RTMI_EXPORT int rtmi_step(rtmi_batch* b, int32_t nsteps) {
+    ARG_TRY(b, "rtmi_step: null");
+    ARG_TRY(nsteps > 0, "rtmi_step: nsteps must be > 0");
+    ARG_TRY(b->p.block_size == 0 || (b->p.block_size % 64 == 0 && b->p.block_size <= 256),
+            "rtmi_step: block_size must be a multiple of 64, at most 256");
+    if (b->ev_used == b->events.size()) {
+        if (b->events.size() >= 1024) {
+            int rc = fold_events(b);
+            if (rc) return rc;
+        } else {
+            hipEvent_t e0, e1;
+            HIP_TRY(hipEventCreate(&e0));
+            HIP_TRY(hipEventCreate(&e1));
+            b->events.emplace_back(e0, e1);
+        }
+    }
+    auto& ev = b->events[b->ev_used++];
+    HIP_TRY(hipMemsetAsync(b->counters + 1, 0, sizeof(unsigned long long), b->stream));
+    HIP_TRY(hipEventRecord(ev.first, b->stream));
+    if (b->p.dtype == RTMI_F64) launch_advance<double>(b, nsteps);
+    else launch_advance<float>(b, nsteps);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev.second, b->stream));
+    b->launches++;
+    return RTMI_OK;
+}
+
+static int read_counters(rtmi_batch* b) {
+    HIP_TRY(hipMemcpyAsync(b->h_counters, b->counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
+    ARG_TRY(b, "rtmi_run: null");
+    // one lane per ray to completion: a single launch covers every remaining row
+    int rc = rtmi_step(b, b->p.max_size);
+    if (rc) return rc;
+    rc = read_counters(b);
+    if (rc) return rc;
+    if (b->h_counters[1] != 0) return fail(RTMI_ERR_STATE, "rtmi_run: rays still live after a full-length launch");
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_sync(rtmi_batch* b) {
+    ARG_TRY(b, "rtmi_sync: null");
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_read_d_ray(rtmi_batch* b, double* d_ray) {
+    ARG_TRY(b && d_ray, "rtmi_read_d_ray: null");
+    double* d = nullptr;
+    const size_t nb = 3 * (size_t)b->R * sizeof(double);
+    HIP_TRY(hipMalloc(&d, nb));
+    const dim3 g((unsigned)((b->R + 255) / 256)), blk(256);
+    if (b->p.dtype == RTMI_F64) hipLaunchKernelGGL(k_pack_d_ray<double>, g, blk, 0, b->stream, batch_dev<double>(b), d);
+    else hipLaunchKernelGGL(k_pack_d_ray<float>, g, blk, 0, b->stream, batch_dev<float>(b), d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ray, d, nb, hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_read_d_ray: ") + hipGetErrorString(e));
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_read_final(rtmi_batch* b, double* final9) {
+    ARG_TRY(b && final9, "rtmi_read_final: null");
+    double* d = nullptr;
+    const size_t nb = 9 * (size_t)b->R * sizeof(double);
+    HIP_TRY(hipMalloc(&d, nb));
+    const dim3 g((unsigned)((b->R + 255) / 256)), blk(256);
+    if (b->p.dtype == RTMI_F64) hipLaunchKernelGGL(k_pack_final<double>, g, blk, 0, b->stream, batch_dev<double>(b), d);
+    else hipLaunchKernelGGL(k_pack_final<float>, g, blk, 0, b->stream, batch_dev<float>(b), d);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(final9, d, nb, hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_read_final: ") + hipGetErrorString(e));
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_read_rows(rtmi_batch* b, int64_t row0, int64_t nrows, double* s_ray, double* n_ray) {
+    ARG_TRY(b, "rtmi_read_rows: null");
+    ARG_TRY(b->p.record_stride > 0, "rtmi_read_rows: batch keeps no trajectory (record_stride = 0)");
+    ARG_TRY(row0 >= 0 && nrows >= 0 && row0 + nrows <= b->p.rec_rows, "rtmi_read_rows: row range outside rec_rows");
+    if (nrows == 0) return RTMI_OK;
+    const size_t R = (size_t)b->R;
+    for (int which = 0; which < 2; which++) {
+        double* dst = which == 0 ? s_ray : n_ray;
+        if (!dst) continue;
+        const size_t per_row = (which == 0 ? 6 : 1) * R, n = per_row * (size_t)nrows;
+        const char* src = (const char*)(which == 0 ? b->s_ray : b->n_ray) + (size_t)row0 * per_row * b->esz;
+        if (b->p.dtype == RTMI_F64) {
+            HIP_TRY(hipMemcpyAsync(dst, src, n * 8, hipMemcpyDeviceToHost, b->stream));
+            HIP_TRY(hipStreamSynchronize(b->stream));
+        } else {
+            double* d = nullptr;
+            HIP_TRY(hipMalloc(&d, n * 8));
+            hipLaunchKernelGGL(k_f32_to_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, (const float*)src, d, n);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(dst, d, n * 8, hipMemcpyDeviceToHost, b->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+            (void)hipFree(d);
+            if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_read_rows: ") + hipGetErrorString(e));
+        }
+    }
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_batch_view(rtmi_batch* b, rtmi_device_view* v) {
+    ARG_TRY(b && v, "rtmi_batch_view: null");
+    const size_t R = (size_t)b->R, e = b->esz;
+    char* s = (char*)b->state;
+    v->s_ray = b->s_ray; v->n_ray = b->n_ray;
+    v->x = s; v->y = s + R * e; v->theta = s + 2 * R * e; v->n = s + 3 * R * e; v->gx = s + 4 * R * e; v->gy = s + 5 * R * e;
+    v->dist_sim = s + 6 * R * e; v->dist_real = s + 7 * R * e; v->T = s + 8 * R * e;
+    v->istep = b->istep; v->R = b->R; v->rec_rows = b->p.rec_rows; v->dtype = b->p.dtype; v->record_stride = b->p.record_stride;
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_batch_stats(rtmi_batch* b, rtmi_stats* s) {
+    ARG_TRY(b && s, "rtmi_batch_stats: null");
+    int rc = fold_events(b);
+    if (rc) return rc;
+    rc = read_counters(b);
+    if (rc) return rc;
+    s->ray_steps = b->h_counters[0];
+    s->live_rays = b->launches ? b->h_counters[1] : (uint64_t)b->R;
+    s->kernel_ms = b->kernel_ms;
+    s->launches = b->launches;
+    hipFuncAttributes fa;
+    s->vgprs = s->sgprs = s->lds_bytes = 0;
+    if (hipFuncGetAttributes(&fa, b->kfn) == hipSuccess) { s->vgprs = fa.numRegs; s->lds_bytes = (uint32_t)fa.sharedSizeBytes; }
+    return RTMI_OK;
+}
