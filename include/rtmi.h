@@ -94,6 +94,12 @@ typedef struct {
  * run the initial conditions (:814-826) on the device and write row 0. */
 int rtmi_batch_create(const rtmi_field *f, const rtmi_params *p, int64_t R, const double *x0, const double *y0,
                       const double *theta0, void *stream, rtmi_batch **out);
+/* Overwrite the ray state with caller-provided values (host, fp64): state9[9][R] = x, y, theta, n, dn/dx,
+ * dn/dy, dist_sim, dist_real, T; hist4[4][R] = the two positions before (x,y), oldest first (op7's
+ * VECTOR_LIST, :73; may be NULL for other methods); istep[R] = last written row (NULL keeps it).  Every ray
+ * with istep+1 < max_size becomes live.  This is the explicit-argument form of one selected_func call
+ * (:868): opN(i_angle, init_n, i_grad, i_unitv, i_vpos, coef_i, grd, z, step) with caller-chosen inputs. */
+int rtmi_batch_set_state(rtmi_batch *b, const double *state9, const double *hist4, const int32_t *istep);
 /* Back to row 0 with the same launch conditions (re-runs the initial conditions; clears trajectories). */
 int rtmi_batch_reset(rtmi_batch *b);
 /* One launch that advances every live ray by at most nsteps DELTA_S steps (the body of the loop at :866-879;

@@ -1,0 +1,95 @@
+"""ctypes binding of librtmi.so (include/rtmi.h).  No fallback: if the HIP library is missing or a
+call fails this raises -- the product path never computes on the CPU."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtmi.so")
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+class RtmiError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"librtmi error {code}: {msg}")
+        self.code = code
+
+
+class Params(C.Structure):
+    _fields_ = [("method", C.c_int32), ("dtype", C.c_int32), ("gamma", C.c_double), ("gamma_step", C.c_double),
+                ("step", C.c_double), ("max_size", C.c_int32), ("record_stride", C.c_int32), ("rec_rows", C.c_int64),
+                ("box", C.c_double * 4), ("launch_mode", C.c_int32), ("block_size", C.c_int32),
+                ("ext_s_ray", C.c_void_p), ("ext_n_ray", C.c_void_p)]
+
+
+class DeviceView(C.Structure):
+    _fields_ = [("s_ray", C.c_void_p), ("n_ray", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p),
+                ("theta", C.c_void_p), ("n", C.c_void_p), ("gx", C.c_void_p), ("gy", C.c_void_p),
+                ("dist_sim", C.c_void_p), ("dist_real", C.c_void_p), ("T", C.c_void_p), ("istep", C.c_void_p),
+                ("R", C.c_int64), ("rec_rows", C.c_int64), ("dtype", C.c_int32), ("record_stride", C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("ray_steps", C.c_uint64), ("live_rays", C.c_uint64), ("kernel_ms", C.c_double),
+                ("launches", C.c_uint32), ("vgprs", C.c_uint32), ("sgprs", C.c_uint32), ("lds_bytes", C.c_uint32)]
+
+
+# every symbol include/rtmi.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "rtmi_abi_version": (C.c_int, []),
+    "rtmi_last_error": (C.c_char_p, []),
+    "rtmi_set_device": (C.c_int, [C.c_int]),
+    "rtmi_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "rtmi_field_build": (C.c_int, [C.c_int] + [C.c_double] * 5 + [C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rtmi_field_from_samples": (C.c_int, [_dp, C.c_int, _dp, C.c_int, _dp, C.c_double, C.c_int, C.c_void_p,
+                                          C.POINTER(C.c_void_p)]),
+    "rtmi_field_dims": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "rtmi_field_read": (C.c_int, [C.c_void_p] + [_dp] * 5),
+    "rtmi_field_eval": (C.c_int, [C.c_void_p, C.c_int64] + [_dp] * 5),
+    "rtmi_field_destroy": (None, [C.c_void_p]),
+    "rtmi_batch_create": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int64, _dp, _dp, _dp, C.c_void_p,
+                                    C.POINTER(C.c_void_p)]),
+    "rtmi_batch_set_state": (C.c_int, [C.c_void_p, _dp, _dp, _ip]),
+    "rtmi_batch_reset": (C.c_int, [C.c_void_p]),
+    "rtmi_step": (C.c_int, [C.c_void_p, C.c_int32]),
+    "rtmi_run": (C.c_int, [C.c_void_p]),
+    "rtmi_sync": (C.c_int, [C.c_void_p]),
+    "rtmi_read_d_ray": (C.c_int, [C.c_void_p, _dp]),
+    "rtmi_read_final": (C.c_int, [C.c_void_p, _dp]),
+    "rtmi_read_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp, _dp]),
+    "rtmi_batch_view": (C.c_int, [C.c_void_p, C.POINTER(DeviceView)]),
+    "rtmi_batch_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "rtmi_batch_destroy": (None, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load librtmi.so (built in-tree by __graft_entry__.build() / make -C raytracing_amd/csrc)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C raytracing_amd/csrc). "
+                "raytracing_amd has no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        if L.rtmi_abi_version() != 1:
+            raise ImportError("librtmi.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        raise RtmiError(code, lib().rtmi_last_error().decode("utf-8", "replace"))
+
+
+def dptr(a):
+    return a.ctypes.data_as(_dp) if a is not None else None

@@ -477,6 +477,7 @@ struct rtmi_batch {
     double kernel_ms = 0;
     uint32_t launches = 0;
     const void* kfn = nullptr;
+    bool dirty = false;          // rtmi_batch_set_state ran since the trajectories were last cleared
 };
 
 template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
@@ -515,12 +516,15 @@ static const void* pick_advance(const rtmi_batch* b) {
     return rec ? advance_fn<float, true>(b->p.method) : advance_fn<float, false>(b->p.method);
 }
 
-static int batch_init_state(rtmi_batch* b) {
+// clear_traj: zero the trajectory arrays (np.zeros, :802-803).  A reset with unchanged launch conditions rewrites
+// exactly the rows it wrote before, so the zeros past each ray's last row survive and need no second pass.
+static int batch_init_state(rtmi_batch* b, bool clear_traj) {
     hipStream_t st = b->stream;
     const size_t R = (size_t)b->R;
     HIP_TRY(hipMemsetAsync(b->counters, 0, 2 * sizeof(unsigned long long), st));
-    if (b->s_ray) HIP_TRY(hipMemsetAsync(b->s_ray, 0, (size_t)b->p.rec_rows * 6 * R * b->esz, st));  // np.zeros (:802)
-    if (b->n_ray) HIP_TRY(hipMemsetAsync(b->n_ray, 0, (size_t)b->p.rec_rows * R * b->esz, st));
+    if (clear_traj && b->s_ray) HIP_TRY(hipMemsetAsync(b->s_ray, 0, (size_t)b->p.rec_rows * 6 * R * b->esz, st));
+    if (clear_traj && b->n_ray) HIP_TRY(hipMemsetAsync(b->n_ray, 0, (size_t)b->p.rec_rows * R * b->esz, st));
+    b->dirty = false;
     const dim3 g((unsigned)((R + 255) / 256)), blk(256);
     if (b->p.dtype == RTMI_F64) hipLaunchKernelGGL(k_init<double>, g, blk, 0, st, batch_dev<double>(b));
     else hipLaunchKernelGGL(k_init<float>, g, blk, 0, st, batch_dev<float>(b));
@@ -581,7 +585,7 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
         HIP_TRY(hipMemcpyAsync(b->launch + 2 * Rz, theta0, Rz * 8, hipMemcpyHostToDevice, b->stream));
         HIP_TRY(hipStreamSynchronize(b->stream));  // caller's host buffers may go away
         b->kfn = pick_advance(b);
-        return batch_init_state(b);
+        return batch_init_state(b, true);
     };
     rc = body();
     if (rc) { rtmi_batch_destroy(b); return rc; }
@@ -591,7 +595,45 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
 
 RTMI_EXPORT int rtmi_batch_reset(rtmi_batch* b) {
     ARG_TRY(b, "rtmi_batch_reset: null");
-    return batch_init_state(b);
+    return batch_init_state(b, b->dirty);
+}
+
+template <typename T> __global__ void k_set_state(BatchDev<T> a, const double* st, const double* hist, const int* istep) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.R) return;
+    T* dst[9] = {a.x, a.y, a.th, a.n, a.gx, a.gy, a.dsim, a.dreal, a.tt};
+#pragma unroll
+    for (int q = 0; q < 9; q++) dst[q][k] = (T)st[(size_t)q * a.R + k];
+    if (a.hist && hist)
+        for (int q = 0; q < 4; q++) a.hist[(size_t)q * a.R + k] = (T)hist[(size_t)q * a.R + k];
+    if (istep) a.istep[k] = istep[k];
+    a.alive[k] = a.istep[k] + 1 < a.max_size;
+}
+
+RTMI_EXPORT int rtmi_batch_set_state(rtmi_batch* b, const double* state9, const double* hist4, const int32_t* istep) {
+    ARG_TRY(b && state9, "rtmi_batch_set_state: null");
+    const size_t R = (size_t)b->R;
+    b->dirty = true;
+    double* d = nullptr;
+    int* di = nullptr;
+    HIP_TRY(hipMalloc(&d, 13 * R * sizeof(double)));
+    hipError_t e = hipMalloc(&di, R * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpyAsync(d, state9, 9 * R * 8, hipMemcpyHostToDevice, b->stream);
+    if (e == hipSuccess && hist4) e = hipMemcpyAsync(d + 9 * R, hist4, 4 * R * 8, hipMemcpyHostToDevice, b->stream);
+    if (e == hipSuccess && istep) e = hipMemcpyAsync(di, istep, R * sizeof(int), hipMemcpyHostToDevice, b->stream);
+    if (e == hipSuccess) {
+        const dim3 g((unsigned)((R + 255) / 256)), blk(256);
+        if (b->p.dtype == RTMI_F64)
+            hipLaunchKernelGGL(k_set_state<double>, g, blk, 0, b->stream, batch_dev<double>(b), d, hist4 ? d + 9 * R : nullptr, istep ? di : nullptr);
+        else
+            hipLaunchKernelGGL(k_set_state<float>, g, blk, 0, b->stream, batch_dev<float>(b), d, hist4 ? d + 9 * R : nullptr, istep ? di : nullptr);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    (void)hipFree(d);
+    (void)hipFree(di);
+    if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_batch_set_state: ") + hipGetErrorString(e));
+    return RTMI_OK;
 }
 
 static int fold_events(rtmi_batch* b) {

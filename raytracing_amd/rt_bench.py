@@ -1,0 +1,464 @@
+"""Host API for the MI355X ray propagation path -- the selection surface of neyuru/RayTracing's
+RT_bench.py (scenarios, step methods op1..op11, DELTA_S stepping, trazar) over librtmi.so.
+
+Names, argument order and return shapes follow the reference so a caller of
+`genZ` / `interpolacion` / `n_gradient` / `trazar` / `search_delta` can switch imports; all numerics
+run in HIP kernels on the GPU (see include/rtmi.h).  Reference lines are RT_bench.py file:line.
+There is no CPU path here: without a HIP device every compute call raises.
+"""
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import _lib
+from ._lib import Params, Stats, DeviceView, check, dptr, lib
+
+# --------------------------------------------------------------------------- constants (:59-97)
+THCK_PARAM = 0.005                                   # :59
+SIGMA = 0.05293304824724534                          # :60-61 (value of -2*THCK*log((A-1)/(sqrt2-A)) under numpy)
+DELTA_G = np.pi / 2                                  # :64
+GOLD_RATIO = (np.sqrt(5) - 1) / 2                    # :65
+GOLD_TOL = 1.4901161193847656e-08                    # :66 sqrt(eps)
+MAX_DEVIATION = 0.2                                  # :69
+DELTA = SIGMA / 3                                    # :77
+DELTA_S_DIVISOR = 20                                 # :79
+DELTA_S = SIGMA / DELTA_S_DIVISOR                    # :81
+N = 10                                               # :82
+DELTA_S_DIVISOR_FISHEYE = 90                         # :84
+DELTA_STEP = 0.01                                    # :89
+DELTA_S_DIVISOR_UPPER_LIMIT = 3                      # :90
+DELTA_S_DIVISOR_LOWER_LIMIT = 1 + DELTA_STEP         # :91
+DELTA_STEP_FISHEYE = 1                               # :92
+DELTA_S_DIVISOR_FISHEYE_UPPER_LIMIT = 303            # :93
+DELTA_S_DIVISOR_FISHEYE_LOWER_LIMIT = 4              # :94
+DELTA_STEP_VERT = 0.005                              # :95
+DELTA_S_DIVISOR_VERT_UPPER_LIMIT = 2                 # :96
+DELTA_S_DIVISOR_VERT_LOWER_LIMIT = 1 / 40            # :97
+
+F64, F32 = 0, 1
+
+
+# --------------------------------------------------------------------------- scenarios (:106-119)
+class Scenario:
+    """A scenario token.  genZ() samples it on the device; calling it evaluates the same formula with
+    numpy for callers that only want to look at n(x, y) (plots, docs) -- it is not on the trace path."""
+
+    def __init__(self, name, code, fn):
+        self.__name__ = name
+        self.code = code
+        self._fn = fn
+
+    def __call__(self, a, b):
+        return self._fn(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64))
+
+    def __repr__(self):
+        return f"<scenario {self.__name__}>"
+
+
+interface = Scenario("interface", 1, lambda a, b: np.sqrt(2) - (np.sqrt(2) - 1) / (1 + np.exp(-b / THCK_PARAM)))
+fisheye = Scenario("fisheye", 2, lambda a, b: 1 / (1 + np.power(a, 2) + np.power(b, 2)))
+vert_heterogeneous = Scenario("vert_heterogeneous", 3, lambda a, b: 1 / (18 + 2 * b))
+SCENARIOS = {"interface": interface, "fisheye": fisheye, "vert_heterogeneous": vert_heterogeneous,
+             "anisotropy": vert_heterogeneous}          # scenario 4 reuses the field of 3 (:1579)
+USER_CHOICE = {"interface": "1", "fisheye": "2", "vert_heterogeneous": "3", "anisotropy": "4"}
+
+# module globals the reference's __main__ sets (:1567-1584); genZ reads `f` like the reference does (:432)
+f = None
+gamma = 1
+
+
+def anisotropy(theta, gamma):  # :118-119 (host helper; the device evaluates its own copy)
+    return np.sqrt((gamma * np.sin(theta)) ** 2 + np.cos(theta) ** 2)
+
+
+def constants(user_choice):
+    """Scenario presets, same 13-tuple as RT_bench.py:247-295."""
+    if user_choice == "1":
+        g, ray_count = 1, 42
+        theta_v = np.linspace(2 * (np.pi / 60), np.pi / 2, ray_count + 1)   # Q9: one unused sample
+        pos_x = np.ones(ray_count) * -2
+        s = 80
+        lim = (-2, 20, -2, 4)
+        flags = (1, 0, 0, 0)
+    elif user_choice == "2":
+        g, ray_count = 1, 1
+        theta_v = np.linspace(np.pi / 2, np.pi / 2, 1)
+        pos_x = np.array((1, 0))
+        s = N * (2 * np.pi)
+        lim = (-1.5, 1.5, -1.5, 1.5)
+        flags = (0, 1, 0, 0)
+    elif user_choice in ("3", "4"):
+        g = 1 if user_choice == "3" else 3
+        ray_count = 31
+        theta_v = np.linspace(0, np.pi / 2, ray_count)
+        pos_x = np.ones(ray_count) * -2
+        s = 80
+        lim = (-2, 5, -2.5, 1)
+        flags = (0, 0, 1, 0) if user_choice == "3" else (0, 0, 0, 1)
+    else:
+        raise ValueError("user_choice must be '1', '2', '3' or '4'")
+    return (g, ray_count, theta_v, pos_x, s) + lim + flags
+
+
+# --------------------------------------------------------------------------- step-method tokens (:469-764)
+class StepMethod:
+    """Token for op<m>.  Passing it to trazar selects the device kernel; calling it advances one ray by
+    one DELTA_S step on the device with the reference's argument list (:469)."""
+
+    def __init__(self, m, label):
+        self.method = m
+        self.__name__ = f"op{m}"
+        self.label = label
+
+    def __repr__(self):
+        return f"<step method op{self.method}:{self.label}>"
+
+    def __call__(self, i_angle, init_n, i_grad, i_unitv, i_vpos, coef_i, grd, z, step, history=None):
+        fld = _field_of(z, grd)
+        g = gamma
+        st = np.zeros((9, 1))
+        st[:, 0] = (i_vpos[0], i_vpos[1], i_angle, init_n, i_grad[0], i_grad[1], 0.0, 0.0, 0.0)
+        hist = None
+        if self.method == 7:
+            if history is None:
+                raise ValueError("op7 needs history=[P0, P1] (the two positions before i_vpos; VECTOR_LIST, :73)")
+            hist = np.ascontiguousarray(np.asarray(history, dtype=np.float64).reshape(4, 1))
+        b = Batch(fld, self.method, step, max_size=1 << 20, box=(-1e300, 1e300, -1e300, 1e300), gamma=g,
+                  thetas=[i_angle], x0=[i_vpos[0]], y0=[i_vpos[1]], record_stride=0)
+        b.set_state(st, hist, np.array([3], dtype=np.int32))
+        b.step(1)
+        fin = b.final()[:, 0]
+        b.close()
+        return np.array((fin[0], fin[1])), fin[2], fin[3], np.array((fin[4], fin[5]))
+
+
+_LABELS = ["1st order Taylor + analytical 2-point momentum-impulse", "1st order Taylor + d_theta/d_s Runge-Kutta (AnDF)",
+           "2-point curvature + d_theta/d_s Runge-Kutta", "2-point curvature + analytical 2-point momentum-impulse",
+           "2-point curvature + optimized 2-point momentum-impulse", "2nd order Taylor + d_theta/d_s Runge-Kutta (HySA)",
+           "2nd order Taylor + 4-point difference method (MxSA)", "2nd order Taylor + analytical 2-point momentum-impulse",
+           "2nd order Taylor + optimized 2-point momentum-impulse",
+           "2-point curvature + optimized anisotropic momentum-impulse",
+           "2nd order Taylor + optimized anisotropic momentum-impulse"]
+op1, op2, op3, op4, op5, op6, op7, op8, op9, op10, op11 = [StepMethod(i + 1, _LABELS[i]) for i in range(11)]
+METHODS = {m.method: m for m in (op1, op2, op3, op4, op5, op6, op7, op8, op9, op10, op11)}
+# menus: isotropic scenarios offer 1..9 (:1238-1264), the anisotropic one offers 1..2 -> op10/op11 (:1286-1291)
+ISOTROPIC_MENU = {str(i): METHODS[i] for i in range(1, 10)}
+ANISOTROPIC_MENU = {"1": op10, "2": op11}
+
+
+def _method_id(selected_func):
+    if isinstance(selected_func, StepMethod):
+        return selected_func.method
+    if isinstance(selected_func, int) and 1 <= selected_func <= 11:
+        return selected_func
+    name = getattr(selected_func, "__name__", "")
+    if name.startswith("op") and name[2:].isdigit() and 1 <= int(name[2:]) <= 11:
+        return int(name[2:])
+    raise ValueError(f"selected_func must be one of op1..op11, got {selected_func!r}")
+
+
+# --------------------------------------------------------------------------- field (:412-464)
+class Field:
+    """z + grd of interpolacion(), resident in HBM (rtmi_field)."""
+
+    def __init__(self, handle, dtype):
+        self._h = C.c_void_p(handle)
+        self.dtype = dtype
+        qx, qy = C.c_int(), C.c_int()
+        check(lib().rtmi_field_dims(self._h, C.byref(qx), C.byref(qy)))
+        self.qx, self.qy = qx.value, qy.value
+
+    @classmethod
+    def build(cls, scenario, limits=None, delta=DELTA, dtype=F64, stream=None):
+        """genZ + interpolacion on the device for one of the four scenarios (rtmi_field_build)."""
+        sc = SCENARIOS[scenario] if isinstance(scenario, str) else scenario
+        if limits is None:
+            limits = constants(USER_CHOICE[scenario])[5:9]
+        h = C.c_void_p()
+        check(lib().rtmi_field_build(sc.code, *[float(v) for v in limits], float(delta), dtype, stream, C.byref(h)))
+        return cls(h.value, dtype)
+
+    @classmethod
+    def from_samples(cls, x, y, Z, delta=DELTA, dtype=F64, stream=None):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        Z = np.ascontiguousarray(Z, dtype=np.float64)
+        if Z.shape != (len(y), len(x)):
+            raise ValueError("Z must have shape (len(y), len(x))")
+        h = C.c_void_p()
+        check(lib().rtmi_field_from_samples(dptr(x), len(x), dptr(y), len(y), dptr(Z), float(delta), dtype, stream,
+                                            C.byref(h)))
+        return cls(h.value, dtype)
+
+    def arrays(self):
+        """(x, y, Z, coef_dy, coef_dx): axes, n samples and the bicubic coefficients of GradX/GradY."""
+        x = np.empty(self.qx); y = np.empty(self.qy)
+        Z = np.empty((self.qy, self.qx)); cdy = np.empty_like(Z); cdx = np.empty_like(Z)
+        check(lib().rtmi_field_read(self._h, dptr(x), dptr(y), dptr(Z), dptr(cdy), dptr(cdx)))
+        return x, y, Z, cdy, cdx
+
+    def n_gradient(self, x, y):
+        x = np.ascontiguousarray(np.atleast_1d(x), dtype=np.float64)
+        y = np.ascontiguousarray(np.atleast_1d(y), dtype=np.float64)
+        n = np.empty_like(x); gx = np.empty_like(x); gy = np.empty_like(x)
+        check(lib().rtmi_field_eval(self._h, len(x), dptr(x), dptr(y), dptr(n), dptr(gx), dptr(gy)))
+        return n, gx, gy
+
+    def close(self):
+        if self._h:
+            lib().rtmi_field_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FieldSpline:
+    """One of the three callables interpolacion() returns (z, grd[0], grd[1]); `spl(y, x)` evaluates on
+    the device with RectBivariateSpline's argument order and [[value]] return shape (:153-155)."""
+
+    def __init__(self, field, which):
+        self.field, self.which = field, which
+
+    def __call__(self, yv, xv):
+        n, gx, gy = self.field.n_gradient(np.atleast_1d(xv), np.atleast_1d(yv))
+        return {"n": n, "dx": gx, "dy": gy}[self.which].reshape(-1, 1) if np.ndim(xv) else \
+            np.array([[{"n": n, "dx": gx, "dy": gy}[self.which][0]]])
+
+
+def genZ(xi, xs, yi, ys, dtype=F64):
+    """RT_bench.py:412-433.  Reads the module-global scenario `f` like the reference.  Returns
+    (x, y, X, Y, ZZ) as numpy arrays; ZZ is sampled on the device for the built-in scenarios."""
+    if f is None:
+        raise RuntimeError("set raytracing_amd.rt_bench.f to a scenario (interface, fisheye, vert_heterogeneous) first")
+    qx = int((xs - xi + 6) / DELTA + 1)
+    qy = int((ys - yi + 6) / DELTA + 1)
+    x, y = np.linspace(xi - 3, xs + 3, qx), np.linspace(yi - 3, ys + 3, qy)
+    X, Y = np.meshgrid(x, y)
+    if isinstance(f, Scenario):
+        fld = Field.build(f, (xi, xs, yi, ys), DELTA, dtype)
+        ZZ = fld.arrays()[2]
+        fld.close()
+    else:
+        ZZ = np.asarray(f(X, Y), dtype=np.float64)   # user-supplied n(x, y): sampled by the caller's function
+    return x, y, X, Y, ZZ
+
+
+def interpolacion(x, y, Z, X=None, Y=None, dtype=F64):
+    """RT_bench.py:435-464 -> (z, grd, hess).  The fits run on the device; hess is None (the reference
+    builds it and never reads it, :462)."""
+    fld = Field.from_samples(x, y, Z, DELTA, dtype)
+    return FieldSpline(fld, "n"), (FieldSpline(fld, "dy"), FieldSpline(fld, "dx")), None
+
+
+def _field_of(z, grd=None):
+    if isinstance(z, Field):
+        return z
+    if isinstance(z, FieldSpline):
+        return z.field
+    raise TypeError("z must come from interpolacion() / Field.build()")
+
+
+def n_gradient(vector, grd, z):
+    """RT_bench.py:141-156."""
+    n, gx, gy = _field_of(z, grd).n_gradient(vector[0], vector[1])
+    return n[0], np.array([gx[0], gy[0]])
+
+
+# --------------------------------------------------------------------------- ray batch (:766-948)
+class Batch:
+    """One trazar() call's rays, resident in HBM (rtmi_batch)."""
+
+    def __init__(self, field, method, step, max_size, box, gamma, thetas, x0, y0, record_stride=1, rec_rows=0,
+                 gamma_step=None, stream=None, ext_s_ray=None, ext_n_ray=None, block_size=0):
+        self.field = field
+        th = np.ascontiguousarray(thetas, dtype=np.float64)
+        self.R = len(th)
+        x0 = np.ascontiguousarray(np.broadcast_to(np.asarray(x0, dtype=np.float64), (self.R,)))
+        y0 = np.ascontiguousarray(np.broadcast_to(np.asarray(y0, dtype=np.float64), (self.R,)))
+        p = Params()
+        p.method = _method_id(method); p.dtype = field.dtype
+        p.gamma = float(gamma); p.gamma_step = float(gamma if gamma_step is None else gamma_step)
+        p.step = float(step); p.max_size = int(max_size)
+        p.record_stride = int(record_stride); p.rec_rows = int(rec_rows)
+        for i in range(4):
+            p.box[i] = float(box[i])
+        p.launch_mode = 0; p.block_size = int(block_size)
+        p.ext_s_ray = ext_s_ray; p.ext_n_ray = ext_n_ray
+        self.params = p
+        self._h = C.c_void_p()
+        check(lib().rtmi_batch_create(field._h, C.byref(p), self.R, dptr(x0), dptr(y0), dptr(th), stream,
+                                      C.byref(self._h)))
+        self.max_size = int(max_size)
+        self.record_stride = int(record_stride)
+        self.rec_rows = int(rec_rows) if rec_rows else ((self.max_size + record_stride - 1) // record_stride
+                                                        if record_stride else 0)
+
+    def set_state(self, state9, hist4=None, istep=None):
+        st = np.ascontiguousarray(state9, dtype=np.float64)
+        assert st.shape == (9, self.R)
+        h = np.ascontiguousarray(hist4, dtype=np.float64) if hist4 is not None else None
+        i = np.ascontiguousarray(istep, dtype=np.int32) if istep is not None else None
+        check(lib().rtmi_batch_set_state(self._h, dptr(st), dptr(h), i.ctypes.data_as(_lib._ip) if i is not None else None))
+
+    def reset(self):
+        check(lib().rtmi_batch_reset(self._h))
+
+    def step(self, nsteps=1):
+        check(lib().rtmi_step(self._h, int(nsteps)))
+
+    def run(self):
+        check(lib().rtmi_run(self._h))
+
+    def sync(self):
+        check(lib().rtmi_sync(self._h))
+
+    def d_ray(self):
+        d = np.empty((3, self.R))
+        check(lib().rtmi_read_d_ray(self._h, dptr(d)))
+        return d
+
+    def final(self):
+        out = np.empty((9, self.R))
+        check(lib().rtmi_read_final(self._h, dptr(out)))
+        return out
+
+    def rows(self, row0=0, nrows=None, want_n_ray=False):
+        nrows = self.rec_rows - row0 if nrows is None else nrows
+        s = np.empty((nrows, 6, self.R))
+        n = np.empty((nrows, self.R)) if want_n_ray else None
+        check(lib().rtmi_read_rows(self._h, row0, nrows, dptr(s), dptr(n)))
+        return (s, n) if want_n_ray else s
+
+    def stats(self):
+        s = Stats()
+        check(lib().rtmi_batch_stats(self._h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def view(self):
+        v = DeviceView()
+        check(lib().rtmi_batch_view(self._h, C.byref(v)))
+        return v
+
+    def close(self):
+        if self._h:
+            lib().rtmi_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def max_rows(user_choice, step, divisor):
+    """max_size of trazar (:796-799)."""
+    c = constants(user_choice)
+    return N * divisor if c[10] else int(np.ceil(c[4] / step) + 1)
+
+
+def snell_errors(s_ray, d_ray, theta_v):
+    """Interface exit-angle metric (:896-919), vectorised over rays (degrees)."""
+    R = s_ray.shape[2]
+    err = np.zeros(R)
+    for k in range(R):
+        i = int(d_ray[2, k])
+        th = theta_v[k]
+        if th < np.pi / 4:
+            angreal = 90 - 180 * th / np.pi
+        elif th == np.pi / 4:
+            angreal = 0
+        else:
+            angreal = 180 * np.arcsin(np.sqrt(2) * np.sin(np.pi / 2 - th)) / np.pi
+        a, b = int(9.5 * i / 10), int(9 * i / 10)
+        distx = s_ray[a, 0, k] - s_ray[b, 0, k]
+        disty = s_ray[a, 1, k] - s_ray[b, 1, k]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            angsim = 180 * np.arctan(np.abs(distx / disty)) / np.pi
+        err[k] = np.abs(angsim - angreal)
+    return err
+
+
+def closure_error(s_ray):
+    """Fisheye closure error in % of 2*pi (:956, :1393)."""
+    return 100 * np.linalg.norm(np.array([1, 0]) - s_ray[-1, 0:2, 0]) / (2 * np.pi)
+
+
+def moment_cv(s_ray, ray_count=None):
+    """Mean coefficient of variation (%) of p_x over rays 1..R-2 (:1354-1360, :1398-1402)."""
+    ray_count = s_ray.shape[2] if ray_count is None else ray_count
+    cvs = np.zeros(ray_count - 2)
+    for i in range(1, ray_count - 1):
+        masked = np.ma.masked_equal(s_ray[:, 2, i], 0).compressed()
+        cvs[i - 1] = 100 * np.std(masked) / np.mean(masked)
+    return np.mean(cvs)
+
+
+def trazar(selected_func, z, grd, show, step, divisor, user_choice, *, thetas=None, starts=None, box=None,
+           gamma=None, max_size=None, record="full", return_batch=False):
+    """RT_bench.py:766-948 on the GPU.  Positional arguments and the returned
+    (s_ray[max_size,6,R], d_ray[3,R], compute_times[R], errors[R]) are the reference's.
+
+    Keyword extensions for synthetic batches: thetas / starts ((R,2) or (2,)) / box / gamma / max_size replace
+    the preset of `user_choice`; record = "full" (reference layout), an int stride, or None (s_ray is None).
+    compute_times holds the device propagation time split evenly over rays, so np.sum(compute_times) is the
+    quantity the reference's benchmark reads (:1526).
+    """
+    g, ray_count, theta_v, pos_x, s, limx_i, limx_s, limy_i, limy_s, op_if, op_fish, _, _ = constants(user_choice)
+    fld = _field_of(z, grd)
+    if thetas is not None:
+        theta_v = np.asarray(thetas, dtype=np.float64)
+        ray_count = len(theta_v)
+    if starts is not None:
+        st = np.asarray(starts, dtype=np.float64)
+        x0, y0 = (st[0], st[1]) if st.ndim == 1 else (st[:, 0], st[:, 1])
+    elif op_fish:
+        x0, y0 = float(pos_x[0]), float(pos_x[1])            # :810
+    else:
+        px = np.asarray(pos_x, dtype=np.float64)
+        x0 = px[:ray_count] if len(px) >= ray_count else np.full(ray_count, px[0])
+        y0 = -2.0                                            # :812
+    if box is None:
+        box = (limx_i, limx_s, limy_i, limy_s)
+    if gamma is None:
+        gamma = g
+    if max_size is None:
+        max_size = N * divisor if op_fish else int(np.ceil(s / step) + 1)   # :796-799
+    stride = 0 if record is None else (1 if record == "full" else int(record))
+    b = Batch(fld, selected_func, step, max_size, box, gamma, theta_v[:ray_count], x0, y0, record_stride=stride)
+    t1 = time.perf_counter()
+    b.run()
+    b.sync()
+    t2 = time.perf_counter()
+    st_ = b.stats()
+    d_ray = b.d_ray()
+    s_ray = b.rows() if stride else None
+    compute_times = np.full(ray_count, (st_["kernel_ms"] * 1e-3 if st_["kernel_ms"] > 0 else t2 - t1) / ray_count)
+    errors = np.zeros(ray_count)
+    if op_if and stride == 1:
+        errors = snell_errors(s_ray, d_ray, theta_v)
+        if show:
+            for k in range(ray_count):
+                i = int(d_ray[2, k])
+                print(f"Coords: [ {s_ray[i, 0, k]: >10.8f} , {s_ray[i, 1, k]: >10.8f} ] | Err: {errors[k]: >10.8f} | "
+                      f"InitAng: {theta_v[k] * 180 / np.pi: >10.8f}")
+    if return_batch:
+        return s_ray, d_ray, compute_times, errors, b
+    b.close()
+    return s_ray, d_ray, compute_times, errors
+
+
+def search_delta(option, z, grd, step, divisor, user_choice):
+    """RT_bench.py:950-958."""
+    c = constants(user_choice)
+    rays, _, _, errors = trazar(option, z, grd, False, step, divisor, user_choice)
+    if c[9]:
+        return np.mean(errors), np.max(errors)
+    if c[10]:
+        return closure_error(rays)
+    return rays[:, 2, :]

@@ -1,0 +1,71 @@
+"""CPU: host-side mirror of the reference's selection surface (no device work)."""
+import numpy as np
+import pytest
+
+from conftest import golden
+from raytracing_amd import rt_bench as rb
+
+
+def test_constants_match_reference(consts):
+    assert rb.SIGMA == consts["SIGMA"] and rb.DELTA == consts["DELTA"] and rb.DELTA_S == consts["DELTA_S"]
+    assert rb.GOLD_TOL == consts["GOLD_TOL"] and rb.GOLD_RATIO == consts["GOLD_RATIO"]
+    assert rb.N == consts["N"] and rb.DELTA_S_DIVISOR_FISHEYE == consts["DELTA_S_DIVISOR_FISHEYE"]
+    # the hard-coded SIGMA is the value of the reference's formula (RT_bench.py:60-61)
+    A = (1 + np.sqrt(2)) / 2 - 99 * (np.sqrt(2) - 1) / 200
+    assert abs(-2 * rb.THCK_PARAM * np.log((A - 1) / (np.sqrt(2) - A)) - rb.SIGMA) < 1e-17
+
+
+@pytest.mark.parametrize("choice,fix", [("1", "traj_interface_op6_16"), ("3", "traj_vert_op6"), ("4", "traj_aniso_op11"),
+                                        ("2", "traj_fisheye_op6_div91")])
+def test_presets_match_reference(choice, fix):
+    t = golden(fix)
+    g, ray_count, theta_v, pos_x, s, xi, xs, yi, ys, a, b, c, d = rb.constants(choice)
+    assert g == t["gamma"] and s == t["s_max"] and np.array_equal(np.array((xi, xs, yi, ys), float), t["box"])
+    assert (a, b, c, d) == tuple(int(choice == k) for k in "1234")
+    if choice != "1":
+        assert ray_count == len(t["theta"]) and np.array_equal(theta_v, t["theta"])
+        assert rb.max_rows(choice, float(t["step"]), int(t["divisor"])) == int(t["max_size"])
+    else:
+        assert ray_count == 42 and len(theta_v) == 43      # Q9: one unused launch angle
+        assert rb.max_rows("1", rb.DELTA_S, 91) == 30228
+    with pytest.raises(ValueError):
+        rb.constants("5")
+
+
+def test_method_tokens_and_menus():
+    assert [m.method for m in (rb.op1, rb.op6, rb.op11)] == [1, 6, 11]
+    assert rb.ISOTROPIC_MENU["6"] is rb.op6 and rb.ANISOTROPIC_MENU == {"1": rb.op10, "2": rb.op11}
+    assert rb._method_id(rb.op7) == 7 and rb._method_id(3) == 3
+
+    def op9():
+        pass
+    assert rb._method_id(op9) == 9        # a reference-style function object selects by name
+    with pytest.raises(ValueError):
+        rb._method_id("hysa")
+
+
+def test_scenario_tokens_evaluate_like_reference():
+    g = golden("field_fisheye")
+    assert np.isclose(rb.fisheye(1.0, 0.0), 0.5) and np.isclose(rb.vert_heterogeneous(0.0, -2.0), 1 / 14)
+    assert np.isclose(rb.interface(0.0, 10.0), 1.0) and np.isclose(rb.interface(0.0, -10.0), np.sqrt(2))
+    assert rb.anisotropy(0.3, 1) == pytest.approx(1.0, abs=1e-15)
+    assert int(g["qx"]) == int((1.5 + 1.5 + 6) / rb.DELTA + 1)
+
+
+def test_metrics_on_reference_rows(oracle_fields):
+    """snell_errors / closure_error / moment_cv restate the reference's in-script checks; fed with the
+    oracle's full trajectories they must reproduce the reference's own numbers."""
+    from oracle import rt_oracle as O
+    t = golden("traj_interface_op6_16")
+    r = O.trazar(oracle_fields("interface"), 6, 1, float(t["step"]), int(t["max_size"]), t["box"], t["pos_x"], -2.0,
+                 t["theta"], record_stride=1)
+    assert np.abs(rb.snell_errors(r["s_ray"], r["d_ray"], t["theta"]) - t["errors"]).max() < 1e-8
+    t = golden("traj_vert_op6")
+    r = O.trazar(oracle_fields("vert_heterogeneous"), 6, 1, float(t["step"]), int(t["max_size"]), t["box"], -2.0, -2.0,
+                 t["theta"], record_stride=1)
+    assert abs(rb.moment_cv(r["s_ray"], 31) - float(t["cv_mean"])) < 1e-9
+    t = golden("traj_fisheye_op6_div304")
+    r = O.trazar(oracle_fields("fisheye"), 6, 1, float(t["step"]), int(t["max_size"]), t["box"], 1.0, 0.0, t["theta"],
+                 record_stride=1)
+    assert abs(rb.closure_error(r["s_ray"]) - float(t["closure_pct"])) < 1e-9
+    assert abs(float(t["closure_pct"]) - 3.0408) < 1e-3      # SURVEY.md section 4 anchor

@@ -1,0 +1,88 @@
+"""CPU: the oracle (oracle/rt_oracle.c) against golden vectors captured from the reference
+(oracle/gen_golden.py).  This is what pins the oracle; the GPU parity tests then compare against it."""
+import numpy as np
+import pytest
+
+from conftest import LIMITS, golden, sub_rows, traj_fixtures, traj_inputs
+from oracle import rt_oracle as O
+
+
+@pytest.mark.parametrize("scen", ["interface", "fisheye", "vert_heterogeneous"])
+def test_field_build_matches_reference(scen, consts, oracle_fields):
+    g = golden(f"field_{scen}")
+    F = oracle_fields(scen)
+    assert (F.qx, F.qy) == (int(g["qx"]), int(g["qy"]))
+    x, y, Z, cdy, cdx = F.arrays()
+    # genZ axes (numpy.linspace) bit for bit
+    assert np.array_equal(x[:4], g["x_head"]) and np.array_equal(x[-4:], g["x_tail"])
+    assert np.array_equal(y[:4], g["y_head"]) and np.array_equal(y[-4:], g["y_tail"])
+    # FITPACK's interior knots are x[2:-2] (not-a-knot)
+    assert np.array_equal(g["tx"][4:-4], x[2:-2]) and np.array_equal(g["ty"][4:-4], y[2:-2])
+    qy, qx = Z.shape
+    for name, arr in (("Z", Z), ("cdy", cdy), ("cdx", cdx)):
+        scale = np.abs(arr).max()
+        for tag, blk in (("c00", arr[:8, :8]), ("c11", arr[-8:, -8:]),
+                         ("mid", arr[qy // 2:qy // 2 + 8, qx // 2:qx // 2 + 8])):
+            # Z: numpy's exp differs from libm's by <= 1 ulp (interface only); coefficients: Givens-QR vs LU
+            assert np.abs(blk - g[f"{name}_{tag}"]).max() <= 4e-15 * max(scale, 1e-300), (name, tag)
+
+
+@pytest.mark.parametrize("scen", ["interface", "fisheye", "vert_heterogeneous"])
+def test_n_gradient_matches_reference(scen, oracle_fields):
+    g = golden(f"field_{scen}")
+    F = oracle_fields(scen)
+    n, gx, gy = F.n_gradient(g["px"], g["py"])
+    _, _, Z, cdy, cdx = F.arrays()
+    assert np.abs(n - g["n"]).max() <= 4e-16 * np.abs(Z).max()
+    assert np.abs(gx - g["gx"]).max() <= 2e-15 * max(np.abs(cdx).max(), 1e-12)
+    assert np.abs(gy - g["gy"]).max() <= 2e-15 * max(np.abs(cdy).max(), 1e-12)
+
+
+@pytest.mark.parametrize("m", range(1, 12))
+def test_single_step_matches_reference(m, oracle_fields):
+    g = golden("step_methods")
+    F = oracle_fields("vert_heterogeneous")
+    out = O.single_step(F, m, 3 if m >= 10 else 1, float(g["step"]), g[f"st{m}"], g[f"hist{m}"])
+    ref = g[f"out{m}"]
+    # np.arctan2 (op1/4/7/8) and numpy's pow differ from libm by <= 1 ulp; everything else is bit-exact
+    assert np.max(np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)) < 2e-15
+
+
+@pytest.mark.parametrize("name,scen,m", traj_fixtures())
+def test_trajectory_matches_reference(name, scen, m, oracle_fields):
+    t = golden("traj_" + name)
+    F = oracle_fields(scen)
+    x0, y0, th = traj_inputs(t, scen)
+    r = O.trazar(F, m, float(t["gamma"]), float(t["step"]), int(t["max_size"]), t["box"], x0, y0, th, record_stride=1)
+    assert r["s_ray"].shape == (int(t["max_size"]), 6, len(th))
+    assert np.array_equal(r["d_ray"][2], t["d_ray"][2]), "last written row per ray"
+    strided, last = sub_rows(r["s_ray"], r["d_ray"], int(t["stride"]))
+    tol = 1e-10 if m == 7 else 1e-12      # op7 differentiates positions: roundoff amplified by 1/step
+    assert np.abs(strided - t["strided"]).max() < tol
+    assert np.abs(last - t["last"]).max() < tol
+    assert np.abs(r["d_ray"][:2] - t["d_ray"][:2]).max() < 1e-12
+    # rows after termination stay zero (Q7)
+    k = int(np.argmin(r["d_ray"][2])); i = int(r["d_ray"][2, k])
+    assert i + 1 >= r["s_ray"].shape[0] or not r["s_ray"][i + 1:, :, k].any()
+
+
+def test_reference_anchor_values(oracle_fields):
+    """SURVEY.md 8c anchors (vert, op6, default DELTA_S), measured on the reference."""
+    t = golden("traj_vert_op6")
+    F = oracle_fields("vert_heterogeneous")
+    n, gx, gy = F.n_gradient(-2.0, -2.0)
+    assert n[0] == 0.07142864686293911 and abs(gy[0] - (-0.01021203672272615)) < 1e-17
+    assert list(t["d_ray"][2, [0, 15, 30]]) == [1006, 2938, 1134]
+    r = O.trazar(F, 6, 1, float(t["step"]), int(t["max_size"]), t["box"], -2.0, -2.0, t["theta"], record_stride=0)
+    fin = r["final"]
+    assert abs(fin[0, 15] - 5.001510180773436) < 1e-12 and abs(fin[1, 15] - 0.8968279249636953) < 1e-12
+    assert abs(fin[8, 0] - 0.19494379134524772) < 1e-13
+
+
+def test_threads_do_not_change_results(oracle_fields):
+    F = oracle_fields("vert_heterogeneous")
+    th = np.linspace(0, np.pi / 2, 64)
+    a = O.trazar(F, 6, 1, 0.002646652412362267, 30228, LIMITS["vert_heterogeneous"], -2.0, -2.0, th, record_stride=0)
+    b = O.trazar(F, 6, 1, 0.002646652412362267, 30228, LIMITS["vert_heterogeneous"], -2.0, -2.0, th, record_stride=0,
+                 nthreads=4)
+    assert np.array_equal(a["final"], b["final"]) and a["steps"] == b["steps"]
