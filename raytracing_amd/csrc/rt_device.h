@@ -6,6 +6,12 @@
 
 namespace rt {
 
+// The library is compiled with -ffp-contract=off: every fusion below is an explicit fma(), so a value is
+// computed with the same roundings wherever the function is inlined (results do not depend on how a run is
+// cut into launches or which kernel variant executes it).
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 // ---------------------------------------------------------------- math traits
 template <typename T> struct M;
 template <> struct M<double> {
@@ -14,8 +20,8 @@ template <> struct M<double> {
     static __device__ __forceinline__ double atan2_(double y, double x) { return ::atan2(y, x); }
     static __device__ __forceinline__ double abs_(double x) { return ::fabs(x); }
     static __device__ __forceinline__ double exp_(double x) { return ::exp(x); }
-    // x[i] of numpy.linspace: i*step + a with separate roundings (no fma), so knots equal the host's bit for bit
-    static __device__ __forceinline__ double lin(int i, double h, double a) { return __dadd_rn(__dmul_rn((double)i, h), a); }
+    // x[i] of numpy.linspace: i*step + a with separate roundings (contraction is off), so knots equal the host's bit for bit
+    static __device__ __forceinline__ double lin(int i, double h, double a) { return (double)i * h + a; }
     static constexpr double gold_tol = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON), RT_bench.py:66
 };
 template <> struct M<float> {
@@ -24,7 +30,7 @@ template <> struct M<float> {
     static __device__ __forceinline__ float atan2_(float y, float x) { return ::atan2f(y, x); }
     static __device__ __forceinline__ float abs_(float x) { return ::fabsf(x); }
     static __device__ __forceinline__ float exp_(float x) { return ::expf(x); }
-    static __device__ __forceinline__ float lin(int i, float h, float a) { return __fadd_rn(__fmul_rn((float)i, h), a); }
+    static __device__ __forceinline__ float lin(int i, float h, float a) { return (float)i * h + a; }
     static constexpr float gold_tol = 3.4526698300124393e-04f;  // sqrt(FLT_EPSILON): the fp32 analogue
 };
 
@@ -80,17 +86,17 @@ template <typename T> __device__ __forceinline__ void bspl3(T v, int l, int q, T
     f = h0 / (t1 - tm1);
     T g0 = f * (t1 - v), g1 = f * (v - tm1);
     f = h1 / (t2 - t0);
-    g1 = g1 + f * (t2 - v);
+    g1 = fma_(f, t2 - v, g1);
     T g2 = f * (v - t0);
     // j = 3
     f = g0 / (t1 - tm2);
     w[0] = f * (t1 - v);
     w[1] = f * (v - tm2);
     f = g1 / (t2 - tm1);
-    w[1] = w[1] + f * (t2 - v);
+    w[1] = fma_(f, t2 - v, w[1]);
     w[2] = f * (v - tm1);
     f = g2 / (t3 - t0);
-    w[2] = w[2] + f * (t3 - v);
+    w[2] = fma_(f, t3 - v, w[2]);
     w[3] = f * (v - t0);
 }
 
@@ -119,7 +125,7 @@ __device__ __forceinline__ void n_gradient(const FieldDev<T>& F, T x, T y, T& n,
         const T fx = T(1) / (xb - xa), fy = T(1) / (yb - ya);
         const T wx0 = fx * (xb - x), wx1 = fx * (x - xa);
         const T wy0 = fy * (yb - y), wy1 = fy * (y - ya);
-        n = (z00 * wy0) * wx0 + (z01 * wy0) * wx1 + (z10 * wy1) * wx0 + (z11 * wy1) * wx1;
+        n = fma_(z11 * wy1, wx1, fma_(z10 * wy1, wx0, fma_(z01 * wy0, wx1, (z00 * wy0) * wx0)));
     }
     // ---- bicubic gradient: shared basis for both components (same knots)
     T wx[4], wy[4];
@@ -131,11 +137,11 @@ __device__ __forceinline__ void n_gradient(const FieldDev<T>& F, T x, T y, T& n,
         T rx = 0, ry = 0;
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            rx += c[r][2 * q] * wx[q];
-            ry += c[r][2 * q + 1] * wx[q];
+            rx = fma_(c[r][2 * q], wx[q], rx);
+            ry = fma_(c[r][2 * q + 1], wx[q], ry);
         }
-        sx += rx * wy[r];
-        sy += ry * wy[r];
+        sx = fma_(rx, wy[r], sx);
+        sy = fma_(ry, wy[r], sy);
     }
     gx = sx;
     gy = sy;
@@ -160,7 +166,7 @@ template <typename T> struct Consts {
 // anisotropy(theta, gamma) (:118-119) from sin/cos
 template <typename T> __device__ __forceinline__ T aniso(T s, T c, T gamma) {
     const T gs = gamma * s;
-    return M<T>::sqrt_(gs * gs + c * c);
+    return M<T>::sqrt_(fma_(gs, gs, c * c));
 }
 // moment() (:217-230) given coef = anisotropy(theta, gamma)
 template <typename T> __device__ __forceinline__ T moment(T n, T coef, T g2m1, T o0, T o1) {
@@ -170,28 +176,28 @@ template <typename T> __device__ __forceinline__ T impulse(T a, T b, T step) { r
 
 // ---- advancement (:300-365)
 template <typename T> __device__ __forceinline__ void adv_first(const Ray<T>& r, T step, T& fx, T& fy) {
-    fx = r.x + r.ux * step;
-    fy = r.y + r.uy * step;
+    fx = fma_(r.ux, step, r.x);
+    fy = fma_(r.uy, step, r.y);
 }
 template <typename T> __device__ __forceinline__ void adv_second(const Ray<T>& r, const Consts<T>& k, T& fx, T& fy) {
-    const T d = r.gx * r.ux + r.gy * r.uy;
+    const T d = fma_(r.gy, r.uy, r.gx * r.ux);  // np.dot on 2 elements rounds exactly like this
     const T s = k.step2 / (T(2) * r.n);
-    fx = (r.x + r.ux * k.step) + (r.gx - d * r.ux) * s;
-    fy = (r.y + r.uy * k.step) + (r.gy - d * r.uy) * s;
+    fx = fma_(fma_(-d, r.ux, r.gx), s, fma_(r.ux, k.step, r.x));
+    fy = fma_(fma_(-d, r.uy, r.gy), s, fma_(r.uy, k.step, r.y));
 }
 // returns the reference's flag: true == curvature NOT negligible (quirk Q14)
 template <typename T> __device__ __forceinline__ bool adv_curv(const Ray<T>& r, const Consts<T>& k, T& fx, T& fy) {
-    const T d = r.gx * r.ux + r.gy * r.uy;
-    const T vx = r.gx - d * r.ux, vy = r.gy - d * r.uy;
-    const T curv = M<T>::sqrt_(vx * vx + vy * vy) / r.n;
+    const T d = fma_(r.gy, r.uy, r.gx * r.ux);
+    const T vx = fma_(-d, r.ux, r.gx), vy = fma_(-d, r.uy, r.gy);
+    const T curv = M<T>::sqrt_(fma_(vy, vy, vx * vx)) / r.n;
     if (curv < T(1.4901161193847656e-08)) {  // GOLD_TOL (:355), same constant in both precisions
         adv_first(r, k.step, fx, fy);
         return false;
     }
     const T dc = curv * k.step;
-    const T sgn = (r.gx * r.uy - r.gy * r.ux > T(0)) ? T(-1) : T(1);  // np.cross (:360)
+    const T sgn = (r.gx * r.uy - r.gy * r.ux > T(0)) ? T(-1) : T(1);  // np.cross (:360), two rounded products
     T s2, c2;
-    M<T>::sincos_(r.th + sgn * dc, &s2, &c2);
+    M<T>::sincos_(sgn < T(0) ? r.th - dc : r.th + dc, &s2, &c2);
     // (:361) [sin th - sin(th-dc), cos(th-dc) - cos th]/curv ; (:363) [sin(th+dc) - sin th, -cos(th+dc) + cos th]/curv
     fx = r.x + (sgn < T(0) ? (r.uy - s2) : (s2 - r.uy)) / curv;
     fy = r.y + (sgn < T(0) ? (c2 - r.ux) : (-c2 + r.ux)) / curv;
@@ -200,20 +206,22 @@ template <typename T> __device__ __forceinline__ bool adv_curv(const Ray<T>& r, 
 
 // ---- angle determination (:370-407)
 template <typename T> __device__ __forceinline__ T ang_rk2(const Ray<T>& r, T step, T fn, T fgx, T fgy) {
-    const T k1 = step * (r.ux * r.gy - r.uy * r.gx) / r.n;
+    const T k1 = step * fma_(r.ux, r.gy, -(r.uy * r.gx)) / r.n;
     T s2, c2;
     M<T>::sincos_(r.th + k1, &s2, &c2);
-    const T k2 = step * (c2 * fgy - s2 * fgx) / fn;
+    const T k2 = step * fma_(c2, fgy, -(s2 * fgx)) / fn;
     return r.th + (k1 + k2) / T(2);
 }
 template <typename T> __device__ __forceinline__ T ang_cost(const Ray<T>& r, T step, T fgx, T fgy) {
-    return M<T>::atan2_(r.n * r.uy + impulse(r.gy, fgy, step), r.n * r.ux + impulse(r.gx, fgx, step));
+    return M<T>::atan2_(fma_(r.n, r.uy, impulse(r.gy, fgy, step)), fma_(r.n, r.ux, impulse(r.gx, fgx, step)));
 }
 
 // golden() (:175-199) on a cost functor; recomputes both cost values every iteration like the
 // reference (Q13) so the comparison sequence, and with it the returned midpoint, is the same.
 template <typename T, typename F> __device__ __forceinline__ T golden(F cost, T a, T b) {
     const T GR = T(kGoldRatio);
+    // bracket arithmetic stays unfused: the iteration count and the returned midpoint then follow the
+    // reference's roundings exactly
     T c = b - (b - a) * GR, d = a + (b - a) * GR;
     for (int it = 0; it < kGoldMaxIter && M<T>::abs_(c - d) > M<T>::gold_tol; ++it) {
         if (cost(c) < cost(d)) b = d; else a = c;
@@ -229,8 +237,8 @@ template <typename T> __device__ __forceinline__ T ang_golden_iso(const Ray<T>& 
     auto cost = [=](T t) {  // (:595, :697)
         T s, c;
         M<T>::sincos_(t, &s, &c);
-        const T ex = fn * c - px - ix, ey = fn * s - py - iy;
-        return ex * ex + ey * ey;
+        const T ex = fma_(fn, c, -px) - ix, ey = fma_(fn, s, -py) - iy;
+        return fma_(ey, ey, ex * ex);
     };
     return golden<T>(cost, r.th - T(kHalfPi), r.th + T(kHalfPi));
 }
@@ -248,7 +256,7 @@ __device__ __forceinline__ T ang_golden_aniso(const Ray<T>& r, const Consts<T>& 
         const T a = aniso(s, c, gam);
         const T ex = moment(fn, a, g2, c, -(s * s)) - mix - impulse(cgx, a * fgx, step);
         const T ey = moment(fn, a, g2, s, c * c) - miy - impulse(cgy, a * fgy, step);
-        return ex * ex + ey * ey;
+        return fma_(ey, ey, ex * ex);
     };
     return golden<T>(cost, r.th - T(kHalfPi), r.th + T(kHalfPi));
 }
@@ -281,7 +289,7 @@ __device__ __forceinline__ void op_step(const FieldDev<T>& F, const Consts<T>& k
 template <typename T>
 __device__ __forceinline__ void store_update(const Consts<T>& k, Ray<T>& r, T fx, T fy, T fth, T fn, T fgx, T fgy) {
     const T dx = r.x - fx, dy = r.y - fy;
-    const T dist = M<T>::sqrt_(dx * dx + dy * dy);
+    const T dist = M<T>::sqrt_(fma_(dy, dy, dx * dx));  // np.linalg.norm on 2 elements
     r.dsim += dist;
     r.dreal += k.step;  // quirk Q16: accumulated, not i*step
     T s, c;

@@ -61,8 +61,8 @@ __device__ static double scenario_n(int sc, double a, double b) {
     if (sc == RTMI_INTERFACE)  // :107 (exp overflows to inf for y < -3.55, result sqrt(2): same as numpy)
         return __dsqrt_rn(2.0) - (__dsqrt_rn(2.0) - 1.0) / (1.0 + exp(-b / 0.005));
     if (sc == RTMI_FISHEYE)    // :111
-        return 1.0 / (__dadd_rn(__dadd_rn(1.0, __dmul_rn(a, a)), __dmul_rn(b, b)));
-    return 1.0 / __dadd_rn(18.0, __dmul_rn(2.0, b));  // :115-116
+        return 1.0 / (1.0 + a * a + b * b);
+    return 1.0 / (18.0 + 2.0 * b);  // :115-116
 }
 
 __global__ void k_sample(int sc, double* Z, int qx, int qy, double ax, double hx, double bx, double ay, double hy,
@@ -73,7 +73,7 @@ __global__ void k_sample(int sc, double* Z, int qx, int qy, double ax, double hx
     Z[(size_t)i * qx + j] = scenario_n(sc, x, y);  // meshgrid X[i,j]=x[j], Y[i,j]=y[i] (:430-432)
 }
 
-// np.gradient(Z, delta, edge_order=2) along one axis (:450); numpy's unfused evaluation order.
+// np.gradient(Z, delta, edge_order=2) along one axis (:450); numpy's evaluation order (contraction is off).
 __global__ void k_gradient(const double* Z, double* out, int qx, int qy, int axis, double dx) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
     if (j >= qx || i >= qy) return;
@@ -82,9 +82,9 @@ __global__ void k_gradient(const double* Z, double* out, int qx, int qy, int axi
     const double* c = Z + (size_t)i * qx + j;
     double r;
     if (p == 0) {
-        r = __dadd_rn(__dadd_rn(__dmul_rn(-1.5 / dx, c[0]), __dmul_rn(2.0 / dx, c[s])), __dmul_rn(-0.5 / dx, c[2 * s]));
+        r = (-1.5 / dx) * c[0] + (2.0 / dx) * c[s] + (-0.5 / dx) * c[2 * s];
     } else if (p == n - 1) {
-        r = __dadd_rn(__dadd_rn(__dmul_rn(0.5 / dx, c[-2 * s]), __dmul_rn(-2.0 / dx, c[-s])), __dmul_rn(1.5 / dx, c[0]));
+        r = (0.5 / dx) * c[-2 * s] + (-2.0 / dx) * c[-s] + (1.5 / dx) * c[0];
     } else {
         r = (c[s] - c[-s]) / (2.0 * dx);
     }
