@@ -8,31 +8,81 @@ namespace rt {
 
 // The library is compiled with -ffp-contract=off: every fusion below is an explicit fma(), so a value is
 // computed with the same roundings wherever the function is inlined (results do not depend on how a run is
-// cut into launches or which kernel variant executes it).
+// cut into launches, on the ray->lane assignment, or on which kernel variant executes it).  For the same
+// reason every data-dependent choice between two formulas below is made PER LANE from that ray's own
+// values, never from a wave vote.
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+// ---------------------------------------------------------------- sin/cos
+// fp64 sincos: 3-constant Cody-Waite reduction by pi/2 (the first step is exact under fma, so the reduction
+// holds ~1e-16 relative accuracy in r for every |x| < 2^30) and the fdlibm minimax kernels on [-pi/4, pi/4];
+// <= 1 ulp.  No data-dependent branch; |x| >= 2^30 or non-finite x gives NaN.
+__device__ __forceinline__ void sincos_k(double x, double* sp, double* cp) {
+    const double n = __builtin_rint(x * 6.36619772367581382433e-01);
+    double r = fma_(-n, 1.57079632679489655800e+00, x);
+    r = fma_(-n, 6.12323399573676603587e-17, r);
+    r = fma_(-n, -1.49738490485916983294e-33, r);
+    r = __builtin_fabs(x) < 1073741824.0 ? r : __builtin_nan("");
+    const double z = r * r;
+    double ps = fma_(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = fma_(z, ps, 2.75573137070700676789e-06);
+    ps = fma_(z, ps, -1.98412698298579493134e-04);
+    ps = fma_(z, ps, 8.33333333332248946124e-03);
+    ps = fma_(z, ps, -1.66666666666666324348e-01);
+    const double s = fma_(z * r, ps, r);
+    double pc = fma_(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = fma_(z, pc, -2.75573143513906633035e-07);
+    pc = fma_(z, pc, 2.48015872894767294178e-05);
+    pc = fma_(z, pc, -1.38888888888741095749e-03);
+    pc = fma_(z, pc, 4.16666666666666019037e-02);
+    const double c = fma_(z * z, pc, fma_(-0.5, z, 1.0));
+    const int q = (int)n;
+    const double ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    *sp = (q & 2) ? -ss : ss;
+    *cp = ((q + 1) & 2) ? -cc : cc;
+}
 
 // ---------------------------------------------------------------- math traits
 template <typename T> struct M;
 template <> struct M<double> {
     static __device__ __forceinline__ double sqrt_(double x) { return __dsqrt_rn(x); }
-    static __device__ __forceinline__ void sincos_(double x, double* s, double* c) { ::sincos(x, s, c); }
+    static __device__ __forceinline__ void sincos_(double x, double* s, double* c) { sincos_k(x, s, c); }
     static __device__ __forceinline__ double atan2_(double y, double x) { return ::atan2(y, x); }
-    static __device__ __forceinline__ double abs_(double x) { return ::fabs(x); }
-    static __device__ __forceinline__ double exp_(double x) { return ::exp(x); }
+    static __device__ __forceinline__ double abs_(double x) { return __builtin_fabs(x); }
     // x[i] of numpy.linspace: i*step + a with separate roundings (contraction is off), so knots equal the host's bit for bit
     static __device__ __forceinline__ double lin(int i, double h, double a) { return (double)i * h + a; }
     static constexpr double gold_tol = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON), RT_bench.py:66
+    static constexpr double small_angle = 0.015625;             // 2^-6: sincos_add's series bound
 };
 template <> struct M<float> {
     static __device__ __forceinline__ float sqrt_(float x) { return __fsqrt_rn(x); }
     static __device__ __forceinline__ void sincos_(float x, float* s, float* c) { ::sincosf(x, s, c); }
     static __device__ __forceinline__ float atan2_(float y, float x) { return ::atan2f(y, x); }
-    static __device__ __forceinline__ float abs_(float x) { return ::fabsf(x); }
-    static __device__ __forceinline__ float exp_(float x) { return ::expf(x); }
+    static __device__ __forceinline__ float abs_(float x) { return __builtin_fabsf(x); }
     static __device__ __forceinline__ float lin(int i, float h, float a) { return (float)i * h + a; }
     static constexpr float gold_tol = 3.4526698300124393e-04f;  // sqrt(FLT_EPSILON): the fp32 analogue
+    static constexpr float small_angle = 0.015625f;
 };
+
+// sin/cos of (theta + k) given s = sin(theta), c = cos(theta): for |k| < 2^-6 the angle-addition formulas
+// with 4-term series of sin k and 1 - cos k (truncation < 1e-19 relative), else a full evaluation.
+template <typename T> __device__ __forceinline__ void sincos_add(T theta, T s, T c, T k, T* so, T* co) {
+    if (M<T>::abs_(k) < M<T>::small_angle) {
+        const T z = k * k;
+        T ps = fma_(z, T(-1.0 / 5040.0), T(1.0 / 120.0));
+        ps = fma_(z, ps, T(-1.0 / 6.0));
+        const T sk = fma_(z * k, ps, k);                 // sin k
+        T pc = fma_(z, T(-1.0 / 40320.0), T(1.0 / 720.0));
+        pc = fma_(z, pc, T(-1.0 / 24.0));
+        pc = fma_(z, pc, T(0.5));
+        const T ck1 = z * pc;                            // 1 - cos k
+        *so = fma_(c, sk, fma_(-s, ck1, s));
+        *co = fma_(-s, sk, fma_(-c, ck1, c));
+    } else {
+        M<T>::sincos_(theta + k, so, co);
+    }
+}
 
 constexpr double kGoldRatio = 0.6180339887498949;   // (sqrt(5)-1)/2, RT_bench.py:65
 constexpr double kHalfPi = 1.5707963267948966;      // DELTA_G, RT_bench.py:64
@@ -47,25 +97,28 @@ template <typename T> struct FieldDev {
     const T* zn;
     const T* g;
     int qx, qy;
-    T ax, hx, bx, inv_hx;
-    T ay, hy, by, inv_hy;
+    T ax, hx, bx, inv_hx, inv_3hx;
+    T ay, hy, by, inv_hy, inv_3hy;
 };
 
 template <typename T> __device__ __forceinline__ T axis_at(int i, int q, T a, T h, T b) {
     return i >= q - 1 ? b : M<T>::lin(i, h, a);
 }
 
-// fpbisp's argument clamp (quirk Q4) and interval search, on a linspace axis: returns j with
-// x[j] <= v < x[j+1], j in [0, q-2] (v == x[q-1] gives q-2).
-template <typename T> __device__ __forceinline__ int locate(T& v, int q, T a, T h, T b, T inv_h) {
+// fpbisp's argument clamp (quirk Q4) and interval search on a linspace axis: j with x[j] <= v < x[j+1],
+// j in [0, q-2] (v == x[q-1] gives q-2); also returns t0 = x[j], t1 = x[j+1].  The guess from one multiply is
+// off by at most one cell, and only when v sits within rounding of a grid line (rare, per-lane fix-up).
+template <typename T> __device__ __forceinline__ int locate(T& v, int q, T a, T h, T b, T inv_h, T& t0, T& t1) {
     v = v < a ? a : v;
     v = v > b ? b : v;
     int j = (int)((v - a) * inv_h);
     j = j < 0 ? 0 : (j > q - 2 ? q - 2 : j);
-    if (axis_at(j, q, a, h, b) > v) {
-        j = j > 0 ? j - 1 : 0;
-    } else if (j < q - 2 && axis_at(j + 1, q, a, h, b) <= v) {
-        j = j + 1;
+    t0 = M<T>::lin(j, h, a);
+    t1 = axis_at(j + 1, q, a, h, b);
+    if (t0 > v) {
+        if (j > 0) { j -= 1; t1 = t0; t0 = M<T>::lin(j, h, a); }
+    } else if (t1 <= v && j < q - 2) {
+        j += 1; t0 = t1; t1 = axis_at(j + 1, q, a, h, b);
     }
     return j;
 }
@@ -75,37 +128,77 @@ template <typename T> __device__ __forceinline__ T knot3(int l, int q, T a, T h,
     return l <= 3 ? a : (l >= q ? b : M<T>::lin(l - 2, h, a));
 }
 
-// FITPACK fpbspl, k = 3: the four non-zero cubic B-splines on [t[l], t[l+1]) at v.
-template <typename T> __device__ __forceinline__ void bspl3(T v, int l, int q, T a, T h, T b, T w[4]) {
-    const T tm2 = knot3(l - 2, q, a, h, b), tm1 = knot3(l - 1, q, a, h, b), t0 = knot3(l, q, a, h, b);
-    const T t1 = knot3(l + 1, q, a, h, b), t2 = knot3(l + 2, q, a, h, b), t3 = knot3(l + 3, q, a, h, b);
-    // j = 1
-    T f = T(1) / (t1 - t0);
-    T h0 = f * (t1 - v), h1 = f * (v - t0);
-    // j = 2
-    f = h0 / (t1 - tm1);
-    T g0 = f * (t1 - v), g1 = f * (v - tm1);
-    f = h1 / (t2 - t0);
-    g1 = fma_(f, t2 - v, g1);
-    T g2 = f * (v - t0);
-    // j = 3
-    f = g0 / (t1 - tm2);
-    w[0] = f * (t1 - v);
-    w[1] = f * (v - tm2);
-    f = g1 / (t2 - tm1);
-    w[1] = fma_(f, t2 - v, w[1]);
-    w[2] = f * (v - tm1);
-    f = g2 / (t3 - t0);
-    w[2] = fma_(f, t3 - v, w[2]);
-    w[3] = f * (v - t0);
+// 1/d for a knot difference d that equals r0^-1 up to grid rounding (d = k*h*(1 + O(1e-13))): one Newton
+// step from r0 is accurate to < 1 ulp and costs two fma instead of an IEEE division.
+template <typename T> __device__ __forceinline__ T rcp_near(T d, T r0) { return fma_(r0, fma_(-d, r0, T(1)), r0); }
+
+// 1/d to < 1 ulp from the hardware estimate (v_rcp, ~23 bits) and two Newton steps; used where no good
+// starting value is known (the not-a-knot end intervals).
+__device__ __forceinline__ double rcp_full(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    r = fma_(r, fma_(-d, r, 1.0), r);
+    return fma_(r, fma_(-d, r, 1.0), r);
+}
+__device__ __forceinline__ float rcp_full(float d) { return 1.0f / d; }
+
+// One axis of n_gradient's basis: cell j (from locate, with t0 = x[j], t1 = x[j+1]) -> the two linear weights
+// (fpbspl k=1 on [t0, t1]) and the four cubic weights (fpbspl k=3 on FITPACK's interval l = clamp(j+2, 3, q-1)).
+// Interior cells (4 <= j <= q-6: the six cubic knots are the consecutive grid points x[j-2..j+3]) reuse t0/t1
+// and take the six knot-difference reciprocals by rcp_near; the not-a-knot end intervals use the general
+// knot rule and rcp_full.  Returns l.
+template <typename T>
+__device__ __forceinline__ int axis_basis(T v, int j, T t0, T t1, int q, T a, T h, T b, T ih, T i3h, T wl[2], T w[4]) {
+    const T i2h = ih * T(0.5);
+    {   // linear: f = 1/(t1 - t0); h0 = f*(t1 - v), h1 = f*(v - t0)
+        const T f = rcp_near(t1 - t0, ih);
+        wl[0] = f * (t1 - v);
+        wl[1] = f * (v - t0);
+    }
+    int l = j + 2;
+    T tm2, tm1, k0, k1, t2, t3, r10, r1m1, r20, r1m2, r2m1, r30;
+    if (j >= 4 && j <= q - 6) {
+        tm2 = M<T>::lin(j - 2, h, a); tm1 = M<T>::lin(j - 1, h, a); k0 = t0; k1 = t1;
+        t2 = M<T>::lin(j + 2, h, a); t3 = M<T>::lin(j + 3, h, a);
+        r10 = rcp_near(k1 - k0, ih);
+        r1m1 = rcp_near(k1 - tm1, i2h); r20 = rcp_near(t2 - k0, i2h);
+        r1m2 = rcp_near(k1 - tm2, i3h); r2m1 = rcp_near(t2 - tm1, i3h); r30 = rcp_near(t3 - k0, i3h);
+    } else {
+        l = l < 3 ? 3 : (l > q - 1 ? q - 1 : l);
+        tm2 = knot3(l - 2, q, a, h, b); tm1 = knot3(l - 1, q, a, h, b); k0 = knot3(l, q, a, h, b);
+        k1 = knot3(l + 1, q, a, h, b); t2 = knot3(l + 2, q, a, h, b); t3 = knot3(l + 3, q, a, h, b);
+        r10 = rcp_full(k1 - k0);
+        r1m1 = rcp_full(k1 - tm1); r20 = rcp_full(t2 - k0);
+        r1m2 = rcp_full(k1 - tm2); r2m1 = rcp_full(t2 - tm1); r30 = rcp_full(t3 - k0);
+    }
+    const T a1 = k1 - v, a2 = t2 - v, a3 = t3 - v;      // t[li] - x
+    const T b0 = v - k0, bm1 = v - tm1, bm2 = v - tm2;  // x - t[lj]
+    // fpbspl recurrence, j = 1, 2, 3, with f = hh[i] / (t[li] - t[lj]) taken as hh[i] * reciprocal
+    const T h0 = r10 * a1, h1 = r10 * b0;
+    T f = h0 * r1m1;
+    const T g0 = f * a1;
+    T g1 = f * bm1;
+    f = h1 * r20;
+    g1 = fma_(f, a2, g1);
+    const T g2 = f * b0;
+    f = g0 * r1m2;
+    w[0] = f * a1;
+    w[1] = f * bm2;
+    f = g1 * r2m1;
+    w[1] = fma_(f, a2, w[1]);
+    w[2] = f * bm1;
+    f = g2 * r30;
+    w[2] = fma_(f, a3, w[2]);
+    w[3] = f * b0;
+    return l;
 }
 
 // n_gradient(vector, grd, z) (:141-156): bilinear n, bicubic dn/dx and dn/dy at (x, y).
 // 36 coefficients are gathered per call: 2x2 of zn and a 4x4 window of interleaved pairs.
 template <typename T>
 __device__ __forceinline__ void n_gradient(const FieldDev<T>& F, T x, T y, T& n, T& gx, T& gy) {
-    const int jx = locate(x, F.qx, F.ax, F.hx, F.bx, F.inv_hx);
-    const int jy = locate(y, F.qy, F.ay, F.hy, F.by, F.inv_hy);
+    T xa, xb, ya, yb;
+    const int jx = locate(x, F.qx, F.ax, F.hx, F.bx, F.inv_hx, xa, xb);
+    const int jy = locate(y, F.qy, F.ay, F.hy, F.by, F.inv_hy, ya, yb);
     // ---- gather (issued first; the basis evaluation below needs no memory)
     int lx = jx + 2; lx = lx < 3 ? 3 : (lx > F.qx - 1 ? F.qx - 1 : lx);
     int ly = jy + 2; ly = ly < 3 ? 3 : (ly > F.qy - 1 ? F.qy - 1 : ly);
@@ -118,30 +211,23 @@ __device__ __forceinline__ void n_gradient(const FieldDev<T>& F, T x, T y, T& n,
 #pragma unroll
         for (int q = 0; q < 8; q++) c[r][q] = gp[(size_t)r * F.qx * 2 + q];
     }
-    // ---- bilinear n: fpbspl k=1 on knots x[jx], x[jx+1]
-    {
-        const T xa = axis_at(jx, F.qx, F.ax, F.hx, F.bx), xb = axis_at(jx + 1, F.qx, F.ax, F.hx, F.bx);
-        const T ya = axis_at(jy, F.qy, F.ay, F.hy, F.by), yb = axis_at(jy + 1, F.qy, F.ay, F.hy, F.by);
-        const T fx = T(1) / (xb - xa), fy = T(1) / (yb - ya);
-        const T wx0 = fx * (xb - x), wx1 = fx * (x - xa);
-        const T wy0 = fy * (yb - y), wy1 = fy * (y - ya);
-        n = fma_(z11 * wy1, wx1, fma_(z10 * wy1, wx0, fma_(z01 * wy0, wx1, (z00 * wy0) * wx0)));
-    }
-    // ---- bicubic gradient: shared basis for both components (same knots)
-    T wx[4], wy[4];
-    bspl3(x, lx, F.qx, F.ax, F.hx, F.bx, wx);
-    bspl3(y, ly, F.qy, F.ay, F.hy, F.by, wy);
+    T lwx[2], lwy[2], wx[4], wy[4];
+    axis_basis(x, jx, xa, xb, F.qx, F.ax, F.hx, F.bx, F.inv_hx, F.inv_3hx, lwx, wx);
+    axis_basis(y, jy, ya, yb, F.qy, F.ay, F.hy, F.by, F.inv_hy, F.inv_3hy, lwy, wy);
+    // ---- bilinear n (fpbisp order: c * w_y * w_x)
+    n = fma_(z11 * lwy[1], lwx[1], fma_(z10 * lwy[1], lwx[0], fma_(z01 * lwy[0], lwx[1], (z00 * lwy[0]) * lwx[0])));
+    // ---- bicubic gradient: shared basis for both components (same knots); row sums, then the column sum
     T sx = 0, sy = 0;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        T rx = 0, ry = 0;
+        T rx = c[r][0] * wx[0], ry = c[r][1] * wx[0];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 1; q < 4; q++) {
             rx = fma_(c[r][2 * q], wx[q], rx);
             ry = fma_(c[r][2 * q + 1], wx[q], ry);
         }
-        sx = fma_(rx, wy[r], sx);
-        sy = fma_(ry, wy[r], sy);
+        sx = r == 0 ? rx * wy[0] : fma_(rx, wy[r], sx);
+        sy = r == 0 ? ry * wy[0] : fma_(ry, wy[r], sy);
     }
     gx = sx;
     gy = sy;
@@ -151,28 +237,31 @@ __device__ __forceinline__ void n_gradient(const FieldDev<T>& F, T x, T y, T& n,
 template <typename T> struct Ray {
     T x, y, th, n, gx, gy;   // position, angle, index, gradient at the current point
     T ux, uy, coef, nray;    // derived: unit tangent, anisotropy(theta,gamma), coef*n
+    T rn;                    // derived: 1/n (IEEE), shared by the three divisions by n of a step
     T dsim, dreal, tt;       // simulated / expected arclength, traveltime
     T mx, my;                // momenta of the current row (output only)
     T hx0, hy0, hx1, hy1;    // op7: the two positions before (x,y), oldest first (VECTOR_LIST, Q11)
 };
 
 template <typename T> struct Consts {
-    T step, step2;           // DELTA_S and pow(DELTA_S, 2) (host-computed, :330)
+    T step, step2h;          // DELTA_S and pow(DELTA_S, 2)/2 (host-computed from numpy's step**2, :330)
     T gamma, g2m1;           // trazar's gamma, gamma**2-1 (:230)
     T gamma_s, g2m1_s;       // module-global gamma of op10/op11 (Q12)
     T box[4];
 };
 
-// anisotropy(theta, gamma) (:118-119) from sin/cos
-template <typename T> __device__ __forceinline__ T aniso(T s, T c, T gamma) {
-    const T gs = gamma * s;
+// anisotropy(theta, gamma) (:118-119) from sin/cos.  ISO (gamma == 1): sqrt(s^2 + c^2), which is 1 +- ulp
+// and is kept (quirk Q5), the product gamma*s is exact.
+template <typename T, bool ISO> __device__ __forceinline__ T aniso(T s, T c, T gamma) {
+    const T gs = ISO ? s : gamma * s;
     return M<T>::sqrt_(fma_(gs, gs, c * c));
 }
-// moment() (:217-230) given coef = anisotropy(theta, gamma)
-template <typename T> __device__ __forceinline__ T moment(T n, T coef, T g2m1, T o0, T o1) {
+// moment() (:217-230) given coef = anisotropy(theta, gamma).  ISO: gamma**2-1 == 0 makes the bracket exactly 1.
+template <typename T, bool ISO> __device__ __forceinline__ T moment(T n, T coef, T g2m1, T o0, T o1) {
+    if (ISO) return n * coef * o0;
     return n * coef * o0 * (T(1) + o1 * g2m1 / (coef * coef));
 }
-template <typename T> __device__ __forceinline__ T impulse(T a, T b, T step) { return step * (a + b) / T(2); }
+template <typename T> __device__ __forceinline__ T impulse(T a, T b, T step) { return step * (a + b) * T(0.5); }
 
 // ---- advancement (:300-365)
 template <typename T> __device__ __forceinline__ void adv_first(const Ray<T>& r, T step, T& fx, T& fy) {
@@ -181,7 +270,7 @@ template <typename T> __device__ __forceinline__ void adv_first(const Ray<T>& r,
 }
 template <typename T> __device__ __forceinline__ void adv_second(const Ray<T>& r, const Consts<T>& k, T& fx, T& fy) {
     const T d = fma_(r.gy, r.uy, r.gx * r.ux);  // np.dot on 2 elements rounds exactly like this
-    const T s = k.step2 / (T(2) * r.n);
+    const T s = k.step2h * r.rn;                // step**2 / (2 n)
     fx = fma_(fma_(-d, r.ux, r.gx), s, fma_(r.ux, k.step, r.x));
     fy = fma_(fma_(-d, r.uy, r.gy), s, fma_(r.uy, k.step, r.y));
 }
@@ -189,28 +278,30 @@ template <typename T> __device__ __forceinline__ void adv_second(const Ray<T>& r
 template <typename T> __device__ __forceinline__ bool adv_curv(const Ray<T>& r, const Consts<T>& k, T& fx, T& fy) {
     const T d = fma_(r.gy, r.uy, r.gx * r.ux);
     const T vx = fma_(-d, r.ux, r.gx), vy = fma_(-d, r.uy, r.gy);
-    const T curv = M<T>::sqrt_(fma_(vy, vy, vx * vx)) / r.n;
+    const T curv = M<T>::sqrt_(fma_(vy, vy, vx * vx)) * r.rn;
     if (curv < T(1.4901161193847656e-08)) {  // GOLD_TOL (:355), same constant in both precisions
         adv_first(r, k.step, fx, fy);
         return false;
     }
     const T dc = curv * k.step;
-    const T sgn = (r.gx * r.uy - r.gy * r.ux > T(0)) ? T(-1) : T(1);  // np.cross (:360), two rounded products
+    const bool neg = r.gx * r.uy - r.gy * r.ux > T(0);  // np.cross (:360), two rounded products
     T s2, c2;
-    M<T>::sincos_(sgn < T(0) ? r.th - dc : r.th + dc, &s2, &c2);
+    M<T>::sincos_(neg ? r.th - dc : r.th + dc, &s2, &c2);
     // (:361) [sin th - sin(th-dc), cos(th-dc) - cos th]/curv ; (:363) [sin(th+dc) - sin th, -cos(th+dc) + cos th]/curv
-    fx = r.x + (sgn < T(0) ? (r.uy - s2) : (s2 - r.uy)) / curv;
-    fy = r.y + (sgn < T(0) ? (c2 - r.ux) : (-c2 + r.ux)) / curv;
+    const T rc = T(1) / curv;
+    fx = fma_(neg ? (r.uy - s2) : (s2 - r.uy), rc, r.x);
+    fy = fma_(neg ? (c2 - r.ux) : (-c2 + r.ux), rc, r.y);
     return true;
 }
 
 // ---- angle determination (:370-407)
-template <typename T> __device__ __forceinline__ T ang_rk2(const Ray<T>& r, T step, T fn, T fgx, T fgy) {
-    const T k1 = step * fma_(r.ux, r.gy, -(r.uy * r.gx)) / r.n;
+// fn_rcp = 1/fn; the intermediate angle theta+k1 is never stored, so its sin/cos come from sincos_add.
+template <typename T> __device__ __forceinline__ T ang_rk2(const Ray<T>& r, T step, T fn_rcp, T fgx, T fgy) {
+    const T k1 = step * fma_(r.ux, r.gy, -(r.uy * r.gx)) * r.rn;
     T s2, c2;
-    M<T>::sincos_(r.th + k1, &s2, &c2);
-    const T k2 = step * fma_(c2, fgy, -(s2 * fgx)) / fn;
-    return r.th + (k1 + k2) / T(2);
+    sincos_add(r.th, r.uy, r.ux, k1, &s2, &c2);
+    const T k2 = step * fma_(c2, fgy, -(s2 * fgx)) * fn_rcp;
+    return r.th + (k1 + k2) * T(0.5);
 }
 template <typename T> __device__ __forceinline__ T ang_cost(const Ray<T>& r, T step, T fgx, T fgy) {
     return M<T>::atan2_(fma_(r.n, r.uy, impulse(r.gy, fgy, step)), fma_(r.n, r.ux, impulse(r.gx, fgx, step)));
@@ -228,7 +319,7 @@ template <typename T, typename F> __device__ __forceinline__ T golden(F cost, T 
         c = b - (b - a) * GR;
         d = a + (b - a) * GR;
     }
-    return (b + a) / T(2);
+    return (b + a) * T(0.5);
 }
 
 template <typename T> __device__ __forceinline__ T ang_golden_iso(const Ray<T>& r, T step, T fn, T fgx, T fgy) {
@@ -245,34 +336,36 @@ template <typename T> __device__ __forceinline__ T ang_golden_iso(const Ray<T>& 
 template <typename T>
 __device__ __forceinline__ T ang_golden_aniso(const Ray<T>& r, const Consts<T>& k, T fn, T fgx, T fgy) {
     // (:725-728 / :758-761); the step functions read the module-global gamma (Q12)
-    const T c0 = aniso(r.uy, r.ux, k.gamma_s);
-    const T mix = moment(r.n, c0, k.g2m1_s, r.ux, -(r.uy * r.uy));
-    const T miy = moment(r.n, c0, k.g2m1_s, r.uy, r.ux * r.ux);
+    const T c0 = aniso<T, false>(r.uy, r.ux, k.gamma_s);
+    const T mix = moment<T, false>(r.n, c0, k.g2m1_s, r.ux, -(r.uy * r.uy));
+    const T miy = moment<T, false>(r.n, c0, k.g2m1_s, r.uy, r.ux * r.ux);
     const T cgx = r.coef * r.gx, cgy = r.coef * r.gy;
     const T gam = k.gamma_s, g2 = k.g2m1_s, step = k.step;
     auto cost = [=](T t) {
         T s, c;
         M<T>::sincos_(t, &s, &c);
-        const T a = aniso(s, c, gam);
-        const T ex = moment(fn, a, g2, c, -(s * s)) - mix - impulse(cgx, a * fgx, step);
-        const T ey = moment(fn, a, g2, s, c * c) - miy - impulse(cgy, a * fgy, step);
+        const T a = aniso<T, false>(s, c, gam);
+        const T q = fn * a, w = g2 / (a * a);       // n*coef and (gamma**2-1)/coef**2, shared by both moments
+        const T ex = q * c * (T(1) + -(s * s) * w) - mix - impulse(cgx, a * fgx, step);
+        const T ey = q * s * (T(1) + (c * c) * w) - miy - impulse(cgy, a * fgy, step);
         return fma_(ey, ey, ex * ex);
     };
     return golden<T>(cost, r.th - T(kHalfPi), r.th + T(kHalfPi));
 }
 
-// ---- opN (:469-764): final position / angle / n / gradient of one DELTA_S step
+// ---- opN (:469-764): final position / angle / n / gradient of one DELTA_S step (+ 1/n at the new point)
 template <typename T, int METHOD>
 __device__ __forceinline__ void op_step(const FieldDev<T>& F, const Consts<T>& k, const Ray<T>& r, T& fx, T& fy,
-                                        T& fth, T& fn, T& fgx, T& fgy) {
+                                        T& fth, T& fn, T& fgx, T& fgy, T& frn) {
     bool flag = true;
     if constexpr (METHOD == 1 || METHOD == 2) adv_first(r, k.step, fx, fy);
     else if constexpr (METHOD == 3 || METHOD == 4 || METHOD == 5 || METHOD == 10) flag = adv_curv(r, k, fx, fy);
     else adv_second(r, k, fx, fy);
     n_gradient(F, fx, fy, fn, fgx, fgy);
+    frn = T(1) / fn;
     if constexpr (METHOD == 1 || METHOD == 8) fth = ang_cost(r, k.step, fgx, fgy);
-    else if constexpr (METHOD == 2 || METHOD == 6) fth = ang_rk2(r, k.step, fn, fgx, fgy);
-    else if constexpr (METHOD == 3) fth = flag ? ang_rk2(r, k.step, fn, fgx, fgy) : r.th;
+    else if constexpr (METHOD == 2 || METHOD == 6) fth = ang_rk2(r, k.step, frn, fgx, fgy);
+    else if constexpr (METHOD == 3) fth = flag ? ang_rk2(r, k.step, frn, fgx, fgy) : r.th;
     else if constexpr (METHOD == 4) fth = flag ? ang_cost(r, k.step, fgx, fgy) : r.th;
     else if constexpr (METHOD == 5) fth = flag ? ang_golden_iso(r, k.step, fn, fgx, fgy) : r.th;
     else if constexpr (METHOD == 9) fth = ang_golden_iso(r, k.step, fn, fgx, fgy);
@@ -286,32 +379,34 @@ __device__ __forceinline__ void op_step(const FieldDev<T>& F, const Consts<T>& k
 }
 
 // store_update_results (:783-790) + the row bookkeeping of the loop body (:871-875)
-template <typename T>
-__device__ __forceinline__ void store_update(const Consts<T>& k, Ray<T>& r, T fx, T fy, T fth, T fn, T fgx, T fgy) {
+template <typename T, bool ISO>
+__device__ __forceinline__ void store_update(const Consts<T>& k, Ray<T>& r, T fx, T fy, T fth, T fn, T fgx, T fgy,
+                                             T frn) {
     const T dx = r.x - fx, dy = r.y - fy;
     const T dist = M<T>::sqrt_(fma_(dy, dy, dx * dx));  // np.linalg.norm on 2 elements
     r.dsim += dist;
     r.dreal += k.step;  // quirk Q16: accumulated, not i*step
     T s, c;
     M<T>::sincos_(fth, &s, &c);
-    const T coef = aniso(s, c, k.gamma);
-    r.mx = moment(fn, coef, k.g2m1, c, -(s * s));
-    r.my = moment(fn, coef, k.g2m1, s, c * c);
+    const T coef = aniso<T, ISO>(s, c, k.gamma);
+    r.mx = moment<T, ISO>(fn, coef, k.g2m1, c, -(s * s));
+    r.my = moment<T, ISO>(fn, coef, k.g2m1, s, c * c);
     r.hx0 = r.hx1; r.hy0 = r.hy1; r.hx1 = r.x; r.hy1 = r.y;
-    r.x = fx; r.y = fy; r.th = fth; r.n = fn; r.gx = fgx; r.gy = fgy;
+    r.x = fx; r.y = fy; r.th = fth; r.n = fn; r.gx = fgx; r.gy = fgy; r.rn = frn;
     r.ux = c; r.uy = s; r.coef = coef;
-    const T nray = coef * fn;                           // (:873)
-    r.tt = r.tt + dist * (r.nray + nray) / T(2);        // (:874) quirk Q6
+    const T nray = coef * fn;                               // (:873)
+    r.tt = r.tt + dist * (r.nray + nray) * T(0.5);          // (:874) quirk Q6
     r.nray = nray;
 }
 
 // derived quantities from the stored state (used when a launch (re)loads a ray from HBM)
-template <typename T> __device__ __forceinline__ void derive(const Consts<T>& k, Ray<T>& r) {
+template <typename T, bool ISO> __device__ __forceinline__ void derive(const Consts<T>& k, Ray<T>& r) {
     M<T>::sincos_(r.th, &r.uy, &r.ux);
-    r.coef = aniso(r.uy, r.ux, k.gamma);
+    r.coef = aniso<T, ISO>(r.uy, r.ux, k.gamma);
     r.nray = r.coef * r.n;
-    r.mx = moment(r.n, r.coef, k.g2m1, r.ux, -(r.uy * r.uy));
-    r.my = moment(r.n, r.coef, k.g2m1, r.uy, r.ux * r.ux);
+    r.rn = T(1) / r.n;
+    r.mx = moment<T, ISO>(r.n, r.coef, k.g2m1, r.ux, -(r.uy * r.uy));
+    r.my = moment<T, ISO>(r.n, r.coef, k.g2m1, r.uy, r.ux * r.ux);
 }
 
 template <typename T> __device__ __forceinline__ bool outside(const Consts<T>& k, const Ray<T>& r) {  // (:878)
@@ -320,21 +415,22 @@ template <typename T> __device__ __forceinline__ bool outside(const Consts<T>& k
 
 // One iteration of trazar's loop for row index i (the row being produced).  For op7 rows 1 and 2 are
 // the bootstrap steps (:833-864): first- and second-order backward differences and no boundary test.
-template <typename T, int METHOD>
+template <typename T, int METHOD, bool ISO>
 __device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& k, Ray<T>& r, int i) {
-    T fx, fy, fth, fn, fgx, fgy;
+    T fx, fy, fth, fn, fgx, fgy, frn;
     if (METHOD == 7 && i <= 2) {
         adv_second(r, k, fx, fy);
         n_gradient(F, fx, fy, fn, fgx, fgy);
+        frn = T(1) / fn;
         T vx, vy;
         if (i == 1) { vx = fx - r.x; vy = fy - r.y; }                                          // (:843)
         else { vx = T(3) * fx - T(4) * r.x + r.hx1; vy = T(3) * fy - T(4) * r.y + r.hy1; }     // (:856)
         fth = M<T>::atan2_(vy, vx);
-        store_update(k, r, fx, fy, fth, fn, fgx, fgy);
+        store_update<T, ISO>(k, r, fx, fy, fth, fn, fgx, fgy, frn);
         return true;  // still alive (no boundary test in the bootstrap)
     }
-    op_step<T, METHOD>(F, k, r, fx, fy, fth, fn, fgx, fgy);
-    store_update(k, r, fx, fy, fth, fn, fgx, fgy);
+    op_step<T, METHOD>(F, k, r, fx, fy, fth, fn, fgx, fgy, frn);
+    store_update<T, ISO>(k, r, fx, fy, fth, fn, fgx, fgy, frn);
     return !outside(k, r);
 }
 

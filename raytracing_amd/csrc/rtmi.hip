@@ -51,8 +51,10 @@ template <typename T> static rt::FieldDev<T> field_dev(const rtmi_field* f) {
     F.zn = (const T*)f->zn;
     F.g = (const T*)f->g;
     F.qx = f->qx; F.qy = f->qy;
-    F.ax = (T)f->ax; F.hx = (T)f->hx; F.bx = (T)f->bx; F.inv_hx = (T)(1.0 / f->hx);
-    F.ay = (T)f->ay; F.hy = (T)f->hy; F.by = (T)f->by; F.inv_hy = (T)(1.0 / f->hy);
+    F.ax = (T)f->ax; F.hx = (T)f->hx; F.bx = (T)f->bx;
+    F.inv_hx = (T)(1.0 / f->hx); F.inv_3hx = (T)(1.0 / (3.0 * f->hx));
+    F.ay = (T)f->ay; F.hy = (T)f->hy; F.by = (T)f->by;
+    F.inv_hy = (T)(1.0 / f->hy); F.inv_3hy = (T)(1.0 / (3.0 * f->hy));
     return F;
 }
 
@@ -377,7 +379,7 @@ template <typename T> __global__ void k_init(BatchDev<T> a) {
     rt::Ray<T> r;
     r.x = (T)a.x0[k]; r.y = (T)a.y0[k]; r.th = (T)a.th0[k];
     rt::n_gradient<T>(a.F, r.x, r.y, r.n, r.gx, r.gy);
-    rt::derive<T>(a.K, r);
+    rt::derive<T, false>(a.K, r);
     r.dsim = 0; r.dreal = 0; r.tt = 0;
     a.x[k] = r.x; a.y[k] = r.y; a.th[k] = r.th; a.n[k] = r.n; a.gx[k] = r.gx; a.gy[k] = r.gy;
     a.dsim[k] = 0; a.dreal[k] = 0; a.tt[k] = 0;
@@ -394,8 +396,10 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
 }
 
 // The loop at :866-879: one lane per ray, state in registers for up to nsteps DELTA_S steps.
-template <typename T, int METHOD, bool RECORD>
-__global__ __launch_bounds__(256) void k_advance(BatchDev<T> a, int nsteps) {
+// ISO (gamma == 1) drops the anisotropic factor's dead arithmetic; results are bit-identical either way.
+template <typename T, int METHOD, bool ISO>
+__global__ __launch_bounds__(256, 2) void k_advance(BatchDev<T> a, int nsteps) {
+    const bool RECORD = a.stride != 0;
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned done = 0, live = 0;
     if (k < a.R && a.alive[k]) {
@@ -404,14 +408,14 @@ __global__ __launch_bounds__(256) void k_advance(BatchDev<T> a, int nsteps) {
         r.dsim = a.dsim[k]; r.dreal = a.dreal[k]; r.tt = a.tt[k];
         if (METHOD == 7) { r.hx0 = a.hist[k]; r.hy0 = a.hist[a.R + k]; r.hx1 = a.hist[2 * a.R + k]; r.hy1 = a.hist[3 * a.R + k]; }
         else { r.hx0 = r.hy0 = r.hx1 = r.hy1 = 0; }
-        rt::derive<T>(a.K, r);
+        rt::derive<T, ISO>(a.K, r);
         int i = a.istep[k];
         int until = RECORD ? a.stride - (i % a.stride) : 0;  // steps until the next recorded row
         long row = RECORD ? i / a.stride : 0;
         bool alive = true;
         for (int it = 0; it < nsteps && alive; ++it) {
             ++i;
-            alive = rt::ray_step<T, METHOD>(a.F, a.K, r, i);
+            alive = rt::ray_step<T, METHOD, ISO>(a.F, a.K, r, i);
             if (RECORD) {
                 if (--until == 0) {
                     until = a.stride;
@@ -447,7 +451,7 @@ template <typename T> __global__ void k_pack_final(BatchDev<T> a, double* out) {
     if (k >= a.R) return;
     rt::Ray<T> r;
     r.x = a.x[k]; r.y = a.y[k]; r.th = a.th[k]; r.n = a.n[k]; r.gx = a.gx[k]; r.gy = a.gy[k]; r.tt = a.tt[k];
-    rt::derive<T>(a.K, r);
+    rt::derive<T, false>(a.K, r);
     const double v[9] = {(double)r.x, (double)r.y, (double)r.th, (double)r.n, (double)r.gx, (double)r.gy,
                          (double)r.mx, (double)r.my, (double)r.tt};
 #pragma unroll
@@ -485,7 +489,7 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     a.F = field_dev<T>(b->field);
     const rtmi_params& p = b->p;
     a.K.step = (T)p.step;
-    a.K.step2 = (T)std::pow(p.step, 2.0);  // numpy scalar step**2 is libm pow (:330)
+    a.K.step2h = (T)(std::pow(p.step, 2.0) / 2.0);  // numpy scalar step**2 is libm pow (:330); /2 is exact
     a.K.gamma = (T)p.gamma; a.K.g2m1 = (T)(p.gamma * p.gamma - 1.0);
     a.K.gamma_s = (T)p.gamma_step; a.K.g2m1_s = (T)(p.gamma_step * p.gamma_step - 1.0);
     for (int i = 0; i < 4; i++) a.K.box[i] = (T)p.box[i];
@@ -502,18 +506,19 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     return a;
 }
 
-template <typename T, bool RECORD> static const void* advance_fn(int m) {
+template <typename T> static const void* advance_fn(int m, bool iso) {
     switch (m) {
-#define CASE_(M) case M: return (const void*)k_advance<T, M, RECORD>;
-        CASE_(1) CASE_(2) CASE_(3) CASE_(4) CASE_(5) CASE_(6) CASE_(7) CASE_(8) CASE_(9) CASE_(10) CASE_(11)
+#define CASE_(M) case M: return iso ? (const void*)k_advance<T, M, true> : (const void*)k_advance<T, M, false>;
+        CASE_(1) CASE_(2) CASE_(3) CASE_(4) CASE_(5) CASE_(6) CASE_(7) CASE_(8) CASE_(9)
 #undef CASE_
+        case 10: return (const void*)k_advance<T, 10, false>;
+        case 11: return (const void*)k_advance<T, 11, false>;
     }
     return nullptr;
 }
 static const void* pick_advance(const rtmi_batch* b) {
-    const bool rec = b->p.record_stride > 0;
-    if (b->p.dtype == RTMI_F64) return rec ? advance_fn<double, true>(b->p.method) : advance_fn<double, false>(b->p.method);
-    return rec ? advance_fn<float, true>(b->p.method) : advance_fn<float, false>(b->p.method);
+    const bool iso = b->p.gamma == 1.0 && b->p.method < 10;
+    return b->p.dtype == RTMI_F64 ? advance_fn<double>(b->p.method, iso) : advance_fn<float>(b->p.method, iso);
 }
 
 // clear_traj: zero the trajectory arrays (np.zeros, :802-803).  A reset with unchanged launch conditions rewrites
