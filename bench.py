@@ -91,7 +91,12 @@ def main():
     ap.add_argument("--scenario", default="vert_heterogeneous", choices=sorted(SCEN))
     ap.add_argument("--method", type=int, default=None)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--record", default="stride:16", help="none | full | stride:N (trajectory rows kept in HBM)")
+    ap.add_argument("--record", default="full", help="full (the reference's s_ray layout, default) | none | stride:N")
+    ap.add_argument("--mode", default="lane", choices=["lane", "refill"],
+                    help="lane: one lane per ray; refill: persistent waves with ballot/prefix lane refill")
+    ap.add_argument("--order", default="fan", choices=["fan", "shuffled"],
+                    help="ray order inside the batch: the sorted fan, or a seeded random permutation of it")
+    ap.add_argument("--refill-min", type=int, default=0)
     ap.add_argument("--rec-rows", type=int, default=0, help="rows to allocate (0 = from max_size; full: 3072 for vert)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
@@ -129,9 +134,12 @@ def main():
         rec_rows = (3072 + stride - 1) // stride     # the fan's longest ray takes 2 938 steps
     R_total = args.rays * world
     th = fan(args.scenario, R_total, rank, world)
+    if args.order == "shuffled":
+        th = np.random.default_rng(1234 + rank).permutation(th)
     fld = rb.Field.build(args.scenario, lim, rb.DELTA, dtype)
     batch = rb.Batch(fld, args.method, step, max_size, lim, sc["gamma"], th, sc["start"][0], sc["start"][1],
-                     record_stride=stride, rec_rows=rec_rows, block_size=args.block)
+                     record_stride=stride, rec_rows=rec_rows, block_size=args.block,
+                     launch_mode=1 if args.mode == "refill" else 0, refill_min=args.refill_min)
 
     def barrier():
         torch.cuda.synchronize()
@@ -179,10 +187,11 @@ def main():
                                    f"interleaved across ranks), op{args.method}, DELTA_S={step:.12g}, "
                                    f"box={tuple(float(v) for v in lim)}, record={args.record}",
                        "rays_per_gpu": args.rays, "ray_steps_per_pass_rank0": int(steps_per_pass),
-                       "method": f"op{args.method}", "record": args.record, "parallelism": f"ray-shard x{world}"},
+                       "method": f"op{args.method}", "record": args.record, "launch_mode": args.mode,
+                       "ray_order": args.order, "parallelism": f"ray-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_advance", "kernel_ms": kern_ms, "alg_bytes_per_ray_step": balg,
+                         "kernel": "k_trace_refill" if args.mode == "refill" else "k_advance", "kernel_ms": kern_ms, "alg_bytes_per_ray_step": balg,
                          "ray_steps_per_launch": int(steps_per_pass), "vgprs": st["vgprs"]},
         }
         prof = os.path.join(ROOT, "profiles", "traffic.json")

@@ -85,6 +85,8 @@ typedef struct {
     double box[4];           /* limx_i, limx_s, limy_i, limy_s (:878) */
     int32_t launch_mode;     /* 0: one lane per ray to completion; 1: persistent waves with lane refill */
     int32_t block_size;      /* 0 -> default */
+    int32_t refill_min;      /* launch_mode 1: compact when this many lanes of a wave are idle (0 -> 32) */
+    int32_t reserved0;
     /* optional caller-owned DEVICE buffers (e.g. torch tensors); NULL -> the library allocates */
     void *ext_s_ray;         /* [rec_rows][6][R] of dtype: x, y, p_x, p_y, T, theta (:802, :871-875) */
     void *ext_n_ray;         /* [rec_rows][R]   of dtype: coef*n (:803, :873) */

@@ -362,7 +362,7 @@ template <typename T> struct BatchDev {
     int* istep;
     unsigned char* alive;
     T *s_ray, *n_ray;
-    unsigned long long* counters;  // [0] ray-steps, [1] live rays (recomputed per launch)
+    unsigned long long* counters;  // [0] ray-steps, [1] live rays (recomputed per launch), [2] refill queue head
     const double *x0, *y0, *th0;   // launch conditions (device, fp64)
 };
 
@@ -395,6 +395,24 @@ __device__ __forceinline__ unsigned wave_sum(unsigned v) {
     return v;
 }
 
+template <typename T, int METHOD, bool ISO>
+__device__ __forceinline__ void load_ray(const BatchDev<T>& a, long k, rt::Ray<T>& r, int& i) {
+    r.x = a.x[k]; r.y = a.y[k]; r.th = a.th[k]; r.n = a.n[k]; r.gx = a.gx[k]; r.gy = a.gy[k];
+    r.dsim = a.dsim[k]; r.dreal = a.dreal[k]; r.tt = a.tt[k];
+    if (METHOD == 7) { r.hx0 = a.hist[k]; r.hy0 = a.hist[a.R + k]; r.hx1 = a.hist[2 * a.R + k]; r.hy1 = a.hist[3 * a.R + k]; }
+    else { r.hx0 = r.hy0 = r.hx1 = r.hy1 = 0; }
+    rt::derive<T, ISO>(a.K, r);
+    i = a.istep[k];
+}
+template <typename T, int METHOD>
+__device__ __forceinline__ void store_ray(const BatchDev<T>& a, long k, const rt::Ray<T>& r, int i, bool alive) {
+    a.x[k] = r.x; a.y[k] = r.y; a.th[k] = r.th; a.n[k] = r.n; a.gx[k] = r.gx; a.gy[k] = r.gy;
+    a.dsim[k] = r.dsim; a.dreal[k] = r.dreal; a.tt[k] = r.tt;
+    if (METHOD == 7) { a.hist[k] = r.hx0; a.hist[a.R + k] = r.hy0; a.hist[2 * a.R + k] = r.hx1; a.hist[3 * a.R + k] = r.hy1; }
+    a.istep[k] = i;
+    a.alive[k] = alive;
+}
+
 // The loop at :866-879: one lane per ray, state in registers for up to nsteps DELTA_S steps.
 // ISO (gamma == 1) drops the anisotropic factor's dead arithmetic; results are bit-identical either way.
 template <typename T, int METHOD, bool ISO>
@@ -404,12 +422,8 @@ __global__ __launch_bounds__(256, 2) void k_advance(BatchDev<T> a, int nsteps) {
     unsigned done = 0, live = 0;
     if (k < a.R && a.alive[k]) {
         rt::Ray<T> r;
-        r.x = a.x[k]; r.y = a.y[k]; r.th = a.th[k]; r.n = a.n[k]; r.gx = a.gx[k]; r.gy = a.gy[k];
-        r.dsim = a.dsim[k]; r.dreal = a.dreal[k]; r.tt = a.tt[k];
-        if (METHOD == 7) { r.hx0 = a.hist[k]; r.hy0 = a.hist[a.R + k]; r.hx1 = a.hist[2 * a.R + k]; r.hy1 = a.hist[3 * a.R + k]; }
-        else { r.hx0 = r.hy0 = r.hx1 = r.hy1 = 0; }
-        rt::derive<T, ISO>(a.K, r);
-        int i = a.istep[k];
+        int i;
+        load_ray<T, METHOD, ISO>(a, k, r, i);
         int until = RECORD ? a.stride - (i % a.stride) : 0;  // steps until the next recorded row
         long row = RECORD ? i / a.stride : 0;
         bool alive = true;
@@ -426,11 +440,7 @@ __global__ __launch_bounds__(256, 2) void k_advance(BatchDev<T> a, int nsteps) {
             alive = alive && (i + 1 < a.max_size);
             ++done;
         }
-        a.x[k] = r.x; a.y[k] = r.y; a.th[k] = r.th; a.n[k] = r.n; a.gx[k] = r.gx; a.gy[k] = r.gy;
-        a.dsim[k] = r.dsim; a.dreal[k] = r.dreal; a.tt[k] = r.tt;
-        if (METHOD == 7) { a.hist[k] = r.hx0; a.hist[a.R + k] = r.hy0; a.hist[2 * a.R + k] = r.hx1; a.hist[3 * a.R + k] = r.hy1; }
-        a.istep[k] = i;
-        a.alive[k] = alive;
+        store_ray<T, METHOD>(a, k, r, i, alive);
         live = alive;
     }
     done = wave_sum(done);
@@ -439,6 +449,74 @@ __global__ __launch_bounds__(256, 2) void k_advance(BatchDev<T> a, int nsteps) {
         if (done) atomicAdd(&a.counters[0], (unsigned long long)done);
         if (live) atomicAdd(&a.counters[1], (unsigned long long)live);
     }
+}
+
+// Persistent waves with lane refill (launch_mode 1): every wave draws rays from a device-side queue
+// (counters[2] = next unclaimed ray).  Whenever at least `refill_min` of its lanes hold a terminated ray the
+// wave compacts: a 64-bit ballot marks the dead lanes, one lane claims that many rays with a single atomic,
+// and each dead lane takes ray base + (number of dead lanes below it) (mbcnt prefix).  A ray's arithmetic
+// never depends on its lane or wave mates, so results are bit-identical to k_advance.
+// Exit: the queue is exhausted and no lane is live -- reached by every wave because each ray takes at most
+// max_size steps and the queue only advances.
+template <typename T, int METHOD, bool ISO>
+__global__ __launch_bounds__(256, 2) void k_trace_refill(BatchDev<T> a, int refill_min, int chunk) {
+    const bool RECORD = a.stride != 0;
+    const unsigned lane = threadIdx.x & 63;
+    rt::Ray<T> r;
+    r.x = r.y = r.th = r.n = r.gx = r.gy = r.ux = r.uy = r.coef = r.nray = r.rn = 0;
+    r.dsim = r.dreal = r.tt = r.mx = r.my = r.hx0 = r.hy0 = r.hx1 = r.hy1 = 0;
+    long k = 0, row = 0;
+    int i = 0, until = 0;
+    bool alive = false;
+    bool exhausted = false;  // wave-uniform
+    unsigned done = 0;
+    for (;;) {
+        unsigned long long live_mask = __ballot(alive);
+        const int n_dead = 64 - __popcll(live_mask);
+        if (!exhausted && (n_dead >= refill_min || live_mask == 0)) {
+            unsigned long long base = 0;
+            if (lane == 0) base = atomicAdd(&a.counters[2], (unsigned long long)n_dead);
+            base = __shfl(base, 0, 64);
+            const unsigned long long dead_mask = ~live_mask;
+            const unsigned slot = __builtin_amdgcn_mbcnt_hi((unsigned)(dead_mask >> 32),
+                                                            __builtin_amdgcn_mbcnt_lo((unsigned)dead_mask, 0u));
+            if (!alive) {
+                const long kk = (long)(base + slot);
+                if (kk < a.R && a.alive[kk]) {
+                    k = kk;
+                    load_ray<T, METHOD, ISO>(a, k, r, i);
+                    until = RECORD ? a.stride - (i % a.stride) : 0;
+                    row = RECORD ? i / a.stride : 0;
+                    alive = true;
+                }
+            }
+            exhausted = base + (unsigned long long)n_dead >= (unsigned long long)a.R;
+            live_mask = __ballot(alive);
+        }
+        if (live_mask == 0) {
+            if (exhausted) break;
+            continue;  // the claimed rays were all finished already; claim again (the queue advanced)
+        }
+        for (int it = 0; it < chunk; ++it) {
+            if (alive) {
+                ++i;
+                alive = rt::ray_step<T, METHOD, ISO>(a.F, a.K, r, i);
+                if (RECORD) {
+                    if (--until == 0) {
+                        until = a.stride;
+                        ++row;
+                        if (row < a.rec_rows) write_row(a, row, k, r);
+                    }
+                }
+                alive = alive && (i + 1 < a.max_size);
+                ++done;
+                if (!alive) store_ray<T, METHOD>(a, k, r, i, false);
+            }
+            if (__ballot(alive) == 0) break;
+        }
+    }
+    done = wave_sum(done);
+    if (lane == 0 && done) atomicAdd(&a.counters[0], (unsigned long long)done);
 }
 
 template <typename T> __global__ void k_pack_d_ray(BatchDev<T> a, double* out) {
@@ -481,6 +559,8 @@ struct rtmi_batch {
     double kernel_ms = 0;
     uint32_t launches = 0;
     const void* kfn = nullptr;
+    const void* kfn_refill = nullptr;
+    int persistent_blocks = 0;   // resident 256-thread blocks of the refill kernel on this device
     bool dirty = false;          // rtmi_batch_set_state ran since the trajectories were last cleared
 };
 
@@ -520,13 +600,27 @@ static const void* pick_advance(const rtmi_batch* b) {
     const bool iso = b->p.gamma == 1.0 && b->p.method < 10;
     return b->p.dtype == RTMI_F64 ? advance_fn<double>(b->p.method, iso) : advance_fn<float>(b->p.method, iso);
 }
+template <typename T> static const void* refill_fn(int m, bool iso) {
+    switch (m) {
+#define CASE_(M) case M: return iso ? (const void*)k_trace_refill<T, M, true> : (const void*)k_trace_refill<T, M, false>;
+        CASE_(1) CASE_(2) CASE_(3) CASE_(4) CASE_(5) CASE_(6) CASE_(7) CASE_(8) CASE_(9)
+#undef CASE_
+        case 10: return (const void*)k_trace_refill<T, 10, false>;
+        case 11: return (const void*)k_trace_refill<T, 11, false>;
+    }
+    return nullptr;
+}
+static const void* pick_refill(const rtmi_batch* b) {
+    const bool iso = b->p.gamma == 1.0 && b->p.method < 10;
+    return b->p.dtype == RTMI_F64 ? refill_fn<double>(b->p.method, iso) : refill_fn<float>(b->p.method, iso);
+}
 
 // clear_traj: zero the trajectory arrays (np.zeros, :802-803).  A reset with unchanged launch conditions rewrites
 // exactly the rows it wrote before, so the zeros past each ray's last row survive and need no second pass.
 static int batch_init_state(rtmi_batch* b, bool clear_traj) {
     hipStream_t st = b->stream;
     const size_t R = (size_t)b->R;
-    HIP_TRY(hipMemsetAsync(b->counters, 0, 2 * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(b->counters, 0, 4 * sizeof(unsigned long long), st));
     if (clear_traj && b->s_ray) HIP_TRY(hipMemsetAsync(b->s_ray, 0, (size_t)b->p.rec_rows * 6 * R * b->esz, st));
     if (clear_traj && b->n_ray) HIP_TRY(hipMemsetAsync(b->n_ray, 0, (size_t)b->p.rec_rows * R * b->esz, st));
     b->dirty = false;
@@ -562,7 +656,8 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     ARG_TRY(p->method != 7 || p->max_size >= 4, "rtmi_batch_create: op7 needs max_size >= 4 (two bootstrap rows)");
     ARG_TRY(p->record_stride >= 0, "rtmi_batch_create: record_stride < 0");
     ARG_TRY(p->box[1] > p->box[0] && p->box[3] > p->box[2], "rtmi_batch_create: empty box");
-    ARG_TRY(p->launch_mode == 0, "rtmi_batch_create: unknown launch_mode");
+    ARG_TRY(p->launch_mode == 0 || p->launch_mode == 1, "rtmi_batch_create: launch_mode must be 0 or 1");
+    ARG_TRY(p->refill_min >= 0 && p->refill_min <= 64, "rtmi_batch_create: refill_min must be in [0, 64]");
     rtmi_batch* b = new (std::nothrow) rtmi_batch();
     if (!b) return fail(RTMI_ERR_ALLOC, "rtmi_batch_create: host allocation failed");
     b->field = f; b->p = *p; b->R = R; b->esz = p->dtype == RTMI_F64 ? 8 : 4; b->stream = (hipStream_t)stream;
@@ -577,7 +672,7 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
         HIP_TRY(hipMalloc(&b->istep, Rz * sizeof(int)));
         HIP_TRY(hipMalloc(&b->alive, Rz));
         HIP_TRY(hipMalloc(&b->launch, 3 * Rz * sizeof(double)));
-        HIP_TRY(hipMalloc(&b->counters, 2 * sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&b->counters, 4 * sizeof(unsigned long long)));
         HIP_TRY(hipHostMalloc(&b->h_counters, 2 * sizeof(unsigned long long)));
         if (b->p.record_stride > 0) {
             if (p->ext_s_ray) b->s_ray = p->ext_s_ray;
@@ -590,6 +685,12 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
         HIP_TRY(hipMemcpyAsync(b->launch + 2 * Rz, theta0, Rz * 8, hipMemcpyHostToDevice, b->stream));
         HIP_TRY(hipStreamSynchronize(b->stream));  // caller's host buffers may go away
         b->kfn = pick_advance(b);
+        b->kfn_refill = pick_refill(b);
+        int dev = 0, cus = 0, per_cu = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, b->kfn_refill, 256, 0));
+        b->persistent_blocks = cus * (per_cu > 0 ? per_cu : 1);
         return batch_init_state(b, true);
     };
     rc = body();
@@ -660,11 +761,7 @@ template <typename T> static void launch_advance(const rtmi_batch* b, int nsteps
     (void)hipLaunchKernel(b->kfn, g, blk, args, 0, b->stream);
 }
 
-RTMI_EXPORT int rtmi_step(rtmi_batch* b, int32_t nsteps) {
-    ARG_TRY(b, "rtmi_step: null");
-    ARG_TRY(nsteps > 0, "rtmi_step: nsteps must be > 0");
-    ARG_TRY(b->p.block_size == 0 || (b->p.block_size % 64 == 0 && b->p.block_size <= 256),
-            "rtmi_step: block_size must be a multiple of 64, at most 256");
+static int next_event_pair(rtmi_batch* b, std::pair<hipEvent_t, hipEvent_t>** out) {
     if (b->ev_used == b->events.size()) {
         if (b->events.size() >= 1024) {
             int rc = fold_events(b);
@@ -676,7 +773,19 @@ RTMI_EXPORT int rtmi_step(rtmi_batch* b, int32_t nsteps) {
             b->events.emplace_back(e0, e1);
         }
     }
-    auto& ev = b->events[b->ev_used++];
+    *out = &b->events[b->ev_used++];
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_step(rtmi_batch* b, int32_t nsteps) {
+    ARG_TRY(b, "rtmi_step: null");
+    ARG_TRY(nsteps > 0, "rtmi_step: nsteps must be > 0");
+    ARG_TRY(b->p.block_size == 0 || (b->p.block_size % 64 == 0 && b->p.block_size <= 256),
+            "rtmi_step: block_size must be a multiple of 64, at most 256");
+    std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
+    int rc0 = next_event_pair(b, &evp);
+    if (rc0) return rc0;
+    auto& ev = *evp;
     HIP_TRY(hipMemsetAsync(b->counters + 1, 0, sizeof(unsigned long long), b->stream));
     HIP_TRY(hipEventRecord(ev.first, b->stream));
     if (b->p.dtype == RTMI_F64) launch_advance<double>(b, nsteps);
@@ -688,15 +797,42 @@ RTMI_EXPORT int rtmi_step(rtmi_batch* b, int32_t nsteps) {
 }
 
 static int read_counters(rtmi_batch* b) {
-    HIP_TRY(hipMemcpyAsync(b->h_counters, b->counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+    HIP_TRY(hipMemcpyAsync(b->h_counters, b->counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));  // [0..1]
     HIP_TRY(hipStreamSynchronize(b->stream));
     return RTMI_OK;
 }
 
+static int next_event_pair(rtmi_batch* b, std::pair<hipEvent_t, hipEvent_t>** out);
+
+template <typename T> static void launch_refill(const rtmi_batch* b) {
+    BatchDev<T> a = batch_dev<T>(b);
+    int refill_min = b->p.refill_min > 0 ? b->p.refill_min : 32;
+    int chunk = 16;
+    void* args[] = {&a, &refill_min, &chunk};
+    long need = (b->R + 255) / 256;
+    const dim3 g((unsigned)(need < b->persistent_blocks ? need : b->persistent_blocks)), blk(256);
+    (void)hipLaunchKernel(b->kfn_refill, g, blk, args, 0, b->stream);
+}
+
 RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
     ARG_TRY(b, "rtmi_run: null");
+    int rc;
+    if (b->p.launch_mode == 1) {
+        // persistent waves with lane refill: one launch drains the ray queue
+        std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+        rc = next_event_pair(b, &ev);
+        if (rc) return rc;
+        HIP_TRY(hipMemsetAsync(b->counters + 1, 0, 2 * sizeof(unsigned long long), b->stream));
+        HIP_TRY(hipEventRecord(ev->first, b->stream));
+        if (b->p.dtype == RTMI_F64) launch_refill<double>(b);
+        else launch_refill<float>(b);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev->second, b->stream));
+        b->launches++;
+        return read_counters(b);
+    }
     // one lane per ray to completion: a single launch covers every remaining row
-    int rc = rtmi_step(b, b->p.max_size);
+    rc = rtmi_step(b, b->p.max_size);
     if (rc) return rc;
     rc = read_counters(b);
     if (rc) return rc;
@@ -793,6 +929,6 @@ RTMI_EXPORT int rtmi_batch_stats(rtmi_batch* b, rtmi_stats* s) {
     s->launches = b->launches;
     hipFuncAttributes fa;
     s->vgprs = s->sgprs = s->lds_bytes = 0;
-    if (hipFuncGetAttributes(&fa, b->kfn) == hipSuccess) { s->vgprs = fa.numRegs; s->lds_bytes = (uint32_t)fa.sharedSizeBytes; }
+    if (hipFuncGetAttributes(&fa, b->p.launch_mode == 1 ? b->kfn_refill : b->kfn) == hipSuccess) { s->vgprs = fa.numRegs; s->lds_bytes = (uint32_t)fa.sharedSizeBytes; }
     return RTMI_OK;
 }

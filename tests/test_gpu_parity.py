@@ -257,6 +257,31 @@ def test_sharding_is_bit_identical(m, rb, gpu_fields):
         p.close()
 
 
+@pytest.mark.parametrize("scen,m,refill_min", [("vert_heterogeneous", 6, 0), ("vert_heterogeneous", 7, 1),
+                                               ("interface", 6, 48), ("vert_heterogeneous", 9, 16)])
+def test_lane_refill_is_bit_identical(scen, m, refill_min, rb, gpu_fields):
+    """launch_mode 1 (persistent waves, ballot/mbcnt compaction of terminated lanes) vs one lane per ray, on a
+    batch whose rays are in random order (neighbouring lanes terminate hundreds of steps apart)."""
+    rng = np.random.default_rng(5)
+    R = 3000 if m != 9 else 300
+    lim = LIMITS[scen]
+    th = rng.permutation(np.linspace(0.06, np.pi / 2, R))
+    ms = int(np.ceil(80 / rb.DELTA_S) + 1)
+    a = rb.Batch(gpu_fields(scen), m, rb.DELTA_S, ms, lim, 1, th, -2.0, -2.0, record_stride=16)
+    a.run()
+    b = rb.Batch(gpu_fields(scen), m, rb.DELTA_S, ms, lim, 1, th, -2.0, -2.0, record_stride=16, launch_mode=1,
+                 refill_min=refill_min)
+    b.step(100)                                # part of the way with the plain kernel, then drain the queue
+    b.run()
+    sa, sb = a.stats(), b.stats()
+    assert sa["ray_steps"] == sb["ray_steps"] == int(a.d_ray()[2].sum()) and sb["live_rays"] == 0
+    assert np.array_equal(a.d_ray(), b.d_ray()) and np.array_equal(a.final(), b.final())
+    assert np.array_equal(a.rows(), b.rows())
+    b.reset(); b.run()                         # and from row 0
+    assert np.array_equal(a.final(), b.final()) and np.array_equal(a.rows(), b.rows())
+    a.close(); b.close()
+
+
 def test_record_strides_and_edges(rb, gpu_fields):
     F = gpu_fields("vert_heterogeneous")
     lim = LIMITS["vert_heterogeneous"]
