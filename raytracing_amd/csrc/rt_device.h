@@ -50,6 +50,8 @@ template <> struct M<double> {
     static __device__ __forceinline__ void sincos_(double x, double* s, double* c) { sincos_k(x, s, c); }
     static __device__ __forceinline__ double atan2_(double y, double x) { return ::atan2(y, x); }
     static __device__ __forceinline__ double abs_(double x) { return __builtin_fabs(x); }
+    static __device__ __forceinline__ double max_(double x, double y) { return __builtin_fmax(x, y); }
+    static __device__ __forceinline__ double min_(double x, double y) { return __builtin_fmin(x, y); }
     // x[i] of numpy.linspace: i*step + a with separate roundings (contraction is off), so knots equal the host's bit for bit
     static __device__ __forceinline__ double lin(int i, double h, double a) { return (double)i * h + a; }
     static constexpr double gold_tol = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON), RT_bench.py:66
@@ -60,6 +62,8 @@ template <> struct M<float> {
     static __device__ __forceinline__ void sincos_(float x, float* s, float* c) { ::sincosf(x, s, c); }
     static __device__ __forceinline__ float atan2_(float y, float x) { return ::atan2f(y, x); }
     static __device__ __forceinline__ float abs_(float x) { return __builtin_fabsf(x); }
+    static __device__ __forceinline__ float max_(float x, float y) { return __builtin_fmaxf(x, y); }
+    static __device__ __forceinline__ float min_(float x, float y) { return __builtin_fminf(x, y); }
     static __device__ __forceinline__ float lin(int i, float h, float a) { return (float)i * h + a; }
     static constexpr float gold_tol = 3.4526698300124393e-04f;  // sqrt(FLT_EPSILON): the fp32 analogue
     static constexpr float small_angle = 0.015625f;
@@ -97,8 +101,9 @@ template <typename T> struct FieldDev {
     const T* zn;
     const T* g;
     int qx, qy;
-    T ax, hx, bx, inv_hx, inv_3hx;
-    T ay, hy, by, inv_hy, inv_3hy;
+    T ax, hx, bx, inv_hx;
+    T ay, hy, by, inv_hy;
+    int exact;   // 1: FITPACK's arithmetic with true knots in every cell (see axis_eval)
 };
 
 template <typename T> __device__ __forceinline__ T axis_at(int i, int q, T a, T h, T b) {
@@ -141,35 +146,23 @@ __device__ __forceinline__ double rcp_full(double d) {
 }
 __device__ __forceinline__ float rcp_full(float d) { return 1.0f / d; }
 
-// One axis of n_gradient's basis: cell j (from locate, with t0 = x[j], t1 = x[j+1]) -> the two linear weights
-// (fpbspl k=1 on [t0, t1]) and the four cubic weights (fpbspl k=3 on FITPACK's interval l = clamp(j+2, 3, q-1)).
-// Interior cells (4 <= j <= q-6: the six cubic knots are the consecutive grid points x[j-2..j+3]) reuse t0/t1
-// and take the six knot-difference reciprocals by rcp_near; the not-a-knot end intervals use the general
-// knot rule and rcp_full.  Returns l.
+// General form of one axis of n_gradient's basis (any cell, FITPACK's arithmetic with true knots): cell j (from
+// locate, with t0 = x[j], t1 = x[j+1]) -> the two linear weights (fpbspl k=1 on [t0, t1]) and the four cubic
+// weights (fpbspl k=3 on the interval l = clamp(j+2, 3, q-1)); reciprocals of knot differences by rcp_full.
 template <typename T>
-__device__ __forceinline__ int axis_basis(T v, int j, T t0, T t1, int q, T a, T h, T b, T ih, T i3h, T wl[2], T w[4]) {
-    const T i2h = ih * T(0.5);
+__device__ __forceinline__ int axis_basis(T v, int j, T t0, T t1, int q, T a, T h, T b, T wl[2], T w[4]) {
     {   // linear: f = 1/(t1 - t0); h0 = f*(t1 - v), h1 = f*(v - t0)
-        const T f = rcp_near(t1 - t0, ih);
+        const T f = rcp_full(t1 - t0);
         wl[0] = f * (t1 - v);
         wl[1] = f * (v - t0);
     }
     int l = j + 2;
-    T tm2, tm1, k0, k1, t2, t3, r10, r1m1, r20, r1m2, r2m1, r30;
-    if (j >= 4 && j <= q - 6) {
-        tm2 = M<T>::lin(j - 2, h, a); tm1 = M<T>::lin(j - 1, h, a); k0 = t0; k1 = t1;
-        t2 = M<T>::lin(j + 2, h, a); t3 = M<T>::lin(j + 3, h, a);
-        r10 = rcp_near(k1 - k0, ih);
-        r1m1 = rcp_near(k1 - tm1, i2h); r20 = rcp_near(t2 - k0, i2h);
-        r1m2 = rcp_near(k1 - tm2, i3h); r2m1 = rcp_near(t2 - tm1, i3h); r30 = rcp_near(t3 - k0, i3h);
-    } else {
-        l = l < 3 ? 3 : (l > q - 1 ? q - 1 : l);
-        tm2 = knot3(l - 2, q, a, h, b); tm1 = knot3(l - 1, q, a, h, b); k0 = knot3(l, q, a, h, b);
-        k1 = knot3(l + 1, q, a, h, b); t2 = knot3(l + 2, q, a, h, b); t3 = knot3(l + 3, q, a, h, b);
-        r10 = rcp_full(k1 - k0);
-        r1m1 = rcp_full(k1 - tm1); r20 = rcp_full(t2 - k0);
-        r1m2 = rcp_full(k1 - tm2); r2m1 = rcp_full(t2 - tm1); r30 = rcp_full(t3 - k0);
-    }
+    l = l < 3 ? 3 : (l > q - 1 ? q - 1 : l);
+    const T tm2 = knot3(l - 2, q, a, h, b), tm1 = knot3(l - 1, q, a, h, b), k0 = knot3(l, q, a, h, b);
+    const T k1 = knot3(l + 1, q, a, h, b), t2 = knot3(l + 2, q, a, h, b), t3 = knot3(l + 3, q, a, h, b);
+    const T r10 = rcp_full(k1 - k0);
+    const T r1m1 = rcp_full(k1 - tm1), r20 = rcp_full(t2 - k0);
+    const T r1m2 = rcp_full(k1 - tm2), r2m1 = rcp_full(t2 - tm1), r30 = rcp_full(t3 - k0);
     const T a1 = k1 - v, a2 = t2 - v, a3 = t3 - v;      // t[li] - x
     const T b0 = v - k0, bm1 = v - tm1, bm2 = v - tm2;  // x - t[lj]
     // fpbspl recurrence, j = 1, 2, 3, with f = hh[i] / (t[li] - t[lj]) taken as hh[i] * reciprocal
@@ -192,16 +185,48 @@ __device__ __forceinline__ int axis_basis(T v, int j, T t0, T t1, int q, T a, T 
     return l;
 }
 
+// One axis of n_gradient: clamp (Q4), locate the cell, evaluate both bases.  Returns j (cell) and l (cubic
+// interval; the 4x4 window starts at column l-3).
+//
+// Fast path (per lane; unless F.exact): a cell at least five cells inside the grid has the six cubic knots
+// x[j-2..j+3] = consecutive linspace points, i.e. equally spaced up to the rounding of i*h + a (measured:
+// <= 3e-13 relative to h on the reference's grids).  There the cubic weights are the uniform B-spline
+// polynomials of u = (v - x[j])/(x[j+1] - x[j]) -- 10 flops instead of 61 -- and differ from fpbspl on the true
+// knots by <= 4e-14 absolute (tools/basis_error.py).  The linear weights keep fpbspl's form.  F.exact forces
+// the general form everywhere; rtmi_field_eval (the n_gradient call surface) always uses it.
+template <typename T>
+__device__ __forceinline__ void axis_eval(T v, int q, T a, T h, T b, T ih, int exact, int& j, int& l, T wl[2], T w[4]) {
+    v = M<T>::min_(M<T>::max_(v, a), b);
+    const int jg = (int)((v - a) * ih);
+    if (!exact && jg >= 5 && jg <= q - 8) {
+        T t0 = M<T>::lin(jg, h, a), t1 = M<T>::lin(jg + 1, h, a);
+        j = jg;
+        if (t0 > v) { j = jg - 1; t1 = t0; t0 = M<T>::lin(j, h, a); }                 // rare: v within rounding of a grid line
+        else if (t1 <= v) { j = jg + 1; t0 = t1; t1 = M<T>::lin(j + 1, h, a); }
+        const T f = rcp_near(t1 - t0, ih);
+        const T om = f * (t1 - v), u = f * (v - t0);
+        wl[0] = om; wl[1] = u;
+        const T u2 = u * u, om2 = om * om;
+        w[0] = om2 * om * T(1.0 / 6.0);
+        w[1] = fma_(u2, fma_(u, T(0.5), T(-1)), T(2.0 / 3.0));
+        w[2] = fma_(om2, fma_(om, T(0.5), T(-1)), T(2.0 / 3.0));
+        w[3] = u2 * u * T(1.0 / 6.0);
+        l = j + 2;
+    } else {
+        T t0, t1;
+        j = locate(v, q, a, h, b, ih, t0, t1);
+        l = axis_basis(v, j, t0, t1, q, a, h, b, wl, w);
+    }
+}
+
 // n_gradient(vector, grd, z) (:141-156): bilinear n, bicubic dn/dx and dn/dy at (x, y).
 // 36 coefficients are gathered per call: 2x2 of zn and a 4x4 window of interleaved pairs.
 template <typename T>
 __device__ __forceinline__ void n_gradient(const FieldDev<T>& F, T x, T y, T& n, T& gx, T& gy) {
-    T xa, xb, ya, yb;
-    const int jx = locate(x, F.qx, F.ax, F.hx, F.bx, F.inv_hx, xa, xb);
-    const int jy = locate(y, F.qy, F.ay, F.hy, F.by, F.inv_hy, ya, yb);
-    // ---- gather (issued first; the basis evaluation below needs no memory)
-    int lx = jx + 2; lx = lx < 3 ? 3 : (lx > F.qx - 1 ? F.qx - 1 : lx);
-    int ly = jy + 2; ly = ly < 3 ? 3 : (ly > F.qy - 1 ? F.qy - 1 : ly);
+    int jx, jy, lx, ly;
+    T lwx[2], lwy[2], wx[4], wy[4];
+    axis_eval(x, F.qx, F.ax, F.hx, F.bx, F.inv_hx, F.exact, jx, lx, lwx, wx);
+    axis_eval(y, F.qy, F.ay, F.hy, F.by, F.inv_hy, F.exact, jy, ly, lwy, wy);
     const T* zp = F.zn + (size_t)jy * F.qx + jx;
     const T z00 = zp[0], z01 = zp[1], z10 = zp[F.qx], z11 = zp[F.qx + 1];
     const T* gp = F.g + ((size_t)(ly - 3) * F.qx + (lx - 3)) * 2;
@@ -211,9 +236,6 @@ __device__ __forceinline__ void n_gradient(const FieldDev<T>& F, T x, T y, T& n,
 #pragma unroll
         for (int q = 0; q < 8; q++) c[r][q] = gp[(size_t)r * F.qx * 2 + q];
     }
-    T lwx[2], lwy[2], wx[4], wy[4];
-    axis_basis(x, jx, xa, xb, F.qx, F.ax, F.hx, F.bx, F.inv_hx, F.inv_3hx, lwx, wx);
-    axis_basis(y, jy, ya, yb, F.qy, F.ay, F.hy, F.by, F.inv_hy, F.inv_3hy, lwy, wy);
     // ---- bilinear n (fpbisp order: c * w_y * w_x)
     n = fma_(z11 * lwy[1], lwx[1], fma_(z10 * lwy[1], lwx[0], fma_(z01 * lwy[0], lwx[1], (z00 * lwy[0]) * lwx[0])));
     // ---- bicubic gradient: shared basis for both components (same knots); row sums, then the column sum
@@ -237,7 +259,7 @@ __device__ __forceinline__ void n_gradient(const FieldDev<T>& F, T x, T y, T& n,
 template <typename T> struct Ray {
     T x, y, th, n, gx, gy;   // position, angle, index, gradient at the current point
     T ux, uy, coef, nray;    // derived: unit tangent, anisotropy(theta,gamma), coef*n
-    T rn;                    // derived: 1/n (IEEE), shared by the three divisions by n of a step
+    T rn;                    // derived: 1/n (rcp_full, < 1 ulp), shared by the three divisions by n of a step
     T dsim, dreal, tt;       // simulated / expected arclength, traveltime
     T mx, my;                // momenta of the current row (output only)
     T hx0, hy0, hx1, hy1;    // op7: the two positions before (x,y), oldest first (VECTOR_LIST, Q11)
@@ -362,7 +384,7 @@ __device__ __forceinline__ void op_step(const FieldDev<T>& F, const Consts<T>& k
     else if constexpr (METHOD == 3 || METHOD == 4 || METHOD == 5 || METHOD == 10) flag = adv_curv(r, k, fx, fy);
     else adv_second(r, k, fx, fy);
     n_gradient(F, fx, fy, fn, fgx, fgy);
-    frn = T(1) / fn;
+    frn = rcp_full(fn);
     if constexpr (METHOD == 1 || METHOD == 8) fth = ang_cost(r, k.step, fgx, fgy);
     else if constexpr (METHOD == 2 || METHOD == 6) fth = ang_rk2(r, k.step, frn, fgx, fgy);
     else if constexpr (METHOD == 3) fth = flag ? ang_rk2(r, k.step, frn, fgx, fgy) : r.th;
@@ -404,7 +426,7 @@ template <typename T, bool ISO> __device__ __forceinline__ void derive(const Con
     M<T>::sincos_(r.th, &r.uy, &r.ux);
     r.coef = aniso<T, ISO>(r.uy, r.ux, k.gamma);
     r.nray = r.coef * r.n;
-    r.rn = T(1) / r.n;
+    r.rn = rcp_full(r.n);
     r.mx = moment<T, ISO>(r.n, r.coef, k.g2m1, r.ux, -(r.uy * r.uy));
     r.my = moment<T, ISO>(r.n, r.coef, k.g2m1, r.uy, r.ux * r.ux);
 }
@@ -421,7 +443,7 @@ __device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& 
     if (METHOD == 7 && i <= 2) {
         adv_second(r, k, fx, fy);
         n_gradient(F, fx, fy, fn, fgx, fgy);
-        frn = T(1) / fn;
+        frn = rcp_full(fn);
         T vx, vy;
         if (i == 1) { vx = fx - r.x; vy = fy - r.y; }                                          // (:843)
         else { vx = T(3) * fx - T(4) * r.x + r.hx1; vy = T(3) * fy - T(4) * r.y + r.hy1; }     // (:856)

@@ -46,15 +46,16 @@ struct rtmi_field {
     hipStream_t stream = nullptr;
 };
 
-template <typename T> static rt::FieldDev<T> field_dev(const rtmi_field* f) {
+template <typename T> static rt::FieldDev<T> field_dev(const rtmi_field* f, int exact) {
     rt::FieldDev<T> F;
+    F.exact = exact;
     F.zn = (const T*)f->zn;
     F.g = (const T*)f->g;
     F.qx = f->qx; F.qy = f->qy;
     F.ax = (T)f->ax; F.hx = (T)f->hx; F.bx = (T)f->bx;
-    F.inv_hx = (T)(1.0 / f->hx); F.inv_3hx = (T)(1.0 / (3.0 * f->hx));
+    F.inv_hx = (T)(1.0 / f->hx);
     F.ay = (T)f->ay; F.hy = (T)f->hy; F.by = (T)f->by;
-    F.inv_hy = (T)(1.0 / f->hy); F.inv_3hy = (T)(1.0 / (3.0 * f->hy));
+    F.inv_hy = (T)(1.0 / f->hy);
     return F;
 }
 
@@ -333,10 +334,10 @@ RTMI_EXPORT int rtmi_field_eval(const rtmi_field* f, int64_t npts, const double*
             hipMemcpyAsync(d + npts, y, nb, hipMemcpyHostToDevice, st) != hipSuccess) { rc = RTMI_ERR_HIP; break; }
         const dim3 g((unsigned)((npts + 255) / 256)), b(256);
         if (f->dtype == RTMI_F64)
-            hipLaunchKernelGGL(k_field_eval<double>, g, b, 0, st, field_dev<double>(f), (long)npts, d, d + npts,
+            hipLaunchKernelGGL(k_field_eval<double>, g, b, 0, st, field_dev<double>(f, 1), (long)npts, d, d + npts,
                                d + 2 * npts, d + 3 * npts, d + 4 * npts);
         else
-            hipLaunchKernelGGL(k_field_eval<float>, g, b, 0, st, field_dev<float>(f), (long)npts, d, d + npts,
+            hipLaunchKernelGGL(k_field_eval<float>, g, b, 0, st, field_dev<float>(f, 1), (long)npts, d, d + npts,
                                d + 2 * npts, d + 3 * npts, d + 4 * npts);
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = RTMI_ERR_HIP; break; }
         if (hipMemcpy(n, d + 2 * npts, nb, hipMemcpyDeviceToHost) != hipSuccess ||
@@ -566,7 +567,7 @@ struct rtmi_batch {
 
 template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     BatchDev<T> a;
-    a.F = field_dev<T>(b->field);
+    a.F = field_dev<T>(b->field, b->p.exact_basis);
     const rtmi_params& p = b->p;
     a.K.step = (T)p.step;
     a.K.step2h = (T)(std::pow(p.step, 2.0) / 2.0);  // numpy scalar step**2 is libm pow (:330); /2 is exact
@@ -658,6 +659,7 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     ARG_TRY(p->box[1] > p->box[0] && p->box[3] > p->box[2], "rtmi_batch_create: empty box");
     ARG_TRY(p->launch_mode == 0 || p->launch_mode == 1, "rtmi_batch_create: launch_mode must be 0 or 1");
     ARG_TRY(p->refill_min >= 0 && p->refill_min <= 64, "rtmi_batch_create: refill_min must be in [0, 64]");
+    ARG_TRY(p->exact_basis == 0 || p->exact_basis == 1, "rtmi_batch_create: exact_basis must be 0 or 1");
     rtmi_batch* b = new (std::nothrow) rtmi_batch();
     if (!b) return fail(RTMI_ERR_ALLOC, "rtmi_batch_create: host allocation failed");
     b->field = f; b->p = *p; b->R = R; b->esz = p->dtype == RTMI_F64 ? 8 : 4; b->stream = (hipStream_t)stream;

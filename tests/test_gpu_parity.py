@@ -282,6 +282,32 @@ def test_lane_refill_is_bit_identical(scen, m, refill_min, rb, gpu_fields):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("scen,m", [("vert_heterogeneous", 6), ("interface", 6), ("fisheye", 6), ("vert_heterogeneous", 7)])
+def test_uniform_basis_vs_exact_basis(scen, m, rb, gpu_fields, oracle_fields):
+    """The trace kernels' interior fast path (uniform cubic B-spline polynomials) against exact_basis=1
+    (FITPACK's fpbspl on the true knots in every cell): the weights differ by <= 4e-14, trajectories by far
+    less than the 1e-9 tolerance, and the exact build matches the oracle at least as closely."""
+    from oracle import rt_oracle as O
+    R = 512
+    lim = LIMITS[scen]
+    if scen == "fisheye":
+        th, x0, y0, step, ms = np.linspace(np.pi / 4, 3 * np.pi / 4, R), 1.0, 0.0, 2 * np.pi / 303, 3040
+    else:
+        th, x0, y0, step, ms = np.linspace(0.06, np.pi / 2, R), -2.0, -2.0, rb.DELTA_S, 30228
+    res = []
+    for exact in (0, 1):
+        b = rb.Batch(gpu_fields(scen), m, step, ms, lim, 1, th, x0, y0, record_stride=0, exact_basis=exact)
+        b.run()
+        res.append((b.d_ray(), b.final()))
+        b.close()
+    assert np.array_equal(res[0][0][2], res[1][0][2])
+    gap = relerr(res[0][1], res[1][1])
+    o = O.trazar(oracle_fields(scen), m, 1, step, ms, lim, x0, y0, th, record_stride=0, nthreads=8)
+    e_fast, e_exact = relerr(res[0][1], o["final"]), relerr(res[1][1], o["final"])
+    print(f"{scen} op{m}: fast vs exact {gap:.2e}; vs oracle: fast {e_fast:.2e}, exact {e_exact:.2e}")
+    assert gap < 1e-11 and e_fast < REL and e_exact < REL
+
+
 def test_record_strides_and_edges(rb, gpu_fields):
     F = gpu_fields("vert_heterogeneous")
     lim = LIMITS["vert_heterogeneous"]
