@@ -88,6 +88,8 @@ typedef struct {
     int32_t refill_min;      /* launch_mode 1: compact when this many lanes of a wave are idle (0 -> 32) */
     int32_t exact_basis;     /* 0: uniform-knot cubic basis in interior cells (<= 4e-14 from FITPACK's weights);
                                 1: FITPACK's fpbspl arithmetic on the true knots in every cell (slower) */
+    int32_t field_path;      /* 0: wave-private LDS tile of the field (default); 1: every lookup gathers from global memory */
+    int32_t reserved0;
     /* optional caller-owned DEVICE buffers (e.g. torch tensors); NULL -> the library allocates */
     void *ext_s_ray;         /* [rec_rows][6][R] of dtype: x, y, p_x, p_y, T, theta (:802, :871-875) */
     void *ext_n_ray;         /* [rec_rows][R]   of dtype: coef*n (:803, :873) */

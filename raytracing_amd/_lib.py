@@ -21,6 +21,7 @@ class Params(C.Structure):
                 ("step", C.c_double), ("max_size", C.c_int32), ("record_stride", C.c_int32), ("rec_rows", C.c_int64),
                 ("box", C.c_double * 4), ("launch_mode", C.c_int32), ("block_size", C.c_int32),
                 ("refill_min", C.c_int32), ("exact_basis", C.c_int32),
+                ("field_path", C.c_int32), ("reserved0", C.c_int32),
                 ("ext_s_ray", C.c_void_p), ("ext_n_ray", C.c_void_p)]
 
 

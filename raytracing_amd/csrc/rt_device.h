@@ -219,40 +219,186 @@ __device__ __forceinline__ void axis_eval(T v, int q, T a, T h, T b, T ih, int e
     }
 }
 
-// n_gradient(vector, grd, z) (:141-156): bilinear n, bicubic dn/dx and dn/dy at (x, y).
-// 36 coefficients are gathered per call: 2x2 of zn and a 4x4 window of interleaved pairs.
-template <typename T>
-__device__ __forceinline__ void n_gradient(const FieldDev<T>& F, T x, T y, T& n, T& gx, T& gy) {
-    int jx, jy, lx, ly;
+// ---------------------------------------------------------------- n_gradient = locate + gather + combine
+// The cell of one lookup: indices and the six basis weights per axis.
+template <typename T> struct Cell {
+    int jx, jy, lx, ly;          // bilinear cell (jx, jy); the cubic 4x4 window starts at (lx-3, ly-3)
     T lwx[2], lwy[2], wx[4], wy[4];
-    axis_eval(x, F.qx, F.ax, F.hx, F.bx, F.inv_hx, F.exact, jx, lx, lwx, wx);
-    axis_eval(y, F.qy, F.ay, F.hy, F.by, F.inv_hy, F.exact, jy, ly, lwy, wy);
-    const T* zp = F.zn + (size_t)jy * F.qx + jx;
-    const T z00 = zp[0], z01 = zp[1], z10 = zp[F.qx], z11 = zp[F.qx + 1];
-    const T* gp = F.g + ((size_t)(ly - 3) * F.qx + (lx - 3)) * 2;
-    T c[4][8];
+};
+
+template <typename T> __device__ __forceinline__ void field_locate(const FieldDev<T>& F, T x, T y, Cell<T>& c) {
+    axis_eval(x, F.qx, F.ax, F.hx, F.bx, F.inv_hx, F.exact, c.jx, c.lx, c.lwx, c.wx);
+    axis_eval(y, F.qy, F.ay, F.hy, F.by, F.inv_hy, F.exact, c.jy, c.ly, c.lwy, c.wy);
+}
+
+// one (d/dx-spline, d/dy-spline) coefficient pair: a single 16-byte (fp64) access in HBM and in LDS
+template <typename T> using Pair = T __attribute__((ext_vector_type(2)));
+#define RT_LDS __attribute__((address_space(3)))
+
+// 36 coefficients straight from HBM/L2: 2x2 of zn and the 4x4 window of interleaved pairs.
+template <typename T>
+__device__ __forceinline__ void gather_global(const FieldDev<T>& F, const Cell<T>& c, T z[4], Pair<T> g[4][4]) {
+    const T* zp = F.zn + (size_t)c.jy * F.qx + c.jx;
+    z[0] = zp[0]; z[1] = zp[1]; z[2] = zp[F.qx]; z[3] = zp[F.qx + 1];
+    const Pair<T>* gp = reinterpret_cast<const Pair<T>*>(F.g) + ((size_t)(c.ly - 3) * F.qx + (c.lx - 3));
 #pragma unroll
     for (int r = 0; r < 4; r++) {
 #pragma unroll
-        for (int q = 0; q < 8; q++) c[r][q] = gp[(size_t)r * F.qx * 2 + q];
+        for (int q = 0; q < 4; q++) g[r][q] = gp[(size_t)r * F.qx + q];
     }
-    // ---- bilinear n (fpbisp order: c * w_y * w_x)
-    n = fma_(z11 * lwy[1], lwx[1], fma_(z10 * lwy[1], lwx[0], fma_(z01 * lwy[0], lwx[1], (z00 * lwy[0]) * lwx[0])));
-    // ---- bicubic gradient: shared basis for both components (same knots); row sums, then the column sum
+}
+
+template <typename T> __device__ __forceinline__ void gather_none(T z[4], Pair<T> g[4][4]) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        z[r] = T(1);
+#pragma unroll
+        for (int q = 0; q < 4; q++) g[r][q] = Pair<T>{T(0), T(0)};
+    }
+}
+
+// bilinear n (fpbisp order: c * w_y * w_x) and the bicubic gradient: one basis for both components (same
+// knots); row sums, then the column sum.
+template <typename T>
+__device__ __forceinline__ void field_combine(const Cell<T>& c, const T z[4], const Pair<T> g[4][4], T& n, T& gx, T& gy) {
+    n = fma_(z[3] * c.lwy[1], c.lwx[1], fma_(z[2] * c.lwy[1], c.lwx[0], fma_(z[1] * c.lwy[0], c.lwx[1], (z[0] * c.lwy[0]) * c.lwx[0])));
     T sx = 0, sy = 0;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-        T rx = c[r][0] * wx[0], ry = c[r][1] * wx[0];
+        T rx = g[r][0].x * c.wx[0], ry = g[r][0].y * c.wx[0];
 #pragma unroll
         for (int q = 1; q < 4; q++) {
-            rx = fma_(c[r][2 * q], wx[q], rx);
-            ry = fma_(c[r][2 * q + 1], wx[q], ry);
+            rx = fma_(g[r][q].x, c.wx[q], rx);
+            ry = fma_(g[r][q].y, c.wx[q], ry);
         }
-        sx = r == 0 ? rx * wy[0] : fma_(rx, wy[r], sx);
-        sy = r == 0 ? ry * wy[0] : fma_(ry, wy[r], sy);
+        sx = r == 0 ? rx * c.wy[0] : fma_(rx, c.wy[r], sx);
+        sy = r == 0 ? ry * c.wy[0] : fma_(ry, c.wy[r], sy);
     }
     gx = sx;
     gy = sy;
+}
+
+// Gather policy 1: every lookup reads its 36 coefficients from global memory (L1/L2-resident in practice).
+template <typename T> struct GlobalGather {
+    __device__ __forceinline__ void fetch(const FieldDev<T>& F, const Cell<T>& c, bool active, T z[4], Pair<T> g[4][4]) {
+        // an idle lane reads the grid's first window instead of its stale cell: all idle lanes then share one
+        // cache line, without a branch around the loads
+        Cell<T> cc = c;
+        cc.jx = active ? c.jx : 0; cc.jy = active ? c.jy : 0; cc.lx = active ? c.lx : 3; cc.ly = active ? c.ly : 3;
+        gather_global(F, cc, z, g);
+    }
+};
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
+    return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+    return v;
+}
+
+// Gather policy 2: a wave-private LDS tile of the field.  The rays of a wave travel together (they leave one
+// origin with neighbouring angles), so their 4x4 windows overlap almost completely and move ~0.15 cell per step:
+// the wave keeps the TILE x TILE block of coefficients around them in LDS, serves lookups with ds_read (a few
+// LDS cycles, broadcast for equal addresses) instead of 18 texture-path loads, and re-stages only when a live
+// lane's window leaves the tile (every ~50 steps).  A lane whose window is outside (incoherent wave, grid edge)
+// reads global memory for that lookup -- the coefficient VALUES are the same bits either way, so results do not
+// depend on the policy.  No block barrier: the tile is private to one wave and LDS executes a wave's DS
+// instructions in order; fetch() must be reached in wave-uniform control flow (it votes and shuffles).
+template <typename T> struct LdsGather {
+    static constexpr int TILE = 16;                 // coefficient rows/cols held
+    static constexpr int GPITCH = TILE + 1;         // pairs per g row (one pad pair against bank aliasing)
+    static constexpr int ZPITCH = TILE + 2;         // elements per zn row
+    static constexpr int ELEMS = 2 * TILE * GPITCH + TILE * ZPITCH;   // in units of T
+    RT_LDS Pair<T>* gt;   // this wave's region: g tile ...
+    RT_LDS T* zt;         // ... then zn tile
+    int ox, oy;      // tile origin in coefficient indices (wave-uniform)
+    int valid;       // tile holds data
+    int cooldown;    // steps to wait before trying to stage again after the wave's windows did not fit
+
+    __device__ __forceinline__ void init(T* wave_lds) {
+        gt = (RT_LDS Pair<T>*)wave_lds;
+        zt = (RT_LDS T*)(wave_lds + 2 * TILE * GPITCH);
+        ox = oy = 0; valid = 0; cooldown = 0;
+    }
+
+    __device__ __forceinline__ void stage(const FieldDev<T>& F) {
+        const unsigned lane = __lane_id();
+        const Pair<T>* gsrc = reinterpret_cast<const Pair<T>*>(F.g);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < TILE * TILE / 64; q++) {
+            const int p = (int)lane + 64 * q, row = p / TILE, col = p % TILE;
+            const size_t src = (size_t)(oy + row) * F.qx + (ox + col);
+            gt[row * GPITCH + col] = gsrc[src];
+            zt[row * ZPITCH + col] = F.zn[src];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    __device__ __forceinline__ void read_tile(int cx, int cy, T z[4], Pair<T> g[4][4]) const {
+        const RT_LDS Pair<T>* gw = gt + cy * GPITCH + cx;
+        const RT_LDS T* zw = zt + (cy + 1) * ZPITCH + (cx + 1);
+        z[0] = zw[0]; z[1] = zw[1]; z[2] = zw[ZPITCH]; z[3] = zw[ZPITCH + 1];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) g[r][q] = gw[r * GPITCH + q];
+        }
+    }
+
+    __device__ __forceinline__ void fetch(const FieldDev<T>& F, const Cell<T>& c, bool active, T z[4], Pair<T> g[4][4]) {
+        int cx = c.lx - 3 - ox, cy = c.ly - 3 - oy;
+        // the bilinear 2x2 sits at window offset (+1,+1) when the cell is not at a not-a-knot end
+        const bool regular = c.jx == c.lx - 2 && c.jy == c.ly - 2;
+        // an idle lane counts as served (it reads tile corner (0,0); nobody uses what it computes)
+        bool fits = !active || (valid && regular && (unsigned)cx <= (unsigned)(TILE - 4) && (unsigned)cy <= (unsigned)(TILE - 4));
+        if (__ballot(!fits) != 0ull) {
+            if (cooldown == 0 && F.qx >= TILE && F.qy >= TILE) {
+                const int mnx = wave_min_i(active && regular ? c.lx - 3 : 0x7fffffff);
+                const int mxx = wave_max_i(active && regular ? c.lx : -0x7fffffff);
+                const int mny = wave_min_i(active && regular ? c.ly - 3 : 0x7fffffff);
+                const int mxy = wave_max_i(active && regular ? c.ly : -0x7fffffff);
+                if (mxx >= mnx && mxx - mnx < TILE && mxy - mny < TILE) {
+                    int nx = mnx - (TILE - (mxx - mnx + 1)) / 2, ny = mny - (TILE - (mxy - mny + 1)) / 2;
+                    nx = nx < 0 ? 0 : (nx > F.qx - TILE ? F.qx - TILE : nx);
+                    ny = ny < 0 ? 0 : (ny > F.qy - TILE ? F.qy - TILE : ny);
+                    ox = nx; oy = ny; valid = 1;
+                    stage(F);
+                    cx = c.lx - 3 - ox; cy = c.ly - 3 - oy;
+                    fits = !active || (regular && (unsigned)cx <= (unsigned)(TILE - 4) && (unsigned)cy <= (unsigned)(TILE - 4));
+                } else {
+                    cooldown = 32;   // incoherent wave: lanes outside read global memory; look again later
+                }
+            } else if (cooldown > 0) {
+                --cooldown;
+            }
+        }
+        cx = (fits && active) ? cx : 0;
+        cy = (fits && active) ? cy : 0;
+        if (__ballot(!fits) == 0ull) {
+            read_tile(cx, cy, z, g);              // the common case, wave-uniform: straight-line LDS reads
+        } else if (fits) {
+            read_tile(cx, cy, z, g);
+        } else {
+            gather_global(F, c, z, g);            // this lane's window is outside the tile (or at a grid end)
+        }
+    }
+};
+
+// n_gradient(vector, grd, z) (:141-156): bilinear n, bicubic dn/dx and dn/dy at (x, y) -> (n, [gx, gy]).
+// `active` tells the gather policy whether this lane's lookup matters (idle lanes still execute it).
+template <typename T, typename G>
+__device__ __forceinline__ void n_gradient(const FieldDev<T>& F, G& gather, bool active, T x, T y, T& n, T& gx, T& gy) {
+    Cell<T> c;
+    field_locate(F, x, y, c);
+    T z[4];
+    Pair<T> g[4][4];
+    gather.fetch(F, c, active, z, g);
+    field_combine(c, z, g, n, gx, gy);
 }
 
 // ---------------------------------------------------------------- per-ray state
@@ -375,28 +521,27 @@ __device__ __forceinline__ T ang_golden_aniso(const Ray<T>& r, const Consts<T>& 
     return golden<T>(cost, r.th - T(kHalfPi), r.th + T(kHalfPi));
 }
 
-// ---- opN (:469-764): final position / angle / n / gradient of one DELTA_S step (+ 1/n at the new point)
+// ---- opN (:469-764), split around the field lookup: advancement, then angle determination
 template <typename T, int METHOD>
-__device__ __forceinline__ void op_step(const FieldDev<T>& F, const Consts<T>& k, const Ray<T>& r, T& fx, T& fy,
-                                        T& fth, T& fn, T& fgx, T& fgy, T& frn) {
-    bool flag = true;
-    if constexpr (METHOD == 1 || METHOD == 2) adv_first(r, k.step, fx, fy);
-    else if constexpr (METHOD == 3 || METHOD == 4 || METHOD == 5 || METHOD == 10) flag = adv_curv(r, k, fx, fy);
-    else adv_second(r, k, fx, fy);
-    n_gradient(F, fx, fy, fn, fgx, fgy);
-    frn = rcp_full(fn);
-    if constexpr (METHOD == 1 || METHOD == 8) fth = ang_cost(r, k.step, fgx, fgy);
-    else if constexpr (METHOD == 2 || METHOD == 6) fth = ang_rk2(r, k.step, frn, fgx, fgy);
-    else if constexpr (METHOD == 3) fth = flag ? ang_rk2(r, k.step, frn, fgx, fgy) : r.th;
-    else if constexpr (METHOD == 4) fth = flag ? ang_cost(r, k.step, fgx, fgy) : r.th;
-    else if constexpr (METHOD == 5) fth = flag ? ang_golden_iso(r, k.step, fn, fgx, fgy) : r.th;
-    else if constexpr (METHOD == 9) fth = ang_golden_iso(r, k.step, fn, fgx, fgy);
-    else if constexpr (METHOD == 10) fth = flag ? ang_golden_aniso(r, k, fn, fgx, fgy) : r.th;
-    else if constexpr (METHOD == 11) fth = ang_golden_aniso(r, k, fn, fgx, fgy);
+__device__ __forceinline__ bool op_advance(const Consts<T>& k, const Ray<T>& r, T& fx, T& fy) {
+    if constexpr (METHOD == 1 || METHOD == 2) { adv_first(r, k.step, fx, fy); return true; }
+    else if constexpr (METHOD == 3 || METHOD == 4 || METHOD == 5 || METHOD == 10) return adv_curv(r, k, fx, fy);
+    else { adv_second(r, k, fx, fy); return true; }
+}
+template <typename T, int METHOD>
+__device__ __forceinline__ T op_angle(const Consts<T>& k, const Ray<T>& r, bool flag, T fx, T fy, T fn, T fgx, T fgy, T frn) {
+    if constexpr (METHOD == 1 || METHOD == 8) return ang_cost(r, k.step, fgx, fgy);
+    else if constexpr (METHOD == 2 || METHOD == 6) return ang_rk2(r, k.step, frn, fgx, fgy);
+    else if constexpr (METHOD == 3) return flag ? ang_rk2(r, k.step, frn, fgx, fgy) : r.th;
+    else if constexpr (METHOD == 4) return flag ? ang_cost(r, k.step, fgx, fgy) : r.th;
+    else if constexpr (METHOD == 5) return flag ? ang_golden_iso(r, k.step, fn, fgx, fgy) : r.th;
+    else if constexpr (METHOD == 9) return ang_golden_iso(r, k.step, fn, fgx, fgy);
+    else if constexpr (METHOD == 10) return flag ? ang_golden_aniso(r, k, fn, fgx, fgy) : r.th;
+    else if constexpr (METHOD == 11) return ang_golden_aniso(r, k, fn, fgx, fgy);
     else {  // 7: finite_diff (:370-372) over [P0, P1, P2, P3] = [h0, h1, (x,y), f]
         const T vx = T(11) * fx - T(18) * r.x + T(9) * r.hx1 - T(2) * r.hx0;
         const T vy = T(11) * fy - T(18) * r.y + T(9) * r.hy1 - T(2) * r.hy0;
-        fth = M<T>::atan2_(vy, vx);
+        return M<T>::atan2_(vy, vx);
     }
 }
 
@@ -435,25 +580,28 @@ template <typename T> __device__ __forceinline__ bool outside(const Consts<T>& k
     return r.x > k.box[1] || r.x < k.box[0] || r.y > k.box[3] || r.y < k.box[2];
 }
 
-// One iteration of trazar's loop for row index i (the row being produced).  For op7 rows 1 and 2 are
-// the bootstrap steps (:833-864): first- and second-order backward differences and no boundary test.
-template <typename T, int METHOD, bool ISO>
-__device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& k, Ray<T>& r, int i) {
-    T fx, fy, fth, fn, fgx, fgy, frn;
+// One iteration of trazar's loop for row index i (the row being produced); returns "still inside the box".
+// For op7 rows 1 and 2 are the bootstrap steps (:833-864): first- and second-order backward differences and
+// no boundary test.  Every lane of a wave calls this together (the gather policy may vote); `active` marks
+// the lanes whose ray is really stepping -- an idle lane just evolves a stale, finite state nobody reads.
+template <typename T, int METHOD, bool ISO, typename G>
+__device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& k, G& gather, bool active, Ray<T>& r, int i) {
+    T fx, fy, fth, fn, fgx, fgy;
+    const bool flag = op_advance<T, METHOD>(k, r, fx, fy);
+    n_gradient(F, gather, active, fx, fy, fn, fgx, fgy);
+    const T frn = rcp_full(fn);
+    bool boot = false;
     if (METHOD == 7 && i <= 2) {
-        adv_second(r, k, fx, fy);
-        n_gradient(F, fx, fy, fn, fgx, fgy);
-        frn = rcp_full(fn);
         T vx, vy;
         if (i == 1) { vx = fx - r.x; vy = fy - r.y; }                                          // (:843)
         else { vx = T(3) * fx - T(4) * r.x + r.hx1; vy = T(3) * fy - T(4) * r.y + r.hy1; }     // (:856)
         fth = M<T>::atan2_(vy, vx);
-        store_update<T, ISO>(k, r, fx, fy, fth, fn, fgx, fgy, frn);
-        return true;  // still alive (no boundary test in the bootstrap)
+        boot = true;  // no boundary test in the bootstrap
+    } else {
+        fth = op_angle<T, METHOD>(k, r, flag, fx, fy, fn, fgx, fgy, frn);
     }
-    op_step<T, METHOD>(F, k, r, fx, fy, fth, fn, fgx, fgy, frn);
     store_update<T, ISO>(k, r, fx, fy, fth, fn, fgx, fgy, frn);
-    return !outside(k, r);
+    return boot || !outside(k, r);
 }
 
 }  // namespace rt

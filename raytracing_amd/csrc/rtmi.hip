@@ -133,7 +133,8 @@ __global__ void k_field_eval(rt::FieldDev<T> F, long npts, const double* x, cons
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npts) return;
     T a, b, c;
-    rt::n_gradient<T>(F, (T)x[i], (T)y[i], a, b, c);
+    rt::GlobalGather<T> gg;
+    rt::n_gradient(F, gg, true, (T)x[i], (T)y[i], a, b, c);
     n[i] = a; gx[i] = b; gy[i] = c;
 }
 
@@ -379,7 +380,8 @@ template <typename T> __global__ void k_init(BatchDev<T> a) {
     if (k >= a.R) return;
     rt::Ray<T> r;
     r.x = (T)a.x0[k]; r.y = (T)a.y0[k]; r.th = (T)a.th0[k];
-    rt::n_gradient<T>(a.F, r.x, r.y, r.n, r.gx, r.gy);
+    rt::GlobalGather<T> gg;
+    rt::n_gradient(a.F, gg, true, r.x, r.y, r.n, r.gx, r.gy);
     rt::derive<T, false>(a.K, r);
     r.dsim = 0; r.dreal = 0; r.tt = 0;
     a.x[k] = r.x; a.y[k] = r.y; a.th[k] = r.th; a.n[k] = r.n; a.gx[k] = r.gx; a.gy[k] = r.gy;
@@ -414,23 +416,51 @@ __device__ __forceinline__ void store_ray(const BatchDev<T>& a, long k, const rt
     a.alive[k] = alive;
 }
 
+// A finite, in-grid dummy state for lanes that hold no ray (they still execute every step, see rt::ray_step).
+template <typename T> __device__ __forceinline__ void idle_ray(const BatchDev<T>& a, rt::Ray<T>& r) {
+    r.x = a.F.ax + a.F.hx * T(8); r.y = a.F.ay + a.F.hy * T(8); r.th = 0; r.n = 1; r.gx = 0; r.gy = 0;
+    r.ux = 1; r.uy = 0; r.coef = 1; r.nray = 1; r.rn = 1;
+    r.dsim = r.dreal = r.tt = r.mx = r.my = 0;
+    r.hx0 = r.hx1 = r.x; r.hy0 = r.hy1 = r.y;
+}
+
+template <typename T, bool LDS> struct GatherOf { using type = rt::GlobalGather<T>; };
+template <typename T> struct GatherOf<T, true> { using type = rt::LdsGather<T>; };
+template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::GlobalGather<T>&, T*) {}
+template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::LdsGather<T>& g, T* lds) {
+    g.init(lds + (threadIdx.x >> 6) * rt::LdsGather<T>::ELEMS);
+}
+
 // The loop at :866-879: one lane per ray, state in registers for up to nsteps DELTA_S steps.
-// ISO (gamma == 1) drops the anisotropic factor's dead arithmetic; results are bit-identical either way.
-template <typename T, int METHOD, bool ISO>
+// ISO (gamma == 1) drops the anisotropic factor's dead arithmetic; LDS selects the wave-private field tile
+// (rt::LdsGather) over per-lookup global gathers.  Results are bit-identical across all four variants.
+// Every lane runs every iteration until no lane of its wave is active; a ray's state is stored the moment it
+// terminates (or when the launch's step budget ends), so idle lanes never write.
+template <typename T, int METHOD, bool ISO, bool LDS>
 __global__ __launch_bounds__(256, 2) void k_advance(BatchDev<T> a, int nsteps) {
+    __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
+    typename GatherOf<T, LDS>::type gather;
+    gather_init<T, LDS>(gather, lds);
     const bool RECORD = a.stride != 0;
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned done = 0, live = 0;
-    if (k < a.R && a.alive[k]) {
-        rt::Ray<T> r;
-        int i;
+    rt::Ray<T> r;
+    int i = 0, until = 0;
+    long row = 0;
+    bool alive = k < a.R && a.alive[k];
+    if (alive) {
         load_ray<T, METHOD, ISO>(a, k, r, i);
-        int until = RECORD ? a.stride - (i % a.stride) : 0;  // steps until the next recorded row
-        long row = RECORD ? i / a.stride : 0;
-        bool alive = true;
-        for (int it = 0; it < nsteps && alive; ++it) {
-            ++i;
-            alive = rt::ray_step<T, METHOD, ISO>(a.F, a.K, r, i);
+        until = RECORD ? a.stride - (i % a.stride) : 0;  // steps until the next recorded row
+        row = RECORD ? i / a.stride : 0;
+    } else {
+        idle_ray(a, r);
+    }
+    for (int it = 0; it < nsteps; ++it) {
+        if (__ballot(alive) == 0ull) break;
+        const bool active = alive;
+        ++i;
+        const bool inside = rt::ray_step<T, METHOD, ISO>(a.F, a.K, gather, active, r, i);
+        if (active) {
             if (RECORD) {
                 if (--until == 0) {
                     until = a.stride;
@@ -438,11 +468,14 @@ __global__ __launch_bounds__(256, 2) void k_advance(BatchDev<T> a, int nsteps) {
                     if (row < a.rec_rows) write_row(a, row, k, r);
                 }
             }
-            alive = alive && (i + 1 < a.max_size);
+            alive = inside && (i + 1 < a.max_size);
             ++done;
+            if (!alive) store_ray<T, METHOD>(a, k, r, i, false);
         }
-        store_ray<T, METHOD>(a, k, r, i, alive);
-        live = alive;
+    }
+    if (alive) {
+        store_ray<T, METHOD>(a, k, r, i, true);
+        live = 1;
     }
     done = wave_sum(done);
     live = wave_sum(live);
@@ -459,13 +492,15 @@ __global__ __launch_bounds__(256, 2) void k_advance(BatchDev<T> a, int nsteps) {
 // never depends on its lane or wave mates, so results are bit-identical to k_advance.
 // Exit: the queue is exhausted and no lane is live -- reached by every wave because each ray takes at most
 // max_size steps and the queue only advances.
-template <typename T, int METHOD, bool ISO>
+template <typename T, int METHOD, bool ISO, bool LDS>
 __global__ __launch_bounds__(256, 2) void k_trace_refill(BatchDev<T> a, int refill_min, int chunk) {
+    __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
+    typename GatherOf<T, LDS>::type gather;
+    gather_init<T, LDS>(gather, lds);
     const bool RECORD = a.stride != 0;
     const unsigned lane = threadIdx.x & 63;
     rt::Ray<T> r;
-    r.x = r.y = r.th = r.n = r.gx = r.gy = r.ux = r.uy = r.coef = r.nray = r.rn = 0;
-    r.dsim = r.dreal = r.tt = r.mx = r.my = r.hx0 = r.hy0 = r.hx1 = r.hy1 = 0;
+    idle_ray(a, r);
     long k = 0, row = 0;
     int i = 0, until = 0;
     bool alive = false;
@@ -499,9 +534,11 @@ __global__ __launch_bounds__(256, 2) void k_trace_refill(BatchDev<T> a, int refi
             continue;  // the claimed rays were all finished already; claim again (the queue advanced)
         }
         for (int it = 0; it < chunk; ++it) {
-            if (alive) {
-                ++i;
-                alive = rt::ray_step<T, METHOD, ISO>(a.F, a.K, r, i);
+            if (__ballot(alive) == 0ull) break;
+            const bool active = alive;
+            ++i;
+            const bool inside = rt::ray_step<T, METHOD, ISO>(a.F, a.K, gather, active, r, i);
+            if (active) {
                 if (RECORD) {
                     if (--until == 0) {
                         until = a.stride;
@@ -509,11 +546,10 @@ __global__ __launch_bounds__(256, 2) void k_trace_refill(BatchDev<T> a, int refi
                         if (row < a.rec_rows) write_row(a, row, k, r);
                     }
                 }
-                alive = alive && (i + 1 < a.max_size);
+                alive = inside && (i + 1 < a.max_size);
                 ++done;
                 if (!alive) store_ray<T, METHOD>(a, k, r, i, false);
             }
-            if (__ballot(alive) == 0) break;
         }
     }
     done = wave_sum(done);
@@ -587,33 +623,34 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     return a;
 }
 
-template <typename T> static const void* advance_fn(int m, bool iso) {
-    switch (m) {
-#define CASE_(M) case M: return iso ? (const void*)k_advance<T, M, true> : (const void*)k_advance<T, M, false>;
-        CASE_(1) CASE_(2) CASE_(3) CASE_(4) CASE_(5) CASE_(6) CASE_(7) CASE_(8) CASE_(9)
-#undef CASE_
-        case 10: return (const void*)k_advance<T, 10, false>;
-        case 11: return (const void*)k_advance<T, 11, false>;
-    }
-    return nullptr;
+// kernel variant tables: [method][iso][lds].  Anisotropic-only methods (op10/op11) have no ISO build.
+#define RTMI_VARIANTS_(K, T, M) \
+    {{(const void*)K<T, M, false, false>, (const void*)K<T, M, false, true>}, \
+     {(const void*)K<T, (M < 10 ? M : 1), (M < 10), false>, (const void*)K<T, (M < 10 ? M : 1), (M < 10), true>}}
+template <typename T> static const void* advance_fn(int m, bool iso, bool lds) {
+    static const void* const tab[11][2][2] = {
+        RTMI_VARIANTS_(k_advance, T, 1), RTMI_VARIANTS_(k_advance, T, 2), RTMI_VARIANTS_(k_advance, T, 3),
+        RTMI_VARIANTS_(k_advance, T, 4), RTMI_VARIANTS_(k_advance, T, 5), RTMI_VARIANTS_(k_advance, T, 6),
+        RTMI_VARIANTS_(k_advance, T, 7), RTMI_VARIANTS_(k_advance, T, 8), RTMI_VARIANTS_(k_advance, T, 9),
+        RTMI_VARIANTS_(k_advance, T, 10), RTMI_VARIANTS_(k_advance, T, 11)};
+    return tab[m - 1][iso ? 1 : 0][lds ? 1 : 0];
 }
+template <typename T> static const void* refill_fn(int m, bool iso, bool lds) {
+    static const void* const tab[11][2][2] = {
+        RTMI_VARIANTS_(k_trace_refill, T, 1), RTMI_VARIANTS_(k_trace_refill, T, 2), RTMI_VARIANTS_(k_trace_refill, T, 3),
+        RTMI_VARIANTS_(k_trace_refill, T, 4), RTMI_VARIANTS_(k_trace_refill, T, 5), RTMI_VARIANTS_(k_trace_refill, T, 6),
+        RTMI_VARIANTS_(k_trace_refill, T, 7), RTMI_VARIANTS_(k_trace_refill, T, 8), RTMI_VARIANTS_(k_trace_refill, T, 9),
+        RTMI_VARIANTS_(k_trace_refill, T, 10), RTMI_VARIANTS_(k_trace_refill, T, 11)};
+    return tab[m - 1][iso ? 1 : 0][lds ? 1 : 0];
+}
+#undef RTMI_VARIANTS_
 static const void* pick_advance(const rtmi_batch* b) {
-    const bool iso = b->p.gamma == 1.0 && b->p.method < 10;
-    return b->p.dtype == RTMI_F64 ? advance_fn<double>(b->p.method, iso) : advance_fn<float>(b->p.method, iso);
-}
-template <typename T> static const void* refill_fn(int m, bool iso) {
-    switch (m) {
-#define CASE_(M) case M: return iso ? (const void*)k_trace_refill<T, M, true> : (const void*)k_trace_refill<T, M, false>;
-        CASE_(1) CASE_(2) CASE_(3) CASE_(4) CASE_(5) CASE_(6) CASE_(7) CASE_(8) CASE_(9)
-#undef CASE_
-        case 10: return (const void*)k_trace_refill<T, 10, false>;
-        case 11: return (const void*)k_trace_refill<T, 11, false>;
-    }
-    return nullptr;
+    const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = b->p.field_path != 1;
+    return b->p.dtype == RTMI_F64 ? advance_fn<double>(b->p.method, iso, lds) : advance_fn<float>(b->p.method, iso, lds);
 }
 static const void* pick_refill(const rtmi_batch* b) {
-    const bool iso = b->p.gamma == 1.0 && b->p.method < 10;
-    return b->p.dtype == RTMI_F64 ? refill_fn<double>(b->p.method, iso) : refill_fn<float>(b->p.method, iso);
+    const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = b->p.field_path != 1;
+    return b->p.dtype == RTMI_F64 ? refill_fn<double>(b->p.method, iso, lds) : refill_fn<float>(b->p.method, iso, lds);
 }
 
 // clear_traj: zero the trajectory arrays (np.zeros, :802-803).  A reset with unchanged launch conditions rewrites
@@ -660,6 +697,7 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     ARG_TRY(p->launch_mode == 0 || p->launch_mode == 1, "rtmi_batch_create: launch_mode must be 0 or 1");
     ARG_TRY(p->refill_min >= 0 && p->refill_min <= 64, "rtmi_batch_create: refill_min must be in [0, 64]");
     ARG_TRY(p->exact_basis == 0 || p->exact_basis == 1, "rtmi_batch_create: exact_basis must be 0 or 1");
+    ARG_TRY(p->field_path == 0 || p->field_path == 1, "rtmi_batch_create: field_path must be 0 (LDS tile) or 1 (global)");
     rtmi_batch* b = new (std::nothrow) rtmi_batch();
     if (!b) return fail(RTMI_ERR_ALLOC, "rtmi_batch_create: host allocation failed");
     b->field = f; b->p = *p; b->R = R; b->esz = p->dtype == RTMI_F64 ? 8 : 4; b->stream = (hipStream_t)stream;

@@ -275,7 +275,7 @@ class Batch:
 
     def __init__(self, field, method, step, max_size, box, gamma, thetas, x0, y0, record_stride=1, rec_rows=0,
                  gamma_step=None, stream=None, ext_s_ray=None, ext_n_ray=None, block_size=0, launch_mode=0,
-                 refill_min=0, exact_basis=0):
+                 refill_min=0, exact_basis=0, field_path=0):
         self.field = field
         th = np.ascontiguousarray(thetas, dtype=np.float64)
         self.R = len(th)
@@ -289,7 +289,7 @@ class Batch:
         for i in range(4):
             p.box[i] = float(box[i])
         p.launch_mode = int(launch_mode); p.block_size = int(block_size); p.refill_min = int(refill_min)
-        p.exact_basis = int(exact_basis)
+        p.exact_basis = int(exact_basis); p.field_path = int(field_path)
         p.ext_s_ray = ext_s_ray; p.ext_n_ray = ext_n_ray
         self.params = p
         self._h = C.c_void_p()

@@ -308,6 +308,35 @@ def test_uniform_basis_vs_exact_basis(scen, m, rb, gpu_fields, oracle_fields):
     assert gap < 1e-11 and e_fast < REL and e_exact < REL
 
 
+@pytest.mark.parametrize("scen,m,shuffle,mode", [("vert_heterogeneous", 6, False, 0), ("vert_heterogeneous", 6, True, 0),
+                                                 ("interface", 6, False, 0), ("fisheye", 6, False, 0),
+                                                 ("vert_heterogeneous", 7, True, 1), ("anisotropy", 11, False, 0)])
+def test_lds_tile_equals_global_gather(scen, m, shuffle, mode, rb, gpu_fields):
+    """field_path 0 (wave-private LDS tile of the field, re-staged as the wave moves; lanes outside the tile fall
+    back to global loads) must give the same bits as field_path 1 (every lookup gathers from global memory):
+    coherent fans, a shuffled batch (tile rarely fits), the refill kernel, rays that run to the grid's edge."""
+    R = 2000 if m != 11 else 200
+    lim = LIMITS[scen]
+    if scen == "fisheye":
+        th, x0, y0, step, ms = np.linspace(np.pi / 4, 3 * np.pi / 4, R), 1.0, 0.0, 2 * np.pi / 303, 3040
+    else:
+        th, x0, y0, step, ms = np.linspace(0.06, np.pi / 2, R), -2.0, -2.0, rb.DELTA_S, 30228
+    if shuffle:
+        th = np.random.default_rng(9).permutation(th)
+    if scen == "vert_heterogeneous" and not shuffle:
+        lim = (-4.9, 7.9, -5.4, 3.9)          # let rays run into the not-a-knot end cells of the grid
+    out = []
+    for path in (0, 1):
+        b = rb.Batch(gpu_fields(scen), m, step, ms, lim, 3 if scen == "anisotropy" else 1, th, x0, y0, record_stride=8,
+                     field_path=path, launch_mode=mode)
+        b.run()
+        out.append((b.d_ray(), b.final(), b.rows(), b.stats()["lds_bytes"]))
+        b.close()
+    assert out[0][3] > 0 and out[1][3] <= 16
+    for u, v in zip(out[0][:3], out[1][:3]):
+        assert np.array_equal(u, v)
+
+
 def test_record_strides_and_edges(rb, gpu_fields):
     F = gpu_fields("vert_heterogeneous")
     lim = LIMITS["vert_heterogeneous"]
