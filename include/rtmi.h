@@ -122,6 +122,14 @@ int rtmi_read_final(rtmi_batch *b, double *final9);
 /* Copy recorded rows [row0, row0+nrows) to host as fp64: s_ray[nrows][6][R] and/or n_ray[nrows][R] (may be NULL). */
 int rtmi_read_rows(rtmi_batch *b, int64_t row0, int64_t nrows, double *s_ray, double *n_ray);
 
+/* The reference's in-script physical checks, evaluated on the device from what the trace left in HBM
+ * (SURVEY.md section 4).  out[R], host, fp64:
+ *   SNELL_ERROR  |exit angle - Snell/reflection angle| in degrees per ray (RT_bench.py:896-919); needs record_stride 1
+ *   CLOSURE      100*|(1,0) - s_ray[-1,0:2,k]|/(2 pi) per ray, the fisheye closure error (:956, :1393)
+ *   PX_CV        100*std/mean of the recorded non-zero p_x per ray (:1354-1360); the reference averages rays 1..R-2 */
+typedef enum { RTMI_METRIC_SNELL_ERROR = 1, RTMI_METRIC_CLOSURE = 2, RTMI_METRIC_PX_CV = 3 } rtmi_metric_kind;
+int rtmi_metric(rtmi_batch *b, int kind, double *out);
+
 typedef struct {
     void *s_ray, *n_ray;                 /* device, dtype, layouts above */
     void *x, *y, *theta, *n, *gx, *gy;   /* device SoA ray state, dtype, length R */

@@ -195,6 +195,37 @@ def main():
         th = np.linspace(np.pi / 4, 3 * np.pi / 4, 9)
         d, s_ray = run_traj(R, "fisheye", 6, 2 * np.pi / 303, 304, rays=(th, np.array((1, 0))))
         save("traj_fisheye_op6_fan9", d)
+    if want("sweep"):
+        # DELTA_S calibration sweep (RT_bench.py:1296-1318): search_delta over every 10th candidate, op6
+        for scen in ("interface", "fisheye", "vert_heterogeneous"):
+            c, linx, liny, Z, z, grd = build_field(R, scen)
+            R.op_interface, R.op_fish, R.op_vert_heterogeneous, R.op_anisotropy = c[9:13]   # globals search_delta reads (:953-957)
+            if c[9]:
+                divisors = np.arange(R.DELTA_S_DIVISOR_UPPER_LIMIT, R.DELTA_S_DIVISOR_LOWER_LIMIT - R.DELTA_STEP, -R.DELTA_STEP)
+                opts = R.SIGMA / divisors
+            elif c[10]:
+                divisors = np.arange(R.DELTA_S_DIVISOR_FISHEYE_UPPER_LIMIT, R.DELTA_S_DIVISOR_FISHEYE_LOWER_LIMIT - R.DELTA_STEP_FISHEYE, -R.DELTA_STEP_FISHEYE)
+                opts = 2 * np.pi / divisors
+            else:
+                divisors = np.arange(R.DELTA_S_DIVISOR_VERT_UPPER_LIMIT, R.DELTA_S_DIVISOR_VERT_LOWER_LIMIT - 2 * R.DELTA_STEP, -R.DELTA_STEP)
+                opts = R.SIGMA / divisors
+            sel = np.arange(0, len(divisors), 10)
+            res = []
+            t = time.time()
+            for i in sel:
+                r = R.search_delta(R.op6, z, grd, opts[i], divisors[i] + 1, SCEN[scen][0])
+                if c[9]:
+                    res.append([r[0], r[1]])
+                elif c[10]:
+                    res.append([r, 0.0])
+                else:
+                    cvs = np.zeros(c[1] - 2)
+                    for k in range(1, c[1] - 1):
+                        masked = np.ma.masked_equal(r[:, k], 0).compressed()
+                        cvs[k - 1] = 100 * np.std(masked) / np.mean(masked)
+                    res.append([np.mean(cvs), 0.0])
+            print(f"sweep {scen}: {len(sel)} candidates {time.time() - t:.1f}s")
+            save(f"sweep_{scen}_op6", dict(all_divisors=divisors, all_options=opts, sel=sel, results=np.array(res)))
     if want("consts"):
         save("constants", consts)
 

@@ -946,6 +946,79 @@ RTMI_EXPORT int rtmi_read_rows(rtmi_batch* b, int64_t row0, int64_t nrows, doubl
     return RTMI_OK;
 }
 
+// ------------------------------------------------------------------ on-device validation metrics
+// One lane per ray; outputs fp64 [R].  They read data the trace left in HBM, so a 1 M-ray run is checked
+// without copying 100+ GB of trajectories to the host.
+template <typename T> __global__ void k_metric_snell(BatchDev<T> a, double* out) {   // RT_bench.py:896-919
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.R) return;
+    const int i = a.istep[k];
+    const double th = a.th0[k];
+    double angreal;
+    if (th < M_PI / 4) angreal = 90 - 180 * th / M_PI;                                  // reflection (:903)
+    else if (th == M_PI / 4) angreal = 0;
+    else angreal = 180 * asin(sqrt(2.0) * sin(M_PI / 2 - th)) / M_PI;                   // refraction (:908)
+    const long ra = (long)(9.5 * i / 10), rb = (long)((double)(9 * (long)i) / 10);      // int(9.5*i/10), int(9*i/10) (:913)
+    const double distx = (double)a.s_ray[(size_t)ra * 6 * a.R + k] - (double)a.s_ray[(size_t)rb * 6 * a.R + k];
+    const double disty = (double)a.s_ray[((size_t)ra * 6 + 1) * a.R + k] - (double)a.s_ray[((size_t)rb * 6 + 1) * a.R + k];
+    const double angsim = 180 * atan(fabs(distx / disty)) / M_PI;                       // (:916)
+    out[k] = fabs(angsim - angreal);
+}
+template <typename T> __global__ void k_metric_closure(BatchDev<T> a, double* out) {  // RT_bench.py:956, :1393
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.R) return;
+    // s_ray[-1, 0:2, k]: the last row of the array -- written only if the ray ran all max_size-1 steps
+    const bool full = a.istep[k] == a.max_size - 1;
+    const double dx = 1.0 - (full ? (double)a.x[k] : 0.0), dy = 0.0 - (full ? (double)a.y[k] : 0.0);
+    out[k] = 100 * sqrt(fma(dy, dy, dx * dx)) / (2 * M_PI);
+}
+template <typename T> __global__ void k_metric_px_cv(BatchDev<T> a, double* out) {    // RT_bench.py:1354-1360, :1398-1402
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.R) return;
+    const long rows = a.istep[k] / a.stride + 1 < a.rec_rows ? a.istep[k] / a.stride + 1 : a.rec_rows;
+    double sum = 0;
+    long cnt = 0;
+    for (long r = 0; r < rows; r++) {            // np.ma.masked_equal(., 0).compressed(): zeros are skipped
+        const double v = (double)a.s_ray[((size_t)r * 6 + 2) * a.R + k];
+        if (v != 0) { sum += v; ++cnt; }
+    }
+    const double mean = sum / (double)cnt;
+    double ss = 0;
+    for (long r = 0; r < rows; r++) {
+        const double v = (double)a.s_ray[((size_t)r * 6 + 2) * a.R + k];
+        if (v != 0) ss = fma(v - mean, v - mean, ss);
+    }
+    out[k] = 100 * sqrt(ss / (double)cnt) / mean;  // 100*np.std/np.mean
+}
+
+RTMI_EXPORT int rtmi_metric(rtmi_batch* b, int kind, double* out) {
+    ARG_TRY(b && out, "rtmi_metric: null");
+    ARG_TRY(kind >= RTMI_METRIC_SNELL_ERROR && kind <= RTMI_METRIC_PX_CV, "rtmi_metric: unknown metric");
+    if (kind == RTMI_METRIC_SNELL_ERROR)
+        ARG_TRY(b->p.record_stride == 1 && b->p.rec_rows >= b->p.max_size,
+                "rtmi_metric: the exit-angle metric needs the full trajectory (record_stride 1, rec_rows >= max_size)");
+    if (kind == RTMI_METRIC_PX_CV) ARG_TRY(b->p.record_stride >= 1, "rtmi_metric: the p_x metric needs recorded rows");
+    double* d = nullptr;
+    const size_t nb = (size_t)b->R * sizeof(double);
+    HIP_TRY(hipMalloc(&d, nb));
+    const dim3 g((unsigned)((b->R + 255) / 256)), blk(256);
+#define LAUNCH_(K)                                                                                          \
+    do {                                                                                                    \
+        if (b->p.dtype == RTMI_F64) hipLaunchKernelGGL(K<double>, g, blk, 0, b->stream, batch_dev<double>(b), d); \
+        else hipLaunchKernelGGL(K<float>, g, blk, 0, b->stream, batch_dev<float>(b), d);                   \
+    } while (0)
+    if (kind == RTMI_METRIC_SNELL_ERROR) LAUNCH_(k_metric_snell);
+    else if (kind == RTMI_METRIC_CLOSURE) LAUNCH_(k_metric_closure);
+    else LAUNCH_(k_metric_px_cv);
+#undef LAUNCH_
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, nb, hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_metric: ") + hipGetErrorString(e));
+    return RTMI_OK;
+}
+
 RTMI_EXPORT int rtmi_batch_view(rtmi_batch* b, rtmi_device_view* v) {
     ARG_TRY(b && v, "rtmi_batch_view: null");
     const size_t R = (size_t)b->R, e = b->esz;

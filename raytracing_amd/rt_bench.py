@@ -336,6 +336,12 @@ class Batch:
         check(lib().rtmi_read_rows(self._h, row0, nrows, dptr(s), dptr(n)))
         return (s, n) if want_n_ray else s
 
+    def metric(self, kind):
+        """On-device per-ray metric: "snell" (degrees), "closure" (%), "px_cv" (%); see rtmi_metric."""
+        out = np.empty(self.R)
+        check(lib().rtmi_metric(self._h, {"snell": 1, "closure": 2, "px_cv": 3}[kind], dptr(out)))
+        return out
+
     def stats(self):
         s = Stats()
         check(lib().rtmi_batch_stats(self._h, C.byref(s)))
@@ -443,7 +449,7 @@ def trazar(selected_func, z, grd, show, step, divisor, user_choice, *, thetas=No
     compute_times = np.full(ray_count, (st_["kernel_ms"] * 1e-3 if st_["kernel_ms"] > 0 else t2 - t1) / ray_count)
     errors = np.zeros(ray_count)
     if op_if and stride == 1:
-        errors = snell_errors(s_ray, d_ray, theta_v)
+        errors = b.metric("snell")          # (:896-919) evaluated on the device
         if show:
             for k in range(ray_count):
                 i = int(d_ray[2, k])
@@ -464,3 +470,122 @@ def search_delta(option, z, grd, step, divisor, user_choice):
     if c[10]:
         return closure_error(rays)
     return rays[:, 2, :]
+
+
+# --------------------------------------------------------------------------- calibration + benchmark harness
+# (the reference's other consumer of trazar, restated over the GPU path)
+def calibrated_delta_s(user_choice, method_choice):
+    """The hard-coded calibrated DELTA_S table (RT_bench.py:1412-1455).  method_choice is the menu entry "1".."9"
+    (isotropic) or "1"/"2" (anisotropic).  Returns (DELTA_S, DELTA_S_DIVISOR_FISHEYE or None)."""
+    c = constants(user_choice)
+    m = str(method_choice)
+    if c[9] or c[11]:
+        div = {"1": 38.64, "2": 38.37, "3": 2.34, "4": 2.53, "5": 2.53, "6": 2.55, "7": 30.05, "8": 2.74, "9": 2.74}[m]
+        return SIGMA / div, None
+    if c[10]:
+        div = {"1": 4587, "2": 4556, "3": 278, "4": 300, "5": 300, "6": 303, "7": 3567, "8": 325, "9": 325}[m]
+        return 2 * np.pi / div, div
+    return SIGMA / (2.53 if m == "1" else 2.74), None
+
+
+def delta_s_candidates(user_choice):
+    """(divisors, delta_s_options) of the DELTA_S search (RT_bench.py:1302-1312)."""
+    c = constants(user_choice)
+    if c[9]:
+        divisors = np.arange(DELTA_S_DIVISOR_UPPER_LIMIT, DELTA_S_DIVISOR_LOWER_LIMIT - DELTA_STEP, -DELTA_STEP)
+        return divisors, SIGMA / divisors
+    if c[10]:
+        divisors = np.arange(DELTA_S_DIVISOR_FISHEYE_UPPER_LIMIT, DELTA_S_DIVISOR_FISHEYE_LOWER_LIMIT - DELTA_STEP_FISHEYE,
+                             -DELTA_STEP_FISHEYE)
+        return divisors, 2 * np.pi / divisors
+    divisors = np.arange(DELTA_S_DIVISOR_VERT_UPPER_LIMIT, DELTA_S_DIVISOR_VERT_LOWER_LIMIT - 2 * DELTA_STEP, -DELTA_STEP)
+    return divisors, SIGMA / divisors
+
+
+def search_delta_sweep(option, z, grd, delta_s_options, divisors, user_choice):
+    """What executor.map(search_delta, ...) returns (RT_bench.py:1317-1318): one entry per DELTA_S candidate --
+    (mean, max) exit-angle error for interface, closure % for fisheye, mean p_x CV (%) for the vert scenarios
+    (the reference returns the p_x history there and reduces it at :1354-1360; the reduction runs on the device)."""
+    c = constants(user_choice)
+    g, ray_count, theta_v, pos_x, s, xi, xs, yi, ys, op_if, op_fish, _, _ = c
+    fld = _field_of(z, grd)
+    out = []
+    for step, divisor in zip(delta_s_options, np.asarray(divisors) + 1):
+        step = float(step)
+        max_size = int(N * divisor) if op_fish else int(np.ceil(s / step) + 1)
+        x0, y0 = (float(pos_x[0]), float(pos_x[1])) if op_fish else (np.asarray(pos_x, float)[:ray_count], -2.0)
+        b = Batch(fld, option, step, max_size, (xi, xs, yi, ys), g, theta_v[:ray_count], x0, y0,
+                  record_stride=0 if op_fish else 1)
+        b.run()
+        if op_if:
+            e = b.metric("snell")
+            out.append((np.mean(e), np.max(e)))
+        elif op_fish:
+            out.append(b.metric("closure")[0])
+        else:
+            out.append(np.mean(b.metric("px_cv")[1:ray_count - 1]))
+        b.close()
+    return out
+
+
+def find_divisor(results, divisors, user_choice, max_deviation=None):
+    """The three find_index rules of the DELTA_S search (RT_bench.py:1320-1385) -> chosen divisor or None."""
+    c = constants(user_choice)
+    if c[9]:
+        md = MAX_DEVIATION if max_deviation is None else max_deviation
+        errors = [r[0] for r in results]; max_errors = [r[1] for r in results]
+        if not any(e > md for e in errors) or not any(e < md for e in errors):
+            return None
+        for i in reversed(range(len(errors))):
+            if errors[i] < md and max_errors[i] < 0.8:
+                if all(e < md for e in errors[:i]) and all(e < 0.8 for e in max_errors[:i]):
+                    return round(divisors[i], 2)
+        return None
+    if c[10]:
+        md = 5 if max_deviation is None else max_deviation
+        errors = list(results)
+        if not any(e > md for e in errors) or not any(e < md for e in errors):
+            return None
+        for i in range(len(errors)):
+            if errors[i] > md:
+                return round(divisors[i - 1])
+        return None
+    md = 0.05 if max_deviation is None else max_deviation
+    errors = list(results)
+    if not any(e > md for e in errors) or not any(e < md for e in errors):
+        return None
+    for i in range(len(errors)):
+        if i > 1 and errors[i] > md and all(e < md for e in errors[:i - 1]):
+            return round(divisors[i - 1], 2)
+    return None
+
+
+def remove_outliers_iqr(data):
+    """RT_bench.py:123-138."""
+    data = np.asarray(data)
+    q1, q3 = np.percentile(data, 25), np.percentile(data, 75)
+    iqr = q3 - q1
+    return data[(data >= q1 - 1.5 * iqr) & (data <= q3 + 1.5 * iqr)]
+
+
+def benchmark(option, z, grd, step, divisor, user_choice, trial=100, replicas=3, max_rounds=20, **kw):
+    """The reference's benchmark statistic (RT_bench.py:1516-1541) over device propagation times: rounds of
+    trial*replicas runs, IQR filter, median of the last 30 %, repeat until two successive medians differ by
+    < 0.5 %; returns the mean of the last two ("Completion time per scenario", seconds)."""
+    _, _, _, _, b = trazar(option, z, grd, False, step, divisor, user_choice, record=None, return_batch=True, **kw)
+    benchmarks = []
+    try:
+        for _ in range(max_rounds):
+            arr = np.zeros(trial * replicas)
+            for j in range(trial * replicas):
+                b.reset()
+                b.run()
+                arr[j] = b.stats()["kernel_ms"] * 1e-3
+            cleaned = remove_outliers_iqr(arr)
+            benchmarks.append(np.median(cleaned[int(-0.3 * len(cleaned)):]))
+            if len(benchmarks) >= 2:
+                if 100 * abs(benchmarks[-1] - benchmarks[-2]) / max(benchmarks[-1], benchmarks[-2]) < 0.5:
+                    break
+    finally:
+        b.close()
+    return float(np.mean(benchmarks[-2:]))

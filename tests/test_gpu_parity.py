@@ -408,3 +408,81 @@ def test_fp32_path_tracks_fp64(rb, gpu_fields):
     err = np.abs(fa[:2] - fb[:2]).max()
     print(f"fp32 vs fp64 end-point max abs error: {err:.3e}")
     assert err < 2e-2
+
+
+# ------------------------------------------------------------------ on-device validation metrics
+def test_device_metrics_match_reference(rb, gpu_fields):
+    """rtmi_metric vs the reference's own numbers (goldens) and vs the host restatements on read-back rows."""
+    # interface: exit-angle errors (:896-919)
+    t = golden("traj_interface_op6_16")
+    b = rb.Batch(gpu_fields("interface"), 6, float(t["step"]), int(t["max_size"]), t["box"], 1, t["theta"], t["pos_x"],
+                 -2.0, record_stride=1)
+    b.run()
+    err = b.metric("snell")
+    assert np.abs(err - t["errors"]).max() < 1e-6
+    assert np.abs(err - rb.snell_errors(b.rows(), b.d_ray(), t["theta"])).max() < 1e-9
+    b.close()
+    # vert: p_x coefficient of variation (:1354-1360), reference value in the fixture
+    t = golden("traj_vert_op6")
+    b = rb.Batch(gpu_fields("vert_heterogeneous"), 6, float(t["step"]), int(t["max_size"]), t["box"], 1, t["theta"], -2.0,
+                 -2.0, record_stride=1)
+    b.run()
+    cv = b.metric("px_cv")
+    assert abs(np.mean(cv[1:-1]) - float(t["cv_mean"])) < 1e-9
+    assert abs(np.mean(cv[1:-1]) - rb.moment_cv(b.rows(), 31)) < 1e-10
+    b.close()
+    # fisheye: closure error after N turns (:956), reference value 3.0408 %
+    t = golden("traj_fisheye_op6_div304")
+    b = rb.Batch(gpu_fields("fisheye"), 6, float(t["step"]), int(t["max_size"]), t["box"], 1, t["theta"], 1.0, 0.0,
+                 record_stride=0)
+    b.run()
+    assert abs(b.metric("closure")[0] - float(t["closure_pct"])) < 1e-9
+    b.close()
+    from raytracing_amd._lib import RtmiError
+    b = rb.Batch(gpu_fields("vert_heterogeneous"), 6, rb.DELTA_S, 500, LIMITS["vert_heterogeneous"], 1, [0.3], -2.0, -2.0,
+                 record_stride=4)
+    b.run()
+    with pytest.raises(RtmiError, match="full trajectory"):
+        b.metric("snell")
+    b.close()
+
+
+def test_cfg3_fisheye_1m_properties(rb, gpu_fields):
+    """cfg3: fisheye, 1 048 576 rays fp64, calibrated op6 step.  Every launch direction from (1,0) rides a circle
+    through (1,0) and (-1,0) (Maxwell fisheye); rays within |theta-pi/2| < 0.39 stay inside the +-1.5 box for all
+    ten turns and must close on (1,0) like the reference's single ray (3.04 %), the others must leave the box."""
+    R = 1 << 20
+    th = np.linspace(np.pi / 4, 3 * np.pi / 4, R)
+    step, ms = 2 * np.pi / 303, 10 * 304
+    b = rb.Batch(gpu_fields("fisheye"), 6, step, ms, LIMITS["fisheye"], 1, th, 1.0, 0.0, record_stride=0)
+    b.run()
+    d, st, cl = b.d_ray(), b.stats(), b.metric("closure")
+    b.close()
+    assert st["ray_steps"] == int(d[2].sum())
+    stay = np.abs(th - np.pi / 2) < 0.38
+    leave = np.abs(th - np.pi / 2) > 0.41
+    assert np.all(d[2][stay] == ms - 1) and np.all(d[2][leave] < ms - 1)
+    mid = R // 2
+    assert abs(cl[mid] - 3.0408) < 0.01 and cl[stay].max() < 6.0
+
+
+# ------------------------------------------------------------------ SURVEY 8f rank 2: DELTA_S calibration sweep
+@pytest.mark.parametrize("scen", ["interface", "fisheye", "vert_heterogeneous"])
+def test_delta_s_sweep_vs_reference(scen, rb, gpu_fields):
+    """search_delta_sweep (device traces + device metrics per candidate) against the reference's search_delta
+    on every 10th candidate of its calibration grid (fixtures made by oracle/gen_golden.py --only sweep)."""
+    g = golden(f"sweep_{scen}_op6")
+    choice = {"interface": "1", "fisheye": "2", "vert_heterogeneous": "3"}[scen]
+    div, opt = rb.delta_s_candidates(choice)
+    assert np.array_equal(div, g["all_divisors"]) and np.array_equal(opt, g["all_options"])
+    sel = g["sel"]
+    res = rb.search_delta_sweep(rb.op6, gpu_fields(scen), None, opt[sel], div[sel], choice)
+    ref = g["results"]
+    if scen == "interface":
+        assert np.abs(np.array(res) - ref).max() < 1e-6           # degrees (mean, max)
+    else:
+        assert np.abs(np.array(res) - ref[:, 0]).max() < 1e-8     # closure % / mean p_x CV %
+    # the selection rule runs on whatever the sweep returns (thresholds: 0.2 deg & 0.8 deg / 5 % / 0.05 %)
+    pick = rb.find_divisor(res, div[sel], choice)
+    ref_pick = rb.find_divisor([tuple(r) for r in ref] if scen == "interface" else list(ref[:, 0]), div[sel], choice)
+    assert pick == ref_pick

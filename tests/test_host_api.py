@@ -69,3 +69,26 @@ def test_metrics_on_reference_rows(oracle_fields):
                  record_stride=1)
     assert abs(rb.closure_error(r["s_ray"]) - float(t["closure_pct"])) < 1e-9
     assert abs(float(t["closure_pct"]) - 3.0408) < 1e-3      # SURVEY.md section 4 anchor
+
+
+def test_calibrated_table_and_candidates():
+    """RT_bench.py:1302-1312 (search grids) and :1412-1455 (calibrated DELTA_S table)."""
+    assert rb.calibrated_delta_s("1", "6") == (rb.SIGMA / 2.55, None) and rb.calibrated_delta_s("3", "7")[0] == rb.SIGMA / 30.05
+    assert rb.calibrated_delta_s("2", "6") == (2 * np.pi / 303, 303) and rb.calibrated_delta_s("4", "2")[0] == rb.SIGMA / 2.74
+    d, o = rb.delta_s_candidates("1")
+    assert len(d) == 200 and d[0] == 3 and np.allclose(o, rb.SIGMA / d)
+    d, o = rb.delta_s_candidates("2")
+    assert len(d) == 300 and d[0] == 303 and d[-1] == 4
+    d, o = rb.delta_s_candidates("3")
+    assert len(d) == 200 and d[0] == 2                 # the reference steps this grid by DELTA_STEP, not DELTA_STEP_VERT (:1311)
+
+
+def test_find_divisor_rules():
+    div = np.array([3.0, 2.9, 2.8, 2.7, 2.6])
+    assert rb.find_divisor([(0.1, 0.3), (0.15, 0.5), (0.19, 0.7), (0.25, 0.9), (0.3, 1.0)], div, "1") == 2.8
+    assert rb.find_divisor([(0.1, 0.3)] * 5, div, "1") is None                   # never crosses the threshold
+    fd = np.array([303, 302, 301, 300])
+    assert rb.find_divisor([3.0, 4.0, 6.0, 7.0], fd, "2") == 302                  # first error above 5 % -> previous
+    assert rb.find_divisor([0.01, 0.02, 0.03, 0.06, 0.07], div, "3") == 2.8      # first CV above 0.05 % at i=3 -> i-1
+    x = np.array([1.0, 1.1, 0.9, 1.05, 5.0, 0.95])
+    assert 5.0 not in rb.remove_outliers_iqr(x) and len(rb.remove_outliers_iqr(x)) == 5
