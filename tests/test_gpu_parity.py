@@ -448,22 +448,27 @@ def test_device_metrics_match_reference(rb, gpu_fields):
 
 
 def test_cfg3_fisheye_1m_properties(rb, gpu_fields):
-    """cfg3: fisheye, 1 048 576 rays fp64, calibrated op6 step.  Every launch direction from (1,0) rides a circle
-    through (1,0) and (-1,0) (Maxwell fisheye); rays within |theta-pi/2| < 0.39 stay inside the +-1.5 box for all
-    ten turns and must close on (1,0) like the reference's single ray (3.04 %), the others must leave the box."""
+    """cfg3: fisheye, 1 048 576 rays fp64, calibrated op6 step.  Every launch direction theta from (1,0) rides the
+    circle through (1,0) and (-1,0) centred at (0, cot theta) (Maxwell fisheye); rays within |theta-pi/2| < 0.38
+    stay inside the +-1.5 box for all 3 039 steps and must still be on their circle, the outer ones must leave
+    the box; the central ray reproduces the reference's closure error (3.0408 %)."""
     R = 1 << 20
     th = np.linspace(np.pi / 4, 3 * np.pi / 4, R)
     step, ms = 2 * np.pi / 303, 10 * 304
     b = rb.Batch(gpu_fields("fisheye"), 6, step, ms, LIMITS["fisheye"], 1, th, 1.0, 0.0, record_stride=0)
     b.run()
-    d, st, cl = b.d_ray(), b.stats(), b.metric("closure")
+    d, st, cl, fin = b.d_ray(), b.stats(), b.metric("closure"), b.final()
     b.close()
     assert st["ray_steps"] == int(d[2].sum())
     stay = np.abs(th - np.pi / 2) < 0.38
     leave = np.abs(th - np.pi / 2) > 0.41
     assert np.all(d[2][stay] == ms - 1) and np.all(d[2][leave] < ms - 1)
     mid = R // 2
-    assert abs(cl[mid] - 3.0408) < 0.01 and cl[stay].max() < 6.0
+    assert abs(cl[mid] - 3.0408) < 0.01
+    yc = 1.0 / np.tan(th[stay])
+    radial = np.abs(np.hypot(fin[0][stay], fin[1][stay] - yc) - np.sqrt(1 + yc * yc))
+    print(f"fisheye 1M: max radial deviation from the analytic circle after 10 turns: {radial.max():.2e}")
+    assert radial.max() < 5e-3
 
 
 # ------------------------------------------------------------------ SURVEY 8f rank 2: DELTA_S calibration sweep
