@@ -130,6 +130,12 @@ int rtmi_read_rows(rtmi_batch *b, int64_t row0, int64_t nrows, double *s_ray, do
 typedef enum { RTMI_METRIC_SNELL_ERROR = 1, RTMI_METRIC_CLOSURE = 2, RTMI_METRIC_PX_CV = 3 } rtmi_metric_kind;
 int rtmi_metric(rtmi_batch *b, int kind, double *out);
 
+/* Isochrone points: per-ray PCHIP interpolation (scipy PchipInterpolator's algorithm) of x, y, theta at the given
+ * traveltimes, from the recorded T column -- the per-ray stage of the reference's wavefront extraction
+ * (RT_bench.py:987-1003).  out[ntimes][3][R], host, fp64; NaN where a ray never reaches that traveltime
+ * (the reference skips such rays, :997).  Needs record_stride 1. */
+int rtmi_isochrones(rtmi_batch *b, int32_t ntimes, const double *times, double *out);
+
 typedef struct {
     void *s_ray, *n_ray;                 /* device, dtype, layouts above */
     void *x, *y, *theta, *n, *gx, *gy;   /* device SoA ray state, dtype, length R */

@@ -226,6 +226,24 @@ def main():
                     res.append([np.mean(cvs), 0.0])
             print(f"sweep {scen}: {len(sel)} candidates {time.time() - t:.1f}s")
             save(f"sweep_{scen}_op6", dict(all_divisors=divisors, all_options=opts, sel=sel, results=np.array(res)))
+    if want("isochrones"):
+        # per-ray stage of the wavefront extraction (RT_bench.py:987-1003), with the reference's own calls
+        from scipy.interpolate import PchipInterpolator
+        for scen, m in (("vert_heterogeneous", 6), ("anisotropy", 11)):
+            if scen == "anisotropy":
+                continue   # 90 s of reference time for the same code path; vert covers it
+            d, s_ray = run_traj(R, scen, m, R.DELTA_S, 91)
+            times = np.arange(0.05, 0.6, 0.05)
+            out = np.full((len(times), 3, s_ray.shape[2]), np.nan)
+            for it, travel_time in enumerate(times):
+                for i in range(s_ray.shape[2]):
+                    n = int(d["d_ray"][2, i]) + 1
+                    t_ray = s_ray[:n, 4, i]
+                    if np.max(t_ray) >= travel_time:
+                        for q, col in enumerate((0, 1, 5)):
+                            out[it, q, i] = PchipInterpolator(t_ray, s_ray[:n, col, i])(travel_time)
+            save("isochrones_vert_op6", dict(times=times, points=out, theta=d["theta"], step=d["step"],
+                                             max_size=d["max_size"], box=d["box"]))
     if want("consts"):
         save("constants", consts)
 

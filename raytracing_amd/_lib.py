@@ -61,6 +61,7 @@ SYMBOLS = {
     "rtmi_read_final": (C.c_int, [C.c_void_p, _dp]),
     "rtmi_read_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp, _dp]),
     "rtmi_metric": (C.c_int, [C.c_void_p, C.c_int, _dp]),
+    "rtmi_isochrones": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
     "rtmi_batch_view": (C.c_int, [C.c_void_p, C.POINTER(DeviceView)]),
     "rtmi_batch_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "rtmi_batch_destroy": (None, [C.c_void_p]),

@@ -1019,6 +1019,96 @@ RTMI_EXPORT int rtmi_metric(rtmi_batch* b, int kind, double* out) {
     return RTMI_OK;
 }
 
+// ------------------------------------------------------------------ isochrones
+// Per-ray PCHIP interpolation of (x, y, theta) at fixed traveltimes -- the first stage of the reference's
+// wavefront extraction (RT_bench.py:987-1003: scipy PchipInterpolator(t_ray, v_ray) evaluated at travel_time).
+// scipy's algorithm restated: shape-preserving derivative estimates (Fritsch-Butland weighted harmonic mean,
+// three-point end formula with the two sign guards), cubic Hermite in the power basis of (t - T_j).
+namespace {
+__device__ __forceinline__ double sgn_(double v) { return (v > 0) - (v < 0); }
+__device__ __forceinline__ double pchip_edge(double h0, double h1, double m0, double m1) {
+    double d = ((2 * h0 + h1) * m0 - h0 * m1) / (h0 + h1);
+    if (sgn_(d) != sgn_(m0)) d = 0;
+    else if (sgn_(m0) != sgn_(m1) && fabs(d) > 3 * fabs(m0)) d = 3 * m0;
+    return d;
+}
+template <typename T> struct Column {   // s_ray[:, q, k]
+    const T* base; size_t pitch;
+    __device__ __forceinline__ double operator()(long row) const { return (double)base[(size_t)row * pitch]; }
+};
+// derivative estimate at point j of an n-point (n >= 3) data set
+template <typename T> __device__ __forceinline__ double pchip_deriv(const Column<T>& tt, const Column<T>& yy, long j, long n) {
+    if (j == 0) {
+        const double h0 = tt(1) - tt(0), h1 = tt(2) - tt(1);
+        return pchip_edge(h0, h1, (yy(1) - yy(0)) / h0, (yy(2) - yy(1)) / h1);
+    }
+    if (j == n - 1) {
+        const double h0 = tt(n - 1) - tt(n - 2), h1 = tt(n - 2) - tt(n - 3);
+        return pchip_edge(h0, h1, (yy(n - 1) - yy(n - 2)) / h0, (yy(n - 2) - yy(n - 3)) / h1);
+    }
+    const double ha = tt(j) - tt(j - 1), hb = tt(j + 1) - tt(j);
+    const double ma = (yy(j) - yy(j - 1)) / ha, mb = (yy(j + 1) - yy(j)) / hb;
+    if (sgn_(ma) != sgn_(mb) || ma == 0 || mb == 0) return 0;
+    const double w1 = 2 * hb + ha, w2 = hb + 2 * ha;
+    return 1.0 / ((w1 / ma + w2 / mb) / (w1 + w2));
+}
+}  // namespace
+
+template <typename T> __global__ void k_isochrone(BatchDev<T> a, int ntimes, const double* times, double* out) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.R) return;
+    const long n = a.istep[k] + 1;                      // rows 0..last_i of this ray (:993)
+    const size_t pitch = (size_t)6 * a.R;
+    const Column<T> tt{a.s_ray + (size_t)4 * a.R + k, pitch};
+    const int qsel[3] = {0, 1, 5};                      // x, y, theta (:993)
+    for (int it = 0; it < ntimes; it++) {
+        const double t = times[it];
+        double res[3] = {NAN, NAN, NAN};
+        if (n >= 2 && tt(n - 1) >= t && t >= tt(0)) {   // np.max(t_ray) >= travel_time (:997)
+            long lo = 0, hi = n - 1;                     // T[lo] <= t < T[hi] (right end closed)
+            while (hi - lo > 1) {
+                const long mid = (lo + hi) >> 1;
+                if (tt(mid) <= t) lo = mid; else hi = mid;
+            }
+            const double dx = tt(lo + 1) - tt(lo), s = t - tt(lo);
+            for (int q = 0; q < 3; q++) {
+                const Column<T> yy{a.s_ray + (size_t)qsel[q] * a.R + k, pitch};
+                const double y0 = yy(lo), y1 = yy(lo + 1), slope = (y1 - y0) / dx;
+                double d0, d1;
+                if (n == 2) { d0 = d1 = slope; }
+                else { d0 = pchip_deriv(tt, yy, lo, n); d1 = pchip_deriv(tt, yy, lo + 1, n); }
+                const double tq = (d0 + d1 - 2 * slope) / dx;           // CubicHermiteSpline coefficients
+                const double c0 = tq / dx, c1 = (slope - d0) / dx - tq;
+                res[q] = y0 + d0 * s + c1 * (s * s) + c0 * (s * s * s);
+            }
+        }
+        for (int q = 0; q < 3; q++) out[((size_t)it * 3 + q) * a.R + k] = res[q];
+    }
+}
+
+RTMI_EXPORT int rtmi_isochrones(rtmi_batch* b, int32_t ntimes, const double* times, double* out) {
+    ARG_TRY(b && times && out, "rtmi_isochrones: null");
+    ARG_TRY(ntimes > 0 && ntimes <= 4096, "rtmi_isochrones: ntimes must be in [1, 4096]");
+    ARG_TRY(b->p.record_stride == 1, "rtmi_isochrones: needs the full trajectory (record_stride 1)");
+    double *d = nullptr, *dt = nullptr;
+    const size_t nb = (size_t)ntimes * 3 * (size_t)b->R * sizeof(double);
+    HIP_TRY(hipMalloc(&d, nb));
+    hipError_t e = hipMalloc(&dt, ntimes * sizeof(double));
+    if (e == hipSuccess) e = hipMemcpyAsync(dt, times, ntimes * sizeof(double), hipMemcpyHostToDevice, b->stream);
+    if (e == hipSuccess) {
+        const dim3 g((unsigned)((b->R + 127) / 128)), blk(128);
+        if (b->p.dtype == RTMI_F64) hipLaunchKernelGGL(k_isochrone<double>, g, blk, 0, b->stream, batch_dev<double>(b), (int)ntimes, dt, d);
+        else hipLaunchKernelGGL(k_isochrone<float>, g, blk, 0, b->stream, batch_dev<float>(b), (int)ntimes, dt, d);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d, nb, hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    (void)hipFree(d);
+    (void)hipFree(dt);
+    if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_isochrones: ") + hipGetErrorString(e));
+    return RTMI_OK;
+}
+
 RTMI_EXPORT int rtmi_batch_view(rtmi_batch* b, rtmi_device_view* v) {
     ARG_TRY(b && v, "rtmi_batch_view: null");
     const size_t R = (size_t)b->R, e = b->esz;

@@ -342,6 +342,13 @@ class Batch:
         check(lib().rtmi_metric(self._h, {"snell": 1, "closure": 2, "px_cv": 3}[kind], dptr(out)))
         return out
 
+    def isochrones(self, times):
+        """(x, y, theta) of every ray at the given traveltimes -> [ntimes, 3, R], NaN where not reached."""
+        t = np.ascontiguousarray(times, dtype=np.float64)
+        out = np.empty((len(t), 3, self.R))
+        check(lib().rtmi_isochrones(self._h, len(t), dptr(t), dptr(out)))
+        return out
+
     def stats(self):
         s = Stats()
         check(lib().rtmi_batch_stats(self._h, C.byref(s)))

@@ -491,3 +491,80 @@ def test_delta_s_sweep_vs_reference(scen, rb, gpu_fields):
     pick = rb.find_divisor(res, div[sel], choice)
     ref_pick = rb.find_divisor([tuple(r) for r in ref] if scen == "interface" else list(ref[:, 0]), div[sel], choice)
     assert pick == ref_pick
+
+
+# ------------------------------------------------------------------ isochrone points
+def test_isochrones_vs_scipy_pchip(rb, gpu_fields):
+    """rtmi_isochrones (device PCHIP per ray) against scipy's PchipInterpolator applied to the reference's own
+    trajectories exactly as RT_bench.py:987-1003 does (fixture isochrones_vert_op6)."""
+    g = golden("isochrones_vert_op6")
+    b = rb.Batch(gpu_fields("vert_heterogeneous"), 6, float(g["step"]), int(g["max_size"]), g["box"], 1, g["theta"], -2.0,
+                 -2.0, record_stride=1)
+    b.run()
+    pts = b.isochrones(g["times"])
+    b.close()
+    ref = g["points"]
+    assert pts.shape == ref.shape == (11, 3, 31)
+    assert np.array_equal(np.isnan(pts), np.isnan(ref))          # same rays reach each traveltime
+    ok = ~np.isnan(ref)
+    assert ok.sum() > 300 and np.abs(pts[ok] - ref[ok]).max() < 1e-10
+    # rays are perpendicular to wavefronts in an isotropic medium (:1016-1039): check one isochrone's tangent
+    it = 3
+    sel = ~np.isnan(pts[it, 0])
+    x, y, th = pts[it, 0, sel], pts[it, 1, sel], pts[it, 2, sel]
+    tx, ty = np.gradient(x), np.gradient(y)                       # wavefront tangent along the ray index
+    cosang = (tx * np.cos(th) + ty * np.sin(th)) / np.hypot(tx, ty)
+    assert np.abs(cosang[2:-2]).max() < 0.02
+
+
+# ------------------------------------------------------------------ remaining BASELINE configs, per-GPU shard sizes
+def test_cfg5_anisotropy_shard_properties(rb, gpu_fields, oracle_fields):
+    """cfg5 shard (anisotropy gamma=3, op11, 131 072 rays = 1/8 of 1 048 576): the horizontal momentum p_x is the
+    ray parameter of a vertically heterogeneous medium and must be conserved (reference metric, :1354-1360);
+    a 1/1024 subsample is compared with the oracle."""
+    from oracle import rt_oracle as O
+    R = 131072
+    th = np.linspace(0, np.pi / 2, R)
+    lim = LIMITS["anisotropy"]
+    ms = int(np.ceil(80 / rb.DELTA_S) + 1)
+    b = rb.Batch(gpu_fields("anisotropy"), 11, rb.DELTA_S, ms, lim, 3, th, -2.0, -2.0, record_stride=0)
+    b.run()
+    d, fin, st = b.d_ray(), b.final(), b.stats()
+    b.close()
+    assert st["ray_steps"] == int(d[2].sum()) and 1100 <= d[2].min() and d[2].max() <= 2900
+    n0 = 0.07142864686293911
+    coef0 = np.sqrt((3 * np.sin(th)) ** 2 + np.cos(th) ** 2)
+    px0 = n0 * coef0 * np.cos(th) * (1 + (-np.sin(th) ** 2) * 8 / coef0 ** 2)
+    keep = slice(1, R - R // 64)                                  # p_x -> 0 towards theta = pi/2
+    assert np.max(np.abs(fin[6][keep] - px0[keep]) / np.abs(px0[keep])) < 2e-3
+    sub = slice(0, R, 1024)
+    o = O.trazar(oracle_fields("anisotropy"), 11, 3, rb.DELTA_S, ms, lim, -2.0, -2.0, th[sub], record_stride=0, nthreads=8)
+    same = d[2][sub] == o["d_ray"][2]
+    per_ray = np.max(np.abs(fin[:, sub] - o["final"]) / np.maximum(np.abs(o["final"]), 1.0), axis=0)
+    print(f"cfg5 subsample: {np.mean(same & (per_ray < REL)):.3f} of rays within 1e-9, worst {per_ray.max():.2e}")
+    assert np.mean(same & (per_ray < REL)) >= 0.9
+
+
+def test_cfg4_fp32_shard_properties(rb, gpu_fields):
+    """cfg4 shard (vert_heterogeneous, fp32 state + field, 1 048 576 rays = 1/8 of 8 388 608).  The reference is
+    fp64-only; measured against this library's fp64 path on a 1/64 subsample: same step counts within +-3,
+    end points within 2e-2, p_x conserved to 1e-3."""
+    R = 1 << 20
+    th = np.linspace(0, np.pi / 2, R)
+    lim = LIMITS["vert_heterogeneous"]
+    ms = int(np.ceil(80 / rb.DELTA_S) + 1)
+    b = rb.Batch(gpu_fields("vert_heterogeneous", 1), 6, rb.DELTA_S, ms, lim, 1, th, -2.0, -2.0, record_stride=0)
+    b.run()
+    d32, f32 = b.d_ray(), b.final()
+    b.close()
+    sub = slice(0, R, 64)
+    a = rb.Batch(gpu_fields("vert_heterogeneous", 0), 6, rb.DELTA_S, ms, lim, 1, th[sub], -2.0, -2.0, record_stride=0)
+    a.run()
+    d64, f64 = a.d_ray(), a.final()
+    a.close()
+    assert np.max(np.abs(d32[2][sub] - d64[2])) <= 3
+    err = np.abs(f32[:2, sub] - f64[:2]).max()
+    print(f"cfg4 fp32 vs fp64 end points: {err:.2e}")
+    assert err < 2e-2
+    px0 = 0.07142864686293911 * np.cos(th)
+    assert np.max(np.abs(f32[6] - px0)[1:-1000] / px0[1:-1000]) < 1e-3
