@@ -535,8 +535,7 @@ def test_cfg5_anisotropy_shard_properties(rb, gpu_fields, oracle_fields):
     n0 = 0.07142864686293911
     coef0 = np.sqrt((3 * np.sin(th)) ** 2 + np.cos(th) ** 2)
     px0 = n0 * coef0 * np.cos(th) * (1 + (-np.sin(th) ** 2) * 8 / coef0 ** 2)
-    keep = slice(1, R - R // 64)                                  # p_x -> 0 towards theta = pi/2
-    assert np.max(np.abs(fin[6][keep] - px0[keep]) / np.abs(px0[keep])) < 2e-3
+    assert np.max(np.abs(fin[6] - px0)) / n0 < 5e-4               # drift relative to p_x's scale (p_x -> 0 at pi/2)
     sub = slice(0, R, 1024)
     o = O.trazar(oracle_fields("anisotropy"), 11, 3, rb.DELTA_S, ms, lim, -2.0, -2.0, th[sub], record_stride=0, nthreads=8)
     same = d[2][sub] == o["d_ray"][2]
@@ -566,5 +565,5 @@ def test_cfg4_fp32_shard_properties(rb, gpu_fields):
     err = np.abs(f32[:2, sub] - f64[:2]).max()
     print(f"cfg4 fp32 vs fp64 end points: {err:.2e}")
     assert err < 2e-2
-    px0 = 0.07142864686293911 * np.cos(th)
-    assert np.max(np.abs(f32[6] - px0)[1:-1000] / px0[1:-1000]) < 1e-3
+    n0 = 0.07142864686293911
+    assert np.max(np.abs(f32[6] - n0 * np.cos(th))) / n0 < 1e-3
