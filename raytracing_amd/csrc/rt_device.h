@@ -46,7 +46,19 @@ __device__ __forceinline__ void sincos_k(double x, double* sp, double* cp) {
 // ---------------------------------------------------------------- math traits
 template <typename T> struct M;
 template <> struct M<double> {
-    static __device__ __forceinline__ double sqrt_(double x) { return __dsqrt_rn(x); }
+    // sqrt for arguments in the normal range (squared step lengths ~1e-5, s^2+c^2 ~ 1): the hardware rsq estimate
+    // with one coupled Newton step and two residual corrections -- the compiler's own correctly-rounded
+    // sequence without its subnormal rescaling and class checks (6 instructions fewer per call).
+    static __device__ __forceinline__ double sqrt_(double x) {
+        const double y = __builtin_amdgcn_rsq(x);
+        double g = x * y, h = 0.5 * y;
+        const double r = fma_(-h, g, 0.5);
+        g = fma_(g, r, g);
+        h = fma_(h, r, h);
+        g = fma_(fma_(-g, g, x), h, g);
+        return fma_(fma_(-g, g, x), h, g);
+    }
+    static __device__ __forceinline__ double sqrt_full(double x) { return __dsqrt_rn(x); }
     static __device__ __forceinline__ void sincos_(double x, double* s, double* c) { sincos_k(x, s, c); }
     static __device__ __forceinline__ double atan2_(double y, double x) { return ::atan2(y, x); }
     static __device__ __forceinline__ double abs_(double x) { return __builtin_fabs(x); }
@@ -59,6 +71,7 @@ template <> struct M<double> {
 };
 template <> struct M<float> {
     static __device__ __forceinline__ float sqrt_(float x) { return __fsqrt_rn(x); }
+    static __device__ __forceinline__ float sqrt_full(float x) { return __fsqrt_rn(x); }
     static __device__ __forceinline__ void sincos_(float x, float* s, float* c) { ::sincosf(x, s, c); }
     static __device__ __forceinline__ float atan2_(float y, float x) { return ::atan2f(y, x); }
     static __device__ __forceinline__ float abs_(float x) { return __builtin_fabsf(x); }
@@ -446,7 +459,7 @@ template <typename T> __device__ __forceinline__ void adv_second(const Ray<T>& r
 template <typename T> __device__ __forceinline__ bool adv_curv(const Ray<T>& r, const Consts<T>& k, T& fx, T& fy) {
     const T d = fma_(r.gy, r.uy, r.gx * r.ux);
     const T vx = fma_(-d, r.ux, r.gx), vy = fma_(-d, r.uy, r.gy);
-    const T curv = M<T>::sqrt_(fma_(vy, vy, vx * vx)) * r.rn;
+    const T curv = M<T>::sqrt_full(fma_(vy, vy, vx * vx)) * r.rn;   // may be exactly 0: full-range sqrt
     if (curv < T(1.4901161193847656e-08)) {  // GOLD_TOL (:355), same constant in both precisions
         adv_first(r, k.step, fx, fy);
         return false;
