@@ -102,6 +102,11 @@ def main():
     ap.add_argument("--rec-rows", type=int, default=0, help="rows to allocate (0 = from max_size; full: 3072 for vert)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse the "
+                         "multi-rank path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--all-on-device", type=int, default=None,
+                    help="rehearsal only: every rank uses this HIP device instead of LOCAL_RANK")
     args = ap.parse_args()
     if args.method is None:
         args.method = 11 if args.scenario == "anisotropy" else 6
@@ -115,11 +120,17 @@ def main():
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
     if not torch.cuda.is_available():
         sys.exit("bench.py: no HIP device (raytracing_amd has no CPU path)")
+    if args.all_on_device is not None:
+        local = args.all_on_device
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")     # where the collectives' tensors live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from raytracing_amd import rt_bench as rb
     from raytracing_amd import _lib
@@ -139,10 +150,22 @@ def main():
     if args.order == "shuffled":
         th = np.random.default_rng(1234 + rank).permutation(th)
     fld = rb.Field.build(args.scenario, lim, rb.DELTA, dtype)
-    batch = rb.Batch(fld, args.method, step, max_size, lim, sc["gamma"], th, sc["start"][0], sc["start"][1],
-                     record_stride=stride, rec_rows=rec_rows, block_size=args.block,
-                     launch_mode=1 if args.mode == "refill" else 0, refill_min=args.refill_min,
-                     field_path=0 if args.field_path == "lds" else 1)
+    def make_batch(stride_, rec_rows_):
+        return rb.Batch(fld, args.method, step, max_size, lim, sc["gamma"], th, sc["start"][0], sc["start"][1],
+                        record_stride=stride_, rec_rows=rec_rows_, block_size=args.block,
+                        launch_mode=1 if args.mode == "refill" else 0, refill_min=args.refill_min,
+                        field_path=0 if args.field_path == "lds" else 1)
+
+    try:
+        batch = make_batch(stride, rec_rows)
+    except _lib.RtmiError as e:
+        if stride != 1:
+            raise
+        # the full trajectory (176 GB at 1 M rays) did not fit this device: keep every 16th row instead
+        print(f"bench.py: full trajectory record failed ({e}); falling back to record=stride:16", file=sys.stderr)
+        args.record, stride = "stride:16", 16
+        rec_rows = (rec_rows + 15) // 16 if rec_rows else 0
+        batch = make_batch(stride, rec_rows)
 
     def barrier():
         torch.cuda.synchronize()
@@ -166,10 +189,10 @@ def main():
     steps_per_pass = st["ray_steps"]
     kern_ms = st["kernel_ms"] / max(st["launches"], 1)
     if world > 1:
-        dt = rd.max_over_ranks(dt, dev)
-        total_steps = rd.sum_over_ranks(steps_per_pass, dev) * args.steps
-        # read-back rehearsal of the sharded layout: d_ray gathered to rank 0 over RCCL (outside the timed region)
-        d_local = torch.as_tensor(batch.d_ray(), device=dev)
+        dt = rd.max_over_ranks(dt, cdev)
+        total_steps = rd.sum_over_ranks(steps_per_pass, cdev) * args.steps
+        # read-back of the sharded layout: d_ray gathered to rank 0 over RCCL (outside the timed region)
+        d_local = torch.as_tensor(batch.d_ray(), device=cdev)
         g = [torch.empty_like(d_local) for _ in range(world)] if rank == 0 else None
         dist.gather(d_local, g, dst=0)
         if rank == 0:
