@@ -398,6 +398,10 @@ template <typename T> struct LdsGather {
             read_tile(cx, cy, z, g);
         } else {
             gather_global(F, c, z, g);            // this lane's window is outside the tile (or at a grid end)
+            // Retire these loads here.  Otherwise the compiler, which shares the ds_read block between this
+            // mixed case and the all-lanes-fit case, guards the LDS reads with vmcnt waits -- and vmcnt also
+            // counts the trajectory stores of the previous step, so every step would wait for HBM writes.
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
         }
     }
 };
