@@ -359,6 +359,29 @@ class Batch:
         check(lib().rtmi_batch_view(self._h, C.byref(v)))
         return v
 
+    def device_tensors(self):
+        """Zero-copy torch views of the batch's device memory (rtmi_batch_view through
+        __cuda_array_interface__): SoA state [R], istep [R], s_ray [rec_rows, 6, R], n_ray [rec_rows, R].
+        For consumers that stay on the GPU or feed torch.distributed (RCCL) collectives; the tensors alias
+        library memory and die with the batch."""
+        import torch
+        v = self.view()
+        ts = "<f8" if v.dtype == F64 else "<f4"
+
+        class _Cai:
+            def __init__(self, ptr, shape, typestr):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False),
+                                                 "version": 2, "strides": None}
+        dev = torch.device("cuda", torch.cuda.current_device())
+        out = {name: torch.as_tensor(_Cai(getattr(v, name), (self.R,), ts), device=dev)
+               for name in ("x", "y", "theta", "n", "gx", "gy", "dist_sim", "dist_real", "T")}
+        out["istep"] = torch.as_tensor(_Cai(v.istep, (self.R,), "<i4"), device=dev)
+        if v.s_ray:
+            out["s_ray"] = torch.as_tensor(_Cai(v.s_ray, (int(v.rec_rows), 6, self.R), ts), device=dev)
+        if v.n_ray:
+            out["n_ray"] = torch.as_tensor(_Cai(v.n_ray, (int(v.rec_rows), self.R), ts), device=dev)
+        return out
+
     def close(self):
         if self._h:
             lib().rtmi_batch_destroy(self._h)

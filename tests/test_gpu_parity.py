@@ -567,3 +567,22 @@ def test_cfg4_fp32_shard_properties(rb, gpu_fields):
     assert err < 2e-2
     n0 = 0.07142864686293911
     assert np.max(np.abs(f32[6] - n0 * np.cos(th))) / n0 < 1e-3
+
+
+def test_device_tensor_views_alias_library_memory(rb, gpu_fields):
+    """Batch.device_tensors(): zero-copy torch views (rtmi_batch_view) used for RCCL read-back."""
+    import torch
+    th = np.linspace(0, np.pi / 2, 777)
+    b = rb.Batch(gpu_fields("vert_heterogeneous"), 6, rb.DELTA_S, 30228, LIMITS["vert_heterogeneous"], 1, th, -2.0, -2.0,
+                 record_stride=32)
+    b.run()
+    t = b.device_tensors()
+    fin, d = b.final(), b.d_ray()
+    assert t["x"].is_cuda and t["s_ray"].shape == (b.rec_rows, 6, 777)
+    assert np.array_equal(t["x"].cpu().numpy(), fin[0]) and np.array_equal(t["T"].cpu().numpy(), fin[8])
+    assert np.array_equal(t["istep"].cpu().numpy(), d[2].astype(np.int32))
+    s, n = b.rows(want_n_ray=True)
+    assert np.array_equal(t["s_ray"].cpu().numpy(), s) and np.array_equal(t["n_ray"].cpu().numpy(), n)
+    assert int(t["istep"].sum().item()) == b.stats()["ray_steps"]      # reductions can stay on the device
+    del t
+    b.close()
