@@ -43,6 +43,27 @@ __device__ __forceinline__ void sincos_k(double x, double* sp, double* cp) {
     *cp = ((q + 1) & 2) ? -cc : cc;
 }
 
+// fp32 sincos: the reduction by pi/2 is done in fp64 (one fma, exact enough for any |x| < 2^30), the minimax
+// kernels on [-pi/4, pi/4] in fp32; ~1 ulp.  The reference has no fp32 path, so this defines it.
+__device__ __forceinline__ void sincos_kf(float x, float* sp, float* cp) {
+    const float n = __builtin_rintf(x * 6.3661977237e-01f);
+    float r = (float)fma_(-(double)n, 1.57079632679489655800e+00, (double)x);
+    r = __builtin_fabsf(x) < 1073741824.0f ? r : __builtin_nanf("");
+    const float z = r * r;
+    float ps = fma_(z, 2.7557314297e-06f, -1.9841270114e-04f);
+    ps = fma_(z, ps, 8.3333337680e-03f);
+    ps = fma_(z, ps, -1.6666667163e-01f);
+    const float s = fma_(z * r, ps, r);
+    float pc = fma_(z, -2.7557314297e-07f, 2.4801587642e-05f);
+    pc = fma_(z, pc, -1.3888889225e-03f);
+    pc = fma_(z, pc, 4.1666667908e-02f);
+    const float c = fma_(z * z, pc, fma_(-0.5f, z, 1.0f));
+    const int q = (int)n;
+    const float ss = (q & 1) ? c : s, cc = (q & 1) ? s : c;
+    *sp = (q & 2) ? -ss : ss;
+    *cp = ((q + 1) & 2) ? -cc : cc;
+}
+
 // ---------------------------------------------------------------- math traits
 template <typename T> struct M;
 template <> struct M<double> {
@@ -70,9 +91,10 @@ template <> struct M<double> {
     static constexpr double small_angle = 0.015625;             // 2^-6: sincos_add's series bound
 };
 template <> struct M<float> {
-    static __device__ __forceinline__ float sqrt_(float x) { return __fsqrt_rn(x); }
-    static __device__ __forceinline__ float sqrt_full(float x) { return __fsqrt_rn(x); }
-    static __device__ __forceinline__ void sincos_(float x, float* s, float* c) { ::sincosf(x, s, c); }
+    // fp32 is the reduced-precision path (no reference to match bit for bit): hardware sqrt/rcp (1 ulp)
+    static __device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
+    static __device__ __forceinline__ float sqrt_full(float x) { return __builtin_amdgcn_sqrtf(x); }
+    static __device__ __forceinline__ void sincos_(float x, float* s, float* c) { sincos_kf(x, s, c); }
     static __device__ __forceinline__ float atan2_(float y, float x) { return ::atan2f(y, x); }
     static __device__ __forceinline__ float abs_(float x) { return __builtin_fabsf(x); }
     static __device__ __forceinline__ float max_(float x, float y) { return __builtin_fmaxf(x, y); }
@@ -157,7 +179,7 @@ __device__ __forceinline__ double rcp_full(double d) {
     r = fma_(r, fma_(-d, r, 1.0), r);
     return fma_(r, fma_(-d, r, 1.0), r);
 }
-__device__ __forceinline__ float rcp_full(float d) { return 1.0f / d; }
+__device__ __forceinline__ float rcp_full(float d) { return __builtin_amdgcn_rcpf(d); }
 
 // General form of one axis of n_gradient's basis (any cell, FITPACK's arithmetic with true knots): cell j (from
 // locate, with t0 = x[j], t1 = x[j+1]) -> the two linear weights (fpbspl k=1 on [t0, t1]) and the four cubic

@@ -586,3 +586,26 @@ def test_device_tensor_views_alias_library_memory(rb, gpu_fields):
     assert int(t["istep"].sum().item()) == b.stats()["ray_steps"]      # reductions can stay on the device
     del t
     b.close()
+
+
+def test_bad_launch_conditions_do_not_disturb_neighbours(rb, gpu_fields):
+    """NaN / infinite launch angles and positions far outside the grid: those rays produce NaN or clamped-field
+    rows and stop at max_size, every other ray of the batch is bit-identical to a clean batch, nothing hangs."""
+    F = gpu_fields("vert_heterogeneous")
+    lim = LIMITS["vert_heterogeneous"]
+    th = np.array([0.3, np.nan, np.inf, 0.5, 0.7, 1e12, 0.9])
+    x0 = np.array([-2.0, -2.0, -2.0, -2.0, 1e6, -2.0, np.nan])
+    for mode, path in ((0, 0), (0, 1), (1, 0)):
+        b = rb.Batch(F, 6, rb.DELTA_S, 600, lim, 1, th, x0, -2.0, record_stride=1, launch_mode=mode, field_path=path)
+        b.run()
+        d, fin, rows = b.d_ray(), b.final(), b.rows()
+        b.close()
+        c = rb.Batch(F, 6, rb.DELTA_S, 600, lim, 1, th[[0, 3]], -2.0, -2.0, record_stride=1)
+        c.run()
+        assert np.array_equal(fin[:, [0, 3]], c.final()) and np.array_equal(rows[:, :, [0, 3]], c.rows())
+        c.close()
+        assert d[2, 1] == 599 and d[2, 2] == 599 and np.isnan(fin[0, 1])      # never "outside": NaN compares false
+        assert d[2, 4] == 1                                                    # launched far outside: one step, stored (Q7)
+    from raytracing_amd._lib import RtmiError
+    with pytest.raises(RtmiError, match="R must be"):
+        rb.Batch(F, 6, rb.DELTA_S, 600, lim, 1, np.array([]), -2.0, -2.0)      # empty batch: rejected, not launched
