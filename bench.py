@@ -27,6 +27,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X vector fp64 (half the 157.3 TF fp32 vector peak of MI355X_MICROARCH.md)
+# fp64 flops per ray-step, from rocprofv3 SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 per wave-step of the op6 kernel
+# (profiles/r01_d_final_pmc_summary.txt: 100 fma + 68 mul + 24 add wave-instructions per 64-ray wave-step)
+FLOPS_PER_RAY_STEP = {(6, "f64"): 2 * 100 + 68 + 24}
 SCEN = {"vert_heterogeneous": dict(choice="3", theta=(0.0, np.pi / 2), start=(-2.0, -2.0), gamma=1),
         "anisotropy": dict(choice="4", theta=(0.0, np.pi / 2), start=(-2.0, -2.0), gamma=3),
         "interface": dict(choice="1", theta=(2 * np.pi / 60, np.pi / 2), start=(-2.0, -2.0), gamma=1),
@@ -232,6 +236,11 @@ def main():
                          "kernel": "k_trace_refill" if args.mode == "refill" else "k_advance", "kernel_ms": kern_ms, "alg_bytes_per_ray_step": balg,
                          "ray_steps_per_launch": int(steps_per_pass), "vgprs": st["vgprs"]},
         }
+        fl = FLOPS_PER_RAY_STEP.get((args.method, args.dtype))
+        if fl:   # what actually limits the kernel: the fp64 vector ALU (reported beside the contract's HBM line)
+            tf = fl * steps_per_pass / (kern_ms * 1e-3) / 1e12
+            out["roofline"]["valu_fp64"] = {"achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "flops_per_ray_step": fl}
         prof = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(prof):
             try:
