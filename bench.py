@@ -101,6 +101,7 @@ def main():
     ap.add_argument("--order", default="fan", choices=["fan", "shuffled"],
                     help="ray order inside the batch: the sorted fan, or a seeded random permutation of it")
     ap.add_argument("--refill-min", type=int, default=0)
+    ap.add_argument("--sort", action="store_true", help="sort rays inside the batch by launch cell and angle (sort_rays)")
     ap.add_argument("--field-path", default="lds", choices=["lds", "global"],
                     help="lds: wave-private LDS tile of the field (default); global: every lookup gathers from L2/HBM")
     ap.add_argument("--rec-rows", type=int, default=0, help="rows to allocate (0 = from max_size; full: 3072 for vert)")
@@ -158,7 +159,7 @@ def main():
         return rb.Batch(fld, args.method, step, max_size, lim, sc["gamma"], th, sc["start"][0], sc["start"][1],
                         record_stride=stride_, rec_rows=rec_rows_, block_size=args.block,
                         launch_mode=1 if args.mode == "refill" else 0, refill_min=args.refill_min,
-                        field_path=0 if args.field_path == "lds" else 1)
+                        field_path=0 if args.field_path == "lds" else 1, sort_rays=args.sort)
 
     try:
         batch = make_batch(stride, rec_rows)
@@ -230,7 +231,7 @@ def main():
                                    f"box={tuple(float(v) for v in lim)}, record={args.record}",
                        "rays_per_gpu": args.rays, "ray_steps_per_pass_rank0": int(steps_per_pass),
                        "method": f"op{args.method}", "record": args.record, "launch_mode": args.mode,
-                       "ray_order": args.order, "field_path": args.field_path, "parallelism": f"ray-shard x{world}"},
+                       "ray_order": args.order, "sort_rays": bool(args.sort), "field_path": args.field_path, "parallelism": f"ray-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_trace_refill" if args.mode == "refill" else "k_advance", "kernel_ms": kern_ms, "alg_bytes_per_ray_step": balg,

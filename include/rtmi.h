@@ -89,7 +89,8 @@ typedef struct {
     int32_t exact_basis;     /* 0: uniform-knot cubic basis in interior cells (<= 4e-14 from FITPACK's weights);
                                 1: FITPACK's fpbspl arithmetic on the true knots in every cell (slower) */
     int32_t field_path;      /* 0: wave-private LDS tile of the field (default); 1: every lookup gathers from global memory */
-    int32_t reserved0;
+    int32_t sort_rays;       /* 1: reorder rays inside the batch by launch cell block and angle so that lanes of a wave stay
+                                coherent; every read call still answers in the caller's ray order (see rtmi_device_view.perm) */
     /* optional caller-owned DEVICE buffers (e.g. torch tensors); NULL -> the library allocates */
     void *ext_s_ray;         /* [rec_rows][6][R] of dtype: x, y, p_x, p_y, T, theta (:802, :871-875) */
     void *ext_n_ray;         /* [rec_rows][R]   of dtype: coef*n (:803, :873) */
@@ -141,6 +142,8 @@ typedef struct {
     void *x, *y, *theta, *n, *gx, *gy;   /* device SoA ray state, dtype, length R */
     void *dist_sim, *dist_real, *T;
     int32_t *istep;                      /* device, last written row per ray */
+    const int32_t *perm;                 /* device [R] or NULL: with sort_rays, slot k of every array above holds the
+                                            caller's ray perm[k] */
     int64_t R, rec_rows;
     int32_t dtype, record_stride;
 } rtmi_device_view;

@@ -21,7 +21,7 @@ class Params(C.Structure):
                 ("step", C.c_double), ("max_size", C.c_int32), ("record_stride", C.c_int32), ("rec_rows", C.c_int64),
                 ("box", C.c_double * 4), ("launch_mode", C.c_int32), ("block_size", C.c_int32),
                 ("refill_min", C.c_int32), ("exact_basis", C.c_int32),
-                ("field_path", C.c_int32), ("reserved0", C.c_int32),
+                ("field_path", C.c_int32), ("sort_rays", C.c_int32),
                 ("ext_s_ray", C.c_void_p), ("ext_n_ray", C.c_void_p)]
 
 
@@ -29,6 +29,7 @@ class DeviceView(C.Structure):
     _fields_ = [("s_ray", C.c_void_p), ("n_ray", C.c_void_p), ("x", C.c_void_p), ("y", C.c_void_p),
                 ("theta", C.c_void_p), ("n", C.c_void_p), ("gx", C.c_void_p), ("gy", C.c_void_p),
                 ("dist_sim", C.c_void_p), ("dist_real", C.c_void_p), ("T", C.c_void_p), ("istep", C.c_void_p),
+                ("perm", C.c_void_p),
                 ("R", C.c_int64), ("rec_rows", C.c_int64), ("dtype", C.c_int32), ("record_stride", C.c_int32)]
 
 

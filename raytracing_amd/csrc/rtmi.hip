@@ -5,7 +5,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
+#include <numeric>
 #include <new>
 #include <string>
 #include <vector>
@@ -365,7 +367,8 @@ template <typename T> struct BatchDev {
     unsigned char* alive;
     T *s_ray, *n_ray;
     unsigned long long* counters;  // [0] ray-steps, [1] live rays (recomputed per launch), [2] refill queue head
-    const double *x0, *y0, *th0;   // launch conditions (device, fp64)
+    const double *x0, *y0, *th0;   // launch conditions (device, fp64), in slot order
+    const int* perm;               // sort_rays: slot k holds caller's ray perm[k] (nullptr: identity)
 };
 
 template <typename T> __device__ __forceinline__ void write_row(const BatchDev<T>& a, long row, long k, const rt::Ray<T>& r) {
@@ -556,10 +559,14 @@ __global__ __launch_bounds__(256, 2) void k_trace_refill(BatchDev<T> a, int refi
     if (lane == 0 && done) atomicAdd(&a.counters[0], (unsigned long long)done);
 }
 
+// index of slot k's ray in the caller's order
+template <typename T> __device__ __forceinline__ long out_index(const BatchDev<T>& a, long k) { return a.perm ? (long)a.perm[k] : k; }
+
 template <typename T> __global__ void k_pack_d_ray(BatchDev<T> a, double* out) {
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.R) return;
-    out[k] = (double)a.dreal[k]; out[a.R + k] = (double)a.dsim[k]; out[2 * a.R + k] = (double)a.istep[k];  // :888-890
+    const long o = out_index(a, k);
+    out[o] = (double)a.dreal[k]; out[a.R + o] = (double)a.dsim[k]; out[2 * a.R + o] = (double)a.istep[k];  // :888-890
 }
 template <typename T> __global__ void k_pack_final(BatchDev<T> a, double* out) {
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -569,8 +576,9 @@ template <typename T> __global__ void k_pack_final(BatchDev<T> a, double* out) {
     rt::derive<T, false>(a.K, r);
     const double v[9] = {(double)r.x, (double)r.y, (double)r.th, (double)r.n, (double)r.gx, (double)r.gy,
                          (double)r.mx, (double)r.my, (double)r.tt};
+    const long o = out_index(a, k);
 #pragma unroll
-    for (int q = 0; q < 9; q++) out[(size_t)q * a.R + k] = v[q];
+    for (int q = 0; q < 9; q++) out[(size_t)q * a.R + o] = v[q];
 }
 __global__ void k_f32_to_f64(const float* in, double* out, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -588,7 +596,8 @@ struct rtmi_batch {
     unsigned char* alive = nullptr;
     void *s_ray = nullptr, *n_ray = nullptr;
     bool own_s = false, own_n = false;
-    double* launch = nullptr;    // [3][R] x0, y0, theta0
+    double* launch = nullptr;    // [3][R] x0, y0, theta0 (slot order)
+    int* perm = nullptr;         // device [R] when sort_rays
     unsigned long long* counters = nullptr;  // device [2]
     unsigned long long* h_counters = nullptr;  // pinned host [2]
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -620,6 +629,7 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     a.s_ray = (T*)b->s_ray; a.n_ray = (T*)b->n_ray;
     a.counters = b->counters;
     a.x0 = b->launch; a.y0 = b->launch + R; a.th0 = b->launch + 2 * R;
+    a.perm = b->perm;
     return a;
 }
 
@@ -674,6 +684,7 @@ RTMI_EXPORT void rtmi_batch_destroy(rtmi_batch* b) {
     if (!b) return;
     (void)hipStreamSynchronize(b->stream);
     (void)hipFree(b->state); (void)hipFree(b->istep); (void)hipFree(b->alive); (void)hipFree(b->launch);
+    (void)hipFree(b->perm);
     (void)hipFree(b->counters);
     if (b->h_counters) (void)hipHostFree(b->h_counters);
     if (b->own_s) (void)hipFree(b->s_ray);
@@ -698,6 +709,7 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     ARG_TRY(p->refill_min >= 0 && p->refill_min <= 64, "rtmi_batch_create: refill_min must be in [0, 64]");
     ARG_TRY(p->exact_basis == 0 || p->exact_basis == 1, "rtmi_batch_create: exact_basis must be 0 or 1");
     ARG_TRY(p->field_path == 0 || p->field_path == 1, "rtmi_batch_create: field_path must be 0 (LDS tile) or 1 (global)");
+    ARG_TRY(p->sort_rays == 0 || p->sort_rays == 1, "rtmi_batch_create: sort_rays must be 0 or 1");
     rtmi_batch* b = new (std::nothrow) rtmi_batch();
     if (!b) return fail(RTMI_ERR_ALLOC, "rtmi_batch_create: host allocation failed");
     b->field = f; b->p = *p; b->R = R; b->esz = p->dtype == RTMI_F64 ? 8 : 4; b->stream = (hipStream_t)stream;
@@ -720,9 +732,40 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
             if (p->ext_n_ray) b->n_ray = p->ext_n_ray;
             else { HIP_TRY(hipMalloc(&b->n_ray, (size_t)b->p.rec_rows * Rz * b->esz)); b->own_n = true; }
         }
-        HIP_TRY(hipMemcpyAsync(b->launch, x0, Rz * 8, hipMemcpyHostToDevice, b->stream));
-        HIP_TRY(hipMemcpyAsync(b->launch + Rz, y0, Rz * 8, hipMemcpyHostToDevice, b->stream));
-        HIP_TRY(hipMemcpyAsync(b->launch + 2 * Rz, theta0, Rz * 8, hipMemcpyHostToDevice, b->stream));
+        std::vector<double> sorted;   // keeps the permuted launch conditions alive until the copies are done
+        if (p->sort_rays) {
+            // Coherence sort: rays that start in the same 16x16-cell block of the grid and leave in neighbouring
+            // directions become neighbouring lanes, so a wave's lookups share cache lines / one LDS tile.
+            std::vector<int> perm(Rz);
+            std::iota(perm.begin(), perm.end(), 0);
+            const double ibx = 1.0 / (16.0 * f->hx), iby = 1.0 / (16.0 * f->hy);
+            auto block = [&](int k) {
+                const double u = (x0[k] - f->ax) * ibx, v = (y0[k] - f->ay) * iby;
+                const long bu = u >= 0 && u < 65535 ? (long)u : (u < 0 ? -1 : 65535);      // NaN -> 65535 (sorted last)
+                const long bv = v >= 0 && v < 65535 ? (long)v : (v < 0 ? -1 : 65535);
+                return bv * 65537 + bu;
+            };
+            std::vector<long> key(Rz);
+            for (size_t k = 0; k < Rz; k++) key[k] = block((int)k);
+            std::stable_sort(perm.begin(), perm.end(), [&](int i, int j) {
+                if (key[i] != key[j]) return key[i] < key[j];
+                const double a = theta0[i], c = theta0[j];
+                if (a == a && c == c) return a < c;
+                return a == a && c != c;       // NaNs last
+            });
+            sorted.resize(3 * Rz);
+            for (size_t k = 0; k < Rz; k++) {
+                sorted[k] = x0[perm[k]]; sorted[Rz + k] = y0[perm[k]]; sorted[2 * Rz + k] = theta0[perm[k]];
+            }
+            HIP_TRY(hipMalloc(&b->perm, Rz * sizeof(int)));
+            HIP_TRY(hipMemcpyAsync(b->perm, perm.data(), Rz * sizeof(int), hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->launch, sorted.data(), 3 * Rz * 8, hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipStreamSynchronize(b->stream));   // perm (local) must outlive the copy
+        } else {
+            HIP_TRY(hipMemcpyAsync(b->launch, x0, Rz * 8, hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->launch + Rz, y0, Rz * 8, hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->launch + 2 * Rz, theta0, Rz * 8, hipMemcpyHostToDevice, b->stream));
+        }
         HIP_TRY(hipStreamSynchronize(b->stream));  // caller's host buffers may go away
         b->kfn = pick_advance(b);
         b->kfn_refill = pick_refill(b);
@@ -748,11 +791,12 @@ template <typename T> __global__ void k_set_state(BatchDev<T> a, const double* s
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.R) return;
     T* dst[9] = {a.x, a.y, a.th, a.n, a.gx, a.gy, a.dsim, a.dreal, a.tt};
+    const long o = out_index(a, k);
 #pragma unroll
-    for (int q = 0; q < 9; q++) dst[q][k] = (T)st[(size_t)q * a.R + k];
+    for (int q = 0; q < 9; q++) dst[q][k] = (T)st[(size_t)q * a.R + o];
     if (a.hist && hist)
-        for (int q = 0; q < 4; q++) a.hist[(size_t)q * a.R + k] = (T)hist[(size_t)q * a.R + k];
-    if (istep) a.istep[k] = istep[k];
+        for (int q = 0; q < 4; q++) a.hist[(size_t)q * a.R + k] = (T)hist[(size_t)q * a.R + o];
+    if (istep) a.istep[k] = istep[o];
     a.alive[k] = a.istep[k] + 1 < a.max_size;
 }
 
@@ -918,6 +962,14 @@ RTMI_EXPORT int rtmi_read_final(rtmi_batch* b, double* final9) {
     return RTMI_OK;
 }
 
+// rows [n][nq][R] in slot order -> fp64 rows in the caller's ray order
+template <typename T> __global__ void k_unpermute_rows(const T* src, double* dst, const int* perm, long R, long nvec) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= R) return;
+    const long o = perm ? (long)perm[k] : k;
+    for (long v = blockIdx.y; v < nvec; v += gridDim.y) dst[(size_t)v * R + o] = (double)src[(size_t)v * R + k];
+}
+
 RTMI_EXPORT int rtmi_read_rows(rtmi_batch* b, int64_t row0, int64_t nrows, double* s_ray, double* n_ray) {
     ARG_TRY(b, "rtmi_read_rows: null");
     ARG_TRY(b->p.record_stride > 0, "rtmi_read_rows: batch keeps no trajectory (record_stride = 0)");
@@ -927,21 +979,31 @@ RTMI_EXPORT int rtmi_read_rows(rtmi_batch* b, int64_t row0, int64_t nrows, doubl
     for (int which = 0; which < 2; which++) {
         double* dst = which == 0 ? s_ray : n_ray;
         if (!dst) continue;
-        const size_t per_row = (which == 0 ? 6 : 1) * R, n = per_row * (size_t)nrows;
+        const size_t nq = which == 0 ? 6 : 1, per_row = nq * R;
         const char* src = (const char*)(which == 0 ? b->s_ray : b->n_ray) + (size_t)row0 * per_row * b->esz;
-        if (b->p.dtype == RTMI_F64) {
-            HIP_TRY(hipMemcpyAsync(dst, src, n * 8, hipMemcpyDeviceToHost, b->stream));
+        if (b->p.dtype == RTMI_F64 && !b->perm) {
+            HIP_TRY(hipMemcpyAsync(dst, src, per_row * (size_t)nrows * 8, hipMemcpyDeviceToHost, b->stream));
             HIP_TRY(hipStreamSynchronize(b->stream));
-        } else {
-            double* d = nullptr;
-            HIP_TRY(hipMalloc(&d, n * 8));
-            hipLaunchKernelGGL(k_f32_to_f64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, b->stream, (const float*)src, d, n);
-            hipError_t e = hipGetLastError();
-            if (e == hipSuccess) e = hipMemcpyAsync(dst, d, n * 8, hipMemcpyDeviceToHost, b->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-            (void)hipFree(d);
-            if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_read_rows: ") + hipGetErrorString(e));
+            continue;
         }
+        // convert / un-permute on the device through a bounded staging buffer (<= 256 MB)
+        const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(nrows, (int64_t)((256u << 20) / (per_row * 8))));
+        double* d = nullptr;
+        HIP_TRY(hipMalloc(&d, (size_t)chunk * per_row * 8));
+        hipError_t e = hipSuccess;
+        for (int64_t r0 = 0; r0 < nrows && e == hipSuccess; r0 += chunk) {
+            const int64_t n = std::min<int64_t>(chunk, nrows - r0);
+            const long nvec = (long)(n * (int64_t)nq);
+            const dim3 g((unsigned)((R + 255) / 256), (unsigned)std::min<long>(nvec, 1024)), blk(256);
+            const char* s0 = src + (size_t)r0 * per_row * b->esz;
+            if (b->p.dtype == RTMI_F64) hipLaunchKernelGGL(k_unpermute_rows<double>, g, blk, 0, b->stream, (const double*)s0, d, b->perm, (long)R, nvec);
+            else hipLaunchKernelGGL(k_unpermute_rows<float>, g, blk, 0, b->stream, (const float*)s0, d, b->perm, (long)R, nvec);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipMemcpyAsync(dst + (size_t)r0 * per_row, d, (size_t)n * per_row * 8, hipMemcpyDeviceToHost, b->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+        }
+        (void)hipFree(d);
+        if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_read_rows: ") + hipGetErrorString(e));
     }
     return RTMI_OK;
 }
@@ -962,7 +1024,7 @@ template <typename T> __global__ void k_metric_snell(BatchDev<T> a, double* out)
     const double distx = (double)a.s_ray[(size_t)ra * 6 * a.R + k] - (double)a.s_ray[(size_t)rb * 6 * a.R + k];
     const double disty = (double)a.s_ray[((size_t)ra * 6 + 1) * a.R + k] - (double)a.s_ray[((size_t)rb * 6 + 1) * a.R + k];
     const double angsim = 180 * atan(fabs(distx / disty)) / M_PI;                       // (:916)
-    out[k] = fabs(angsim - angreal);
+    out[out_index(a, k)] = fabs(angsim - angreal);
 }
 template <typename T> __global__ void k_metric_closure(BatchDev<T> a, double* out) {  // RT_bench.py:956, :1393
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -970,7 +1032,7 @@ template <typename T> __global__ void k_metric_closure(BatchDev<T> a, double* ou
     // s_ray[-1, 0:2, k]: the last row of the array -- written only if the ray ran all max_size-1 steps
     const bool full = a.istep[k] == a.max_size - 1;
     const double dx = 1.0 - (full ? (double)a.x[k] : 0.0), dy = 0.0 - (full ? (double)a.y[k] : 0.0);
-    out[k] = 100 * sqrt(fma(dy, dy, dx * dx)) / (2 * M_PI);
+    out[out_index(a, k)] = 100 * sqrt(fma(dy, dy, dx * dx)) / (2 * M_PI);
 }
 template <typename T> __global__ void k_metric_px_cv(BatchDev<T> a, double* out) {    // RT_bench.py:1354-1360, :1398-1402
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -988,7 +1050,7 @@ template <typename T> __global__ void k_metric_px_cv(BatchDev<T> a, double* out)
         const double v = (double)a.s_ray[((size_t)r * 6 + 2) * a.R + k];
         if (v != 0) ss = fma(v - mean, v - mean, ss);
     }
-    out[k] = 100 * sqrt(ss / (double)cnt) / mean;  // 100*np.std/np.mean
+    out[out_index(a, k)] = 100 * sqrt(ss / (double)cnt) / mean;  // 100*np.std/np.mean
 }
 
 RTMI_EXPORT int rtmi_metric(rtmi_batch* b, int kind, double* out) {
@@ -1082,7 +1144,7 @@ template <typename T> __global__ void k_isochrone(BatchDev<T> a, int ntimes, con
                 res[q] = y0 + d0 * s + c1 * (s * s) + c0 * (s * s * s);
             }
         }
-        for (int q = 0; q < 3; q++) out[((size_t)it * 3 + q) * a.R + k] = res[q];
+        for (int q = 0; q < 3; q++) out[((size_t)it * 3 + q) * a.R + out_index(a, k)] = res[q];
     }
 }
 
@@ -1116,6 +1178,7 @@ RTMI_EXPORT int rtmi_batch_view(rtmi_batch* b, rtmi_device_view* v) {
     v->s_ray = b->s_ray; v->n_ray = b->n_ray;
     v->x = s; v->y = s + R * e; v->theta = s + 2 * R * e; v->n = s + 3 * R * e; v->gx = s + 4 * R * e; v->gy = s + 5 * R * e;
     v->dist_sim = s + 6 * R * e; v->dist_real = s + 7 * R * e; v->T = s + 8 * R * e;
+    v->perm = b->perm;
     v->istep = b->istep; v->R = b->R; v->rec_rows = b->p.rec_rows; v->dtype = b->p.dtype; v->record_stride = b->p.record_stride;
     return RTMI_OK;
 }

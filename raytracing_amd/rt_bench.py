@@ -275,7 +275,7 @@ class Batch:
 
     def __init__(self, field, method, step, max_size, box, gamma, thetas, x0, y0, record_stride=1, rec_rows=0,
                  gamma_step=None, stream=None, ext_s_ray=None, ext_n_ray=None, block_size=0, launch_mode=0,
-                 refill_min=0, exact_basis=0, field_path=0):
+                 refill_min=0, exact_basis=0, field_path=0, sort_rays=False):
         self.field = field
         th = np.ascontiguousarray(thetas, dtype=np.float64)
         self.R = len(th)
@@ -290,6 +290,7 @@ class Batch:
             p.box[i] = float(box[i])
         p.launch_mode = int(launch_mode); p.block_size = int(block_size); p.refill_min = int(refill_min)
         p.exact_basis = int(exact_basis); p.field_path = int(field_path)
+        p.sort_rays = int(bool(sort_rays))
         p.ext_s_ray = ext_s_ray; p.ext_n_ray = ext_n_ray
         self.params = p
         self._h = C.c_void_p()
@@ -376,6 +377,8 @@ class Batch:
         out = {name: torch.as_tensor(_Cai(getattr(v, name), (self.R,), ts), device=dev)
                for name in ("x", "y", "theta", "n", "gx", "gy", "dist_sim", "dist_real", "T")}
         out["istep"] = torch.as_tensor(_Cai(v.istep, (self.R,), "<i4"), device=dev)
+        if v.perm:   # sort_rays: slot k of every tensor here is the caller's ray perm[k]
+            out["perm"] = torch.as_tensor(_Cai(v.perm, (self.R,), "<i4"), device=dev)
         if v.s_ray:
             out["s_ray"] = torch.as_tensor(_Cai(v.s_ray, (int(v.rec_rows), 6, self.R), ts), device=dev)
         if v.n_ray:

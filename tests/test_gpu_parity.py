@@ -609,3 +609,31 @@ def test_bad_launch_conditions_do_not_disturb_neighbours(rb, gpu_fields):
     from raytracing_amd._lib import RtmiError
     with pytest.raises(RtmiError, match="R must be"):
         rb.Batch(F, 6, rb.DELTA_S, 600, lim, 1, np.array([]), -2.0, -2.0)      # empty batch: rejected, not launched
+
+
+@pytest.mark.parametrize("scen,m,mode", [("vert_heterogeneous", 6, 0), ("interface", 7, 0), ("vert_heterogeneous", 6, 1)])
+def test_sort_rays_answers_in_caller_order(scen, m, mode, rb, gpu_fields):
+    """sort_rays=1 reorders rays inside the batch (coherent lanes) but every read -- d_ray, final state, rows,
+    n_ray, metrics, isochrones, set_state -- answers in the caller's order, bit-identical to the unsorted batch."""
+    rng = np.random.default_rng(11)
+    R = 1500
+    lim = LIMITS[scen]
+    th = rng.permutation(np.linspace(0.06, np.pi / 2, R))
+    x0 = np.where(rng.random(R) < 0.2, -1.0, -2.0)          # two launch points -> two cell blocks in the sort key
+    th[7] = np.nan
+    ms = 3000
+    out = []
+    for srt in (False, True):
+        b = rb.Batch(gpu_fields(scen), m, rb.DELTA_S, ms, lim, 1, th, x0, -2.0, record_stride=1, sort_rays=srt,
+                     launch_mode=mode)
+        b.step(50)
+        b.run()
+        s, n = b.rows(1000, 700, want_n_ray=True)
+        perm = b.device_tensors().get("perm")
+        out.append((b.d_ray(), b.final(), s, n, b.metric("px_cv"), b.metric("closure"), b.isochrones([0.05, 0.1]),
+                    None if perm is None else perm.cpu().tolist()))      # copied before the batch (and its memory) goes
+        del perm
+        b.close()
+    assert out[0][7] is None and sorted(out[1][7]) == list(range(R))
+    for u, v in zip(out[0][:7], out[1][:7]):
+        assert np.array_equal(u, v, equal_nan=True)
