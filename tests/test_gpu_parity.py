@@ -332,7 +332,7 @@ def test_lds_tile_equals_global_gather(scen, m, shuffle, mode, rb, gpu_fields):
         b.run()
         out.append((b.d_ray(), b.final(), b.rows(), b.stats()["lds_bytes"]))
         b.close()
-    assert out[0][3] > 0 and out[1][3] <= 16
+    assert out[0][3] > 4096 and out[1][3] <= 512        # the tile variant really carries the LDS tile
     for u, v in zip(out[0][:3], out[1][:3]):
         assert np.array_equal(u, v)
 
