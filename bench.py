@@ -102,8 +102,8 @@ def main():
                     help="ray order inside the batch: the sorted fan, or a seeded random permutation of it")
     ap.add_argument("--refill-min", type=int, default=0)
     ap.add_argument("--sort", action="store_true", help="sort rays inside the batch by launch cell and angle (sort_rays)")
-    ap.add_argument("--field-path", default="lds", choices=["lds", "global"],
-                    help="lds: wave-private LDS tile of the field (default); global: every lookup gathers from L2/HBM")
+    ap.add_argument("--field-path", default="auto", choices=["auto", "lds", "global"],
+                    help="auto (default): LDS tile when recording densely, else global; lds / global force one")
     ap.add_argument("--rec-rows", type=int, default=0, help="rows to allocate (0 = from max_size; full: 3072 for vert)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
@@ -159,7 +159,7 @@ def main():
         return rb.Batch(fld, args.method, step, max_size, lim, sc["gamma"], th, sc["start"][0], sc["start"][1],
                         record_stride=stride_, rec_rows=rec_rows_, block_size=args.block,
                         launch_mode=1 if args.mode == "refill" else 0, refill_min=args.refill_min,
-                        field_path=0 if args.field_path == "lds" else 1, sort_rays=args.sort)
+                        field_path={"auto": 0, "global": 1, "lds": 2}[args.field_path], sort_rays=args.sort)
 
     try:
         batch = make_batch(stride, rec_rows)

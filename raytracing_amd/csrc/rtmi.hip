@@ -654,12 +654,20 @@ template <typename T> static const void* refill_fn(int m, bool iso, bool lds) {
     return tab[m - 1][iso ? 1 : 0][lds ? 1 : 0];
 }
 #undef RTMI_VARIANTS_
+// field_path 0 (auto): the LDS tile pays when the step loop also streams trajectory rows (its lookups then stay off
+// the vector-memory queue the stores occupy: 27.0 vs 29.0 ms at full record); without dense recording the plain
+// gather is ahead (18.9 vs 20.3 ms) because the kernel is VALU-bound and the tile costs ~25 integer instructions.
+static bool use_lds_tile(const rtmi_batch* b) {
+    if (b->p.field_path == 1) return false;
+    if (b->p.field_path == 2) return true;
+    return b->p.record_stride == 1 || b->p.record_stride == 2;
+}
 static const void* pick_advance(const rtmi_batch* b) {
-    const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = b->p.field_path != 1;
+    const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
     return b->p.dtype == RTMI_F64 ? advance_fn<double>(b->p.method, iso, lds) : advance_fn<float>(b->p.method, iso, lds);
 }
 static const void* pick_refill(const rtmi_batch* b) {
-    const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = b->p.field_path != 1;
+    const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
     return b->p.dtype == RTMI_F64 ? refill_fn<double>(b->p.method, iso, lds) : refill_fn<float>(b->p.method, iso, lds);
 }
 
@@ -708,7 +716,7 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     ARG_TRY(p->launch_mode == 0 || p->launch_mode == 1, "rtmi_batch_create: launch_mode must be 0 or 1");
     ARG_TRY(p->refill_min >= 0 && p->refill_min <= 64, "rtmi_batch_create: refill_min must be in [0, 64]");
     ARG_TRY(p->exact_basis == 0 || p->exact_basis == 1, "rtmi_batch_create: exact_basis must be 0 or 1");
-    ARG_TRY(p->field_path == 0 || p->field_path == 1, "rtmi_batch_create: field_path must be 0 (LDS tile) or 1 (global)");
+    ARG_TRY(p->field_path >= 0 && p->field_path <= 2, "rtmi_batch_create: field_path must be 0 (auto), 1 (global) or 2 (LDS tile)");
     ARG_TRY(p->sort_rays == 0 || p->sort_rays == 1, "rtmi_batch_create: sort_rays must be 0 or 1");
     rtmi_batch* b = new (std::nothrow) rtmi_batch();
     if (!b) return fail(RTMI_ERR_ALLOC, "rtmi_batch_create: host allocation failed");

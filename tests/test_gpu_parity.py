@@ -312,7 +312,7 @@ def test_uniform_basis_vs_exact_basis(scen, m, rb, gpu_fields, oracle_fields):
                                                  ("interface", 6, False, 0), ("fisheye", 6, False, 0),
                                                  ("vert_heterogeneous", 7, True, 1), ("anisotropy", 11, False, 0)])
 def test_lds_tile_equals_global_gather(scen, m, shuffle, mode, rb, gpu_fields):
-    """field_path 0 (wave-private LDS tile of the field, re-staged as the wave moves; lanes outside the tile fall
+    """field_path 2 (wave-private LDS tile of the field, re-staged as the wave moves; lanes outside the tile fall
     back to global loads) must give the same bits as field_path 1 (every lookup gathers from global memory):
     coherent fans, a shuffled batch (tile rarely fits), the refill kernel, rays that run to the grid's edge."""
     R = 2000 if m != 11 else 200
@@ -326,7 +326,7 @@ def test_lds_tile_equals_global_gather(scen, m, shuffle, mode, rb, gpu_fields):
     if scen == "vert_heterogeneous" and not shuffle:
         lim = (-4.9, 7.9, -5.4, 3.9)          # let rays run into the not-a-knot end cells of the grid
     out = []
-    for path in (0, 1):
+    for path in (2, 1):
         b = rb.Batch(gpu_fields(scen), m, step, ms, lim, 3 if scen == "anisotropy" else 1, th, x0, y0, record_stride=8,
                      field_path=path, launch_mode=mode)
         b.run()
@@ -595,7 +595,7 @@ def test_bad_launch_conditions_do_not_disturb_neighbours(rb, gpu_fields):
     lim = LIMITS["vert_heterogeneous"]
     th = np.array([0.3, np.nan, np.inf, 0.5, 0.7, 1e12, 0.9])
     x0 = np.array([-2.0, -2.0, -2.0, -2.0, 1e6, -2.0, np.nan])
-    for mode, path in ((0, 0), (0, 1), (1, 0)):
+    for mode, path in ((0, 2), (0, 1), (1, 2)):
         b = rb.Batch(F, 6, rb.DELTA_S, 600, lim, 1, th, x0, -2.0, record_stride=1, launch_mode=mode, field_path=path)
         b.run()
         d, fin, rows = b.d_ray(), b.final(), b.rows()
