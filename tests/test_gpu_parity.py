@@ -637,3 +637,28 @@ def test_sort_rays_answers_in_caller_order(scen, m, mode, rb, gpu_fields):
     assert out[0][7] is None and sorted(out[1][7]) == list(range(R))
     for u, v in zip(out[0][:7], out[1][:7]):
         assert np.array_equal(u, v, equal_nan=True)
+
+
+def test_north_star_1m_rays_vs_oracle_subsample(rb, gpu_fields, oracle_fields):
+    """The bench workload itself (vert_heterogeneous, 1 048 576 rays, op6, default DELTA_S, fp64): every 512th ray
+    against the oracle (end state to 1e-9, step counts exactly), the device step counter against sum(d_ray[2]),
+    and p_x conservation over the whole fan."""
+    from oracle import rt_oracle as O
+    R = 1 << 20
+    th = np.linspace(0, np.pi / 2, R)
+    lim = LIMITS["vert_heterogeneous"]
+    ms = int(np.ceil(80 / rb.DELTA_S) + 1)
+    b = rb.Batch(gpu_fields("vert_heterogeneous"), 6, rb.DELTA_S, ms, lim, 1, th, -2.0, -2.0, record_stride=0)
+    b.run()
+    d, fin, st = b.d_ray(), b.final(), b.stats()
+    b.close()
+    assert st["ray_steps"] == int(d[2].sum()) == 1937541698           # the figure bench.py divides by the time
+    sub = slice(0, R, 512)
+    o = O.trazar(oracle_fields("vert_heterogeneous"), 6, 1, rb.DELTA_S, ms, lim, -2.0, -2.0, th[sub], record_stride=0,
+                 nthreads=8)
+    assert np.array_equal(d[2][sub], o["d_ray"][2])
+    err = relerr(fin[:, sub], o["final"])
+    print(f"1M-ray fan, 2048-ray subsample vs oracle: max rel err {err:.2e}")
+    assert err < REL and relerr(d[:2, sub], o["d_ray"][:2]) < REL
+    n0 = 0.07142864686293911
+    assert np.max(np.abs(fin[6] - n0 * np.cos(th))) / n0 < 5e-4          # the scheme's own p_x drift (CV threshold scale)
