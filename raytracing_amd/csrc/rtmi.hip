@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <exception>
 #include <numeric>
 #include <new>
 #include <string>
@@ -193,7 +194,7 @@ std::vector<double> linspace(double a, double b, int n) {
 }
 }  // namespace
 
-static int field_finish(rtmi_field* f, double delta) {
+static int field_finish_impl(rtmi_field* f, double delta) {
     const int qx = f->qx, qy = f->qy;
     const size_t nz = (size_t)qx * qy;
     hipStream_t st = f->stream;
@@ -230,6 +231,14 @@ static int field_finish(rtmi_field* f, double delta) {
     HIP_TRY(hipFree(dlux));
     HIP_TRY(hipFree(dluy));
     return RTMI_OK;
+}
+
+static int field_finish(rtmi_field* f, double delta) {
+    try {
+        return field_finish_impl(f, delta);
+    } catch (const std::exception& e) {   // host vectors of the collocation factorisation
+        return fail(RTMI_ERR_ALLOC, std::string("field build: ") + e.what());
+    }
 }
 
 RTMI_EXPORT int rtmi_abi_version(void) { return RTMI_ABI_VERSION; }
@@ -288,9 +297,13 @@ RTMI_EXPORT int rtmi_field_from_samples(const double* x, int qx, const double* y
     ARG_TRY(x && y && Z, "rtmi_field_from_samples: null input");
     ARG_TRY(delta > 0, "rtmi_field_from_samples: delta must be > 0");
     ARG_TRY(qx >= 8 && qy >= 8, "rtmi_field_from_samples: grid must be at least 8x8");
-    const std::vector<double> lx = linspace(x[0], x[qx - 1], qx), ly = linspace(y[0], y[qy - 1], qy);
-    if (memcmp(lx.data(), x, qx * sizeof(double)) || memcmp(ly.data(), y, qy * sizeof(double)))
-        return fail(RTMI_ERR_UNSUPPORTED, "rtmi_field_from_samples: axes must be numpy.linspace grids (genZ, RT_bench.py:429)");
+    try {
+        const std::vector<double> lx = linspace(x[0], x[qx - 1], qx), ly = linspace(y[0], y[qy - 1], qy);
+        if (memcmp(lx.data(), x, qx * sizeof(double)) || memcmp(ly.data(), y, qy * sizeof(double)))
+            return fail(RTMI_ERR_UNSUPPORTED, "rtmi_field_from_samples: axes must be numpy.linspace grids (genZ, RT_bench.py:429)");
+    } catch (const std::exception& e) {
+        return fail(RTMI_ERR_ALLOC, std::string("rtmi_field_from_samples: ") + e.what());
+    }
     rtmi_field* f = nullptr;
     int rc = field_alloc(dtype, qx, qy, stream, &f);
     if (rc) { rtmi_field_destroy(f); return rc; }
@@ -314,8 +327,12 @@ RTMI_EXPORT int rtmi_field_read(const rtmi_field* f, double* x, double* y, doubl
     ARG_TRY(f, "rtmi_field_read: null field");
     const size_t nz = (size_t)f->qx * f->qy * sizeof(double);
     HIP_TRY(hipStreamSynchronize(f->stream));
-    if (x) { auto v = linspace(f->ax, f->bx, f->qx); memcpy(x, v.data(), v.size() * sizeof(double)); }
-    if (y) { auto v = linspace(f->ay, f->by, f->qy); memcpy(y, v.data(), v.size() * sizeof(double)); }
+    try {
+        if (x) { auto v = linspace(f->ax, f->bx, f->qx); memcpy(x, v.data(), v.size() * sizeof(double)); }
+        if (y) { auto v = linspace(f->ay, f->by, f->qy); memcpy(y, v.data(), v.size() * sizeof(double)); }
+    } catch (const std::exception& e) {
+        return fail(RTMI_ERR_ALLOC, std::string("rtmi_field_read: ") + e.what());
+    }
     if (Z) HIP_TRY(hipMemcpy(Z, f->dZ, nz, hipMemcpyDeviceToHost));
     if (cdy) HIP_TRY(hipMemcpy(cdy, f->dCdy, nz, hipMemcpyDeviceToHost));
     if (cdx) HIP_TRY(hipMemcpy(cdx, f->dCdx, nz, hipMemcpyDeviceToHost));
@@ -784,7 +801,11 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
         b->persistent_blocks = cus * (per_cu > 0 ? per_cu : 1);
         return batch_init_state(b, true);
     };
-    rc = body();
+    try {
+        rc = body();
+    } catch (const std::exception& e) {   // host allocations (sort_rays) must not unwind across the C ABI
+        rc = fail(RTMI_ERR_ALLOC, std::string("rtmi_batch_create: ") + e.what());
+    }
     if (rc) { rtmi_batch_destroy(b); return rc; }
     *out = b;
     return RTMI_OK;
