@@ -72,6 +72,15 @@ class Field:
         lib().rto_field_dims(self.h, C.byref(qx), C.byref(qy))
         self.qx, self.qy = qx.value, qy.value
 
+    @classmethod
+    def from_samples(cls, x, y, Z, delta):
+        """interpolacion(x, y, Z, X, Y) (RT_bench.py:435) for caller-provided samples."""
+        x = _f64(x); y = _f64(y); Z = _f64(Z)
+        self = cls.__new__(cls)
+        self.h = lib().rto_field_from_samples(_p(x), len(x), _p(y), len(y), _p(Z), float(delta))
+        self.qx, self.qy = len(x), len(y)
+        return self
+
     def arrays(self):
         x = np.empty(self.qx); y = np.empty(self.qy)
         Z = np.empty((self.qy, self.qx)); cdy = np.empty_like(Z); cdx = np.empty_like(Z)

@@ -705,3 +705,37 @@ def test_random_rays_through_grid_ends_vs_oracle(scen, m, rb, gpu_fields, oracle
     # there): that is the reference's own conditioning, so those methods are reproducible to ~1e-8 per such step.
     tol = 1e-7 if m == 7 else (2e-5 if m in (3, 4, 5, 10) and scen == "interface" else REL)
     assert err.max() < tol
+
+
+@pytest.mark.parametrize("qx,qy", [(8, 8), (12, 10), (40, 17)])
+def test_small_custom_grids_vs_oracle(qx, qy, rb):
+    """interpolacion() on caller-sampled grids far smaller than the LDS tile and the interior fast path assume:
+    every cell then takes FITPACK's general not-a-knot arithmetic and the global gather.  Coefficients, point
+    lookups (inside and outside the grid) and short traces against the oracle."""
+    from oracle import rt_oracle as O
+    rng = np.random.default_rng(qx * 100 + qy)
+    x = np.linspace(-1.0, 2.0, qx); y = np.linspace(0.5, 2.5, qy)
+    X, Y = np.meshgrid(x, y)
+    Z = 1.2 + 0.3 * np.sin(1.3 * X) * np.cos(0.7 * Y) + 0.05 * rng.standard_normal(X.shape)
+    delta = 0.11
+    F = rb.Field.from_samples(x, y, Z, delta)
+    OF = O.Field.from_samples(x, y, Z, delta)
+    for a, b in zip(F.arrays()[2:], OF.arrays()[2:]):
+        assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max()
+    px = rng.uniform(-1.5, 2.5, 400); py = rng.uniform(0.0, 3.0, 400)
+    for u, v in zip(F.n_gradient(px, py), OF.n_gradient(px, py)):
+        assert np.abs(u - v).max() <= 1e-12 * max(np.abs(v).max(), 1.0)
+    R = 130
+    x0 = rng.uniform(-0.9, 1.9, R); y0 = rng.uniform(0.6, 2.4, R); th = rng.uniform(-np.pi, np.pi, R)
+    lim = (-0.99, 1.99, 0.51, 2.49)
+    for m in (2, 6):
+        for path in (1, 2):
+            b = rb.Batch(F, m, 0.01, 500, lim, 1, th, x0, y0, record_stride=0, field_path=path)
+            b.run()
+            d, fin = b.d_ray(), b.final()
+            b.close()
+            o = O.trazar(OF, m, 1, 0.01, 500, lim, x0, y0, th, record_stride=0)
+            same = d[2] == o["d_ray"][2]
+            assert same.mean() > 0.98
+            assert relerr(fin[:, same], o["final"][:, same]) < 1e-8      # noisy Z: gradients are O(1) per cell
+    F.close()
