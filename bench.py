@@ -106,6 +106,9 @@ def main():
                     help="auto (default): LDS tile when recording densely, else global; lds / global force one")
     ap.add_argument("--rec-rows", type=int, default=0, help="rows to allocate (0 = from max_size; full: 3072 for vert)")
     ap.add_argument("--block", type=int, default=0)
+    ap.add_argument("--chunk", type=int, default=0,
+                    help="0: one launch runs every ray to termination (default); N: the host advances the batch N "
+                         "DELTA_S steps per launch (state round-trips HBM between launches), N=1 is one step at a time")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="torch.distributed backend for N>1 (nccl = RCCL over xGMI; gloo only to rehearse the "
@@ -178,9 +181,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    longest = {"vert_heterogeneous": 2953, "anisotropy": 2900}.get(args.scenario, max_size - 1)
+
     def one_pass():
         batch.reset()
-        batch.run()
+        if args.chunk <= 0:
+            batch.run()
+        else:   # enough launches for the longest ray of the fan; launches after the last ray stopped exit at once
+            for _ in range((longest + args.chunk - 1) // args.chunk + 1):
+                batch.step(args.chunk)
+            batch.sync()
 
     for _ in range(args.warmup):
         one_pass()
@@ -231,7 +241,7 @@ def main():
                                    f"box={tuple(float(v) for v in lim)}, record={args.record}",
                        "rays_per_gpu": args.rays, "ray_steps_per_pass_rank0": int(steps_per_pass),
                        "method": f"op{args.method}", "record": args.record, "launch_mode": args.mode,
-                       "ray_order": args.order, "sort_rays": bool(args.sort), "field_path": args.field_path, "parallelism": f"ray-shard x{world}"},
+                       "ray_order": args.order, "sort_rays": bool(args.sort), "field_path": args.field_path, "steps_per_launch": args.chunk or "all", "parallelism": f"ray-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "kernel": "k_trace_refill" if args.mode == "refill" else "k_advance", "kernel_ms": kern_ms, "alg_bytes_per_ray_step": balg,

@@ -152,7 +152,7 @@ typedef struct {
 int rtmi_batch_view(rtmi_batch *b, rtmi_device_view *v);
 
 typedef struct {
-    uint64_t ray_steps;      /* sum over rays of steps taken since create/reset */
+    uint64_t ray_steps;      /* sum over rays of the last written row (= sum of d_ray[2]): steps taken since create/reset */
     uint64_t live_rays;      /* rays that would still step */
     double kernel_ms;        /* sum of advance-kernel durations since create/reset (HIP events on the batch's stream) */
     uint32_t launches;       /* advance-kernel launches since create/reset */

@@ -383,7 +383,7 @@ template <typename T> struct BatchDev {
     int* istep;
     unsigned char* alive;
     T *s_ray, *n_ray;
-    unsigned long long* counters;  // [0] ray-steps, [1] live rays (recomputed per launch), [2] refill queue head
+    unsigned long long* counters;  // [0] ray-steps, [1] live rays (filled by k_stats on demand), [2] refill queue head
     const double *x0, *y0, *th0;   // launch conditions (device, fp64), in slot order
     const int* perm;               // sort_rays: slot k holds caller's ray perm[k] (nullptr: identity)
 };
@@ -412,10 +412,27 @@ template <typename T> __global__ void k_init(BatchDev<T> a) {
     if (a.stride && a.rec_rows > 0) write_row(a, 0, k, r);
 }
 
-__device__ __forceinline__ unsigned wave_sum(unsigned v) {
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+}
+
+// Batch totals on demand: counters[0] = sum of istep (ray-steps taken = sum of d_ray[2]), counters[1] = live rays.
+// Kept out of the advance kernels on purpose: two same-address atomics per wave cost more than a whole
+// one-step launch (16 384 waves x ~12 ns each), and both totals are functions of state already in HBM.
+__global__ void k_stats(const int* istep, const unsigned char* alive, long R, unsigned long long* counters) {
+    unsigned long long steps = 0, live = 0;
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < R; k += (long)gridDim.x * blockDim.x) {
+        steps += (unsigned long long)istep[k];
+        live += alive[k];
+    }
+    steps = wave_sum(steps);
+    live = wave_sum(live);
+    if ((threadIdx.x & 63) == 0) {
+        if (steps) atomicAdd(&counters[0], steps);
+        if (live) atomicAdd(&counters[1], live);
+    }
 }
 
 template <typename T, int METHOD, bool ISO>
@@ -465,7 +482,6 @@ __global__ __launch_bounds__(256, LDS ? 2 : 3) void k_advance(BatchDev<T> a, int
     gather_init<T, LDS>(gather, lds);
     const bool RECORD = a.stride != 0;
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned done = 0, live = 0;
     rt::Ray<T> r;
     int i = 0, until = 0;
     long row = 0;
@@ -491,20 +507,10 @@ __global__ __launch_bounds__(256, LDS ? 2 : 3) void k_advance(BatchDev<T> a, int
                 }
             }
             alive = inside && (i + 1 < a.max_size);
-            ++done;
             if (!alive) store_ray<T, METHOD>(a, k, r, i, false);
         }
     }
-    if (alive) {
-        store_ray<T, METHOD>(a, k, r, i, true);
-        live = 1;
-    }
-    done = wave_sum(done);
-    live = wave_sum(live);
-    if ((threadIdx.x & 63) == 0) {
-        if (done) atomicAdd(&a.counters[0], (unsigned long long)done);
-        if (live) atomicAdd(&a.counters[1], (unsigned long long)live);
-    }
+    if (alive) store_ray<T, METHOD>(a, k, r, i, true);
 }
 
 // Persistent waves with lane refill (launch_mode 1): every wave draws rays from a device-side queue
@@ -527,7 +533,6 @@ __global__ __launch_bounds__(256, 2) void k_trace_refill(BatchDev<T> a, int refi
     int i = 0, until = 0;
     bool alive = false;
     bool exhausted = false;  // wave-uniform
-    unsigned done = 0;
     for (;;) {
         unsigned long long live_mask = __ballot(alive);
         const int n_dead = 64 - __popcll(live_mask);
@@ -569,13 +574,10 @@ __global__ __launch_bounds__(256, 2) void k_trace_refill(BatchDev<T> a, int refi
                     }
                 }
                 alive = inside && (i + 1 < a.max_size);
-                ++done;
                 if (!alive) store_ray<T, METHOD>(a, k, r, i, false);
             }
         }
     }
-    done = wave_sum(done);
-    if (lane == 0 && done) atomicAdd(&a.counters[0], (unsigned long long)done);
 }
 
 // index of slot k's ray in the caller's order
@@ -901,7 +903,6 @@ RTMI_EXPORT int rtmi_step(rtmi_batch* b, int32_t nsteps) {
     int rc0 = next_event_pair(b, &evp);
     if (rc0) return rc0;
     auto& ev = *evp;
-    HIP_TRY(hipMemsetAsync(b->counters + 1, 0, sizeof(unsigned long long), b->stream));
     HIP_TRY(hipEventRecord(ev.first, b->stream));
     if (b->p.dtype == RTMI_F64) launch_advance<double>(b, nsteps);
     else launch_advance<float>(b, nsteps);
@@ -912,6 +913,9 @@ RTMI_EXPORT int rtmi_step(rtmi_batch* b, int32_t nsteps) {
 }
 
 static int read_counters(rtmi_batch* b) {
+    HIP_TRY(hipMemsetAsync(b->counters, 0, 2 * sizeof(unsigned long long), b->stream));
+    hipLaunchKernelGGL(k_stats, dim3(256), dim3(256), 0, b->stream, b->istep, b->alive, (long)b->R, b->counters);
+    HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(b->h_counters, b->counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));  // [0..1]
     HIP_TRY(hipStreamSynchronize(b->stream));
     return RTMI_OK;
@@ -937,7 +941,7 @@ RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
         rc = next_event_pair(b, &ev);
         if (rc) return rc;
-        HIP_TRY(hipMemsetAsync(b->counters + 1, 0, 2 * sizeof(unsigned long long), b->stream));
+        HIP_TRY(hipMemsetAsync(b->counters + 2, 0, sizeof(unsigned long long), b->stream));   // refill queue head
         HIP_TRY(hipEventRecord(ev->first, b->stream));
         if (b->p.dtype == RTMI_F64) launch_refill<double>(b);
         else launch_refill<float>(b);
@@ -1221,7 +1225,7 @@ RTMI_EXPORT int rtmi_batch_stats(rtmi_batch* b, rtmi_stats* s) {
     rc = read_counters(b);
     if (rc) return rc;
     s->ray_steps = b->h_counters[0];
-    s->live_rays = b->launches ? b->h_counters[1] : (uint64_t)b->R;
+    s->live_rays = b->h_counters[1];
     s->kernel_ms = b->kernel_ms;
     s->launches = b->launches;
     hipFuncAttributes fa;
