@@ -403,26 +403,39 @@ def max_rows(user_choice, step, divisor):
     return N * divisor if c[10] else int(np.ceil(c[4] / step) + 1)
 
 
-def snell_errors(s_ray, d_ray, theta_v):
-    """Interface exit-angle metric (:896-919), vectorised over rays (degrees)."""
+def snell_angles(s_ray, d_ray, theta_v):
+    """Interface exit angles (:896-919) per ray, degrees: (angsim, angreal) -- the simulated outward angle over
+    the second-to-last 5 % of the trajectory and the Snell / reflection angle it should have."""
     R = s_ray.shape[2]
-    err = np.zeros(R)
+    angsim, angreal = np.zeros(R), np.zeros(R)
     for k in range(R):
         i = int(d_ray[2, k])
         th = theta_v[k]
         if th < np.pi / 4:
-            angreal = 90 - 180 * th / np.pi
+            angreal[k] = 90 - 180 * th / np.pi
         elif th == np.pi / 4:
-            angreal = 0
+            angreal[k] = 0
         else:
-            angreal = 180 * np.arcsin(np.sqrt(2) * np.sin(np.pi / 2 - th)) / np.pi
+            angreal[k] = 180 * np.arcsin(np.sqrt(2) * np.sin(np.pi / 2 - th)) / np.pi
         a, b = int(9.5 * i / 10), int(9 * i / 10)
         distx = s_ray[a, 0, k] - s_ray[b, 0, k]
         disty = s_ray[a, 1, k] - s_ray[b, 1, k]
         with np.errstate(divide="ignore", invalid="ignore"):
-            angsim = 180 * np.arctan(np.abs(distx / disty)) / np.pi
-        err[k] = np.abs(angsim - angreal)
-    return err
+            angsim[k] = 180 * np.arctan(np.abs(distx / disty)) / np.pi
+    return angsim, angreal
+
+
+def snell_errors(s_ray, d_ray, theta_v):
+    """Host restatement of the exit-angle error (:918); the library evaluates it on the device (rtmi_metric)."""
+    angsim, angreal = snell_angles(s_ray, d_ray, theta_v)
+    return np.abs(angsim - angreal)
+
+
+def _format_num(num):
+    """The reference's column formatter (:929-943)."""
+    if num < 0:
+        return "{: >10.8f}".format(num) if abs(num) < 10 else "{: >10.7f}".format(num)
+    return "{: >10.9f}".format(num) if num < 10 else "{: >10.8f}".format(num)
 
 
 def closure_error(s_ray):
@@ -483,11 +496,13 @@ def trazar(selected_func, z, grd, show, step, divisor, user_choice, *, thetas=No
     errors = np.zeros(ray_count)
     if op_if and stride == 1:
         errors = b.metric("snell")          # (:896-919) evaluated on the device
-        if show:
+        if show:   # the reference's per-ray table (:921-945)
+            angsim, angreal = snell_angles(s_ray, d_ray, theta_v)
             for k in range(ray_count):
                 i = int(d_ray[2, k])
-                print(f"Coords: [ {s_ray[i, 0, k]: >10.8f} , {s_ray[i, 1, k]: >10.8f} ] | Err: {errors[k]: >10.8f} | "
-                      f"InitAng: {theta_v[k] * 180 / np.pi: >10.8f}")
+                f = _format_num
+                print(f"Coords: [ {f(s_ray[i, 0, k])} , {f(s_ray[i, 1, k])} ] | SimAng: {f(angsim[k])} | "
+                      f"SnellAng: {f(angreal[k])} | Err: {f(errors[k])} | InitAng: {f(theta_v[k] * 180 / np.pi)}")
     if return_batch:
         return s_ray, d_ray, compute_times, errors, b
     b.close()
