@@ -164,6 +164,17 @@ def test_trajectory_vs_reference(name, scen, m, rb, gpu_fields):
     assert not s[i + 1:, :, k].any()                                   # rows after termination stay zero (Q7)
 
 
+def test_trazar_show_prints_reference_table(rb, gpu_fields, capsys):
+    t = golden("traj_interface_op6_16")
+    F = gpu_fields("interface")
+    z, grd = rb.FieldSpline(F, "n"), (rb.FieldSpline(F, "dy"), rb.FieldSpline(F, "dx"))
+    rb.trazar(rb.op6, z, grd, True, rb.DELTA_S, 91, "1", thetas=t["theta"])
+    lines = [l for l in capsys.readouterr().out.splitlines() if l.startswith("Coords:")]
+    assert len(lines) == 16 and all("SnellAng:" in l and "InitAng:" in l for l in lines)
+    err0 = float(lines[0].split("Err:")[1].split("|")[0])
+    assert abs(err0 - t["errors"][0]) < 1e-6
+
+
 def test_trazar_call_surface_interface(rb, gpu_fields):
     """trazar(selected_func, z, grd, show, step, divisor, user_choice) with the 16-ray cfg1 batch."""
     t = golden("traj_interface_op6_16")
