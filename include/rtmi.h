@@ -107,6 +107,10 @@ int rtmi_batch_create(const rtmi_field *f, const rtmi_params *p, int64_t R, cons
  * with istep+1 < max_size becomes live.  This is the explicit-argument form of one selected_func call
  * (:868): opN(i_angle, init_n, i_grad, i_unitv, i_vpos, coef_i, grd, z, step) with caller-chosen inputs. */
 int rtmi_batch_set_state(rtmi_batch *b, const double *state9, const double *hist4, const int32_t *istep);
+/* Give every ray its own DELTA_S and max_size (host arrays [R], caller's ray order): one batch then holds the whole
+ * DELTA_S calibration sweep, candidate x ray (search_delta over delta_s_options, RT_bench.py:950-958, 1317-1318).
+ * max_size[k] <= params.max_size (which sizes the trajectory arrays).  Survives rtmi_batch_reset. */
+int rtmi_batch_set_per_ray(rtmi_batch *b, const double *step, const int32_t *max_size);
 /* Back to row 0 with the same launch conditions (re-runs the initial conditions; clears trajectories). */
 int rtmi_batch_reset(rtmi_batch *b);
 /* One launch that advances every live ray by at most nsteps DELTA_S steps (the body of the loop at :866-879;

@@ -386,6 +386,8 @@ template <typename T> struct BatchDev {
     unsigned long long* counters;  // [0] ray-steps, [1] live rays (filled by k_stats on demand), [2] refill queue head
     const double *x0, *y0, *th0;   // launch conditions (device, fp64), in slot order
     const int* perm;               // sort_rays: slot k holds caller's ray perm[k] (nullptr: identity)
+    const T *vstep, *vstep2h;      // per-ray DELTA_S and DELTA_S**2/2 (rtmi_batch_set_per_ray; nullptr: uniform)
+    const int* vmax;               // per-ray max_size (same)
 };
 
 template <typename T> __device__ __forceinline__ void write_row(const BatchDev<T>& a, long row, long k, const rt::Ray<T>& r) {
@@ -408,7 +410,7 @@ template <typename T> __global__ void k_init(BatchDev<T> a) {
     a.dsim[k] = 0; a.dreal[k] = 0; a.tt[k] = 0;
     if (a.hist) { a.hist[k] = 0; a.hist[a.R + k] = 0; a.hist[2 * a.R + k] = 0; a.hist[3 * a.R + k] = 0; }
     a.istep[k] = 0;
-    a.alive[k] = a.max_size > 1;
+    a.alive[k] = max_size_of(a, k) > 1;
     if (a.stride && a.rec_rows > 0) write_row(a, 0, k, r);
 }
 
@@ -475,7 +477,7 @@ template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::
 // has no dense row stores to queue the scratch reloads behind), the tile variant for two with no spills.
 // Every lane runs every iteration until no lane of its wave is active; a ray's state is stored the moment it
 // terminates (or when the launch's step budget ends), so idle lanes never write.
-template <typename T, int METHOD, bool ISO, bool LDS>
+template <typename T, int METHOD, bool ISO, bool LDS, bool VAR>
 __global__ __launch_bounds__(256, LDS ? 2 : 3) void k_advance(BatchDev<T> a, int nsteps) {
     __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
     typename GatherOf<T, LDS>::type gather;
@@ -486,6 +488,10 @@ __global__ __launch_bounds__(256, LDS ? 2 : 3) void k_advance(BatchDev<T> a, int
     int i = 0, until = 0;
     long row = 0;
     bool alive = k < a.R && a.alive[k];
+    // VAR: every ray carries its own DELTA_S and max_size (the calibration sweep as one candidate x ray batch)
+    rt::Consts<T> K = a.K;
+    int max_size = a.max_size;
+    if (VAR && k < a.R) { K.step = a.vstep[k]; K.step2h = a.vstep2h[k]; max_size = a.vmax[k]; }
     if (alive) {
         load_ray<T, METHOD, ISO>(a, k, r, i);
         until = RECORD ? a.stride - (i % a.stride) : 0;  // steps until the next recorded row
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(256, LDS ? 2 : 3) void k_advance(BatchDev<T> a, int
         if (__ballot(alive) == 0ull) break;
         const bool active = alive;
         ++i;
-        const bool inside = rt::ray_step<T, METHOD, ISO>(a.F, a.K, gather, active, r, i);
+        const bool inside = rt::ray_step<T, METHOD, ISO>(a.F, K, gather, active, r, i);
         if (active) {
             if (RECORD) {
                 if (--until == 0) {
@@ -506,7 +512,7 @@ __global__ __launch_bounds__(256, LDS ? 2 : 3) void k_advance(BatchDev<T> a, int
                     if (row < a.rec_rows) write_row(a, row, k, r);
                 }
             }
-            alive = inside && (i + 1 < a.max_size);
+            alive = inside && (i + 1 < max_size);
             if (!alive) store_ray<T, METHOD>(a, k, r, i, false);
         }
     }
@@ -580,6 +586,8 @@ __global__ __launch_bounds__(256, 2) void k_trace_refill(BatchDev<T> a, int refi
     }
 }
 
+template <typename T> __device__ __forceinline__ int max_size_of(const BatchDev<T>& a, long k) { return a.vmax ? a.vmax[k] : a.max_size; }
+
 // index of slot k's ray in the caller's order
 template <typename T> __device__ __forceinline__ long out_index(const BatchDev<T>& a, long k) { return a.perm ? (long)a.perm[k] : k; }
 
@@ -619,6 +627,8 @@ struct rtmi_batch {
     bool own_s = false, own_n = false;
     double* launch = nullptr;    // [3][R] x0, y0, theta0 (slot order)
     int* perm = nullptr;         // device [R] when sort_rays
+    void *vstep = nullptr, *vstep2h = nullptr;   // device [R] dtype: per-ray DELTA_S, DELTA_S**2/2 (set_per_ray)
+    int* vmax = nullptr;         // device [R]: per-ray max_size
     unsigned long long* counters = nullptr;  // device [2]
     unsigned long long* h_counters = nullptr;  // pinned host [2]
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -651,30 +661,41 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     a.counters = b->counters;
     a.x0 = b->launch; a.y0 = b->launch + R; a.th0 = b->launch + 2 * R;
     a.perm = b->perm;
+    a.vstep = (const T*)b->vstep; a.vstep2h = (const T*)b->vstep2h; a.vmax = b->vmax;
     return a;
 }
 
 // kernel variant tables: [method][iso][lds].  Anisotropic-only methods (op10/op11) have no ISO build.
-#define RTMI_VARIANTS_(K, T, M) \
-    {{(const void*)K<T, M, false, false>, (const void*)K<T, M, false, true>}, \
-     {(const void*)K<T, (M < 10 ? M : 1), (M < 10), false>, (const void*)K<T, (M < 10 ? M : 1), (M < 10), true>}}
+#define RTMI_ADV_(T, M) \
+    {{(const void*)k_advance<T, M, false, false, false>, (const void*)k_advance<T, M, false, true, false>}, \
+     {(const void*)k_advance<T, (M < 10 ? M : 1), (M < 10), false, false>, (const void*)k_advance<T, (M < 10 ? M : 1), (M < 10), true, false>}}
+#define RTMI_ADVVAR_(T, M) \
+    {(const void*)k_advance<T, M, false, false, true>, (const void*)k_advance<T, (M < 10 ? M : 1), (M < 10), false, true>}
+#define RTMI_REFILL_(T, M) \
+    {{(const void*)k_trace_refill<T, M, false, false>, (const void*)k_trace_refill<T, M, false, true>}, \
+     {(const void*)k_trace_refill<T, (M < 10 ? M : 1), (M < 10), false>, (const void*)k_trace_refill<T, (M < 10 ? M : 1), (M < 10), true>}}
 template <typename T> static const void* advance_fn(int m, bool iso, bool lds) {
-    static const void* const tab[11][2][2] = {
-        RTMI_VARIANTS_(k_advance, T, 1), RTMI_VARIANTS_(k_advance, T, 2), RTMI_VARIANTS_(k_advance, T, 3),
-        RTMI_VARIANTS_(k_advance, T, 4), RTMI_VARIANTS_(k_advance, T, 5), RTMI_VARIANTS_(k_advance, T, 6),
-        RTMI_VARIANTS_(k_advance, T, 7), RTMI_VARIANTS_(k_advance, T, 8), RTMI_VARIANTS_(k_advance, T, 9),
-        RTMI_VARIANTS_(k_advance, T, 10), RTMI_VARIANTS_(k_advance, T, 11)};
+    static const void* const tab[11][2][2] = {RTMI_ADV_(T, 1), RTMI_ADV_(T, 2), RTMI_ADV_(T, 3), RTMI_ADV_(T, 4),
+                                              RTMI_ADV_(T, 5), RTMI_ADV_(T, 6), RTMI_ADV_(T, 7), RTMI_ADV_(T, 8),
+                                              RTMI_ADV_(T, 9), RTMI_ADV_(T, 10), RTMI_ADV_(T, 11)};
     return tab[m - 1][iso ? 1 : 0][lds ? 1 : 0];
+}
+// per-ray DELTA_S / max_size builds (global gather only): [method][iso]
+template <typename T> static const void* advance_var_fn(int m, bool iso) {
+    static const void* const tab[11][2] = {RTMI_ADVVAR_(T, 1), RTMI_ADVVAR_(T, 2), RTMI_ADVVAR_(T, 3), RTMI_ADVVAR_(T, 4),
+                                           RTMI_ADVVAR_(T, 5), RTMI_ADVVAR_(T, 6), RTMI_ADVVAR_(T, 7), RTMI_ADVVAR_(T, 8),
+                                           RTMI_ADVVAR_(T, 9), RTMI_ADVVAR_(T, 10), RTMI_ADVVAR_(T, 11)};
+    return tab[m - 1][iso ? 1 : 0];
 }
 template <typename T> static const void* refill_fn(int m, bool iso, bool lds) {
-    static const void* const tab[11][2][2] = {
-        RTMI_VARIANTS_(k_trace_refill, T, 1), RTMI_VARIANTS_(k_trace_refill, T, 2), RTMI_VARIANTS_(k_trace_refill, T, 3),
-        RTMI_VARIANTS_(k_trace_refill, T, 4), RTMI_VARIANTS_(k_trace_refill, T, 5), RTMI_VARIANTS_(k_trace_refill, T, 6),
-        RTMI_VARIANTS_(k_trace_refill, T, 7), RTMI_VARIANTS_(k_trace_refill, T, 8), RTMI_VARIANTS_(k_trace_refill, T, 9),
-        RTMI_VARIANTS_(k_trace_refill, T, 10), RTMI_VARIANTS_(k_trace_refill, T, 11)};
+    static const void* const tab[11][2][2] = {RTMI_REFILL_(T, 1), RTMI_REFILL_(T, 2), RTMI_REFILL_(T, 3), RTMI_REFILL_(T, 4),
+                                              RTMI_REFILL_(T, 5), RTMI_REFILL_(T, 6), RTMI_REFILL_(T, 7), RTMI_REFILL_(T, 8),
+                                              RTMI_REFILL_(T, 9), RTMI_REFILL_(T, 10), RTMI_REFILL_(T, 11)};
     return tab[m - 1][iso ? 1 : 0][lds ? 1 : 0];
 }
-#undef RTMI_VARIANTS_
+#undef RTMI_ADV_
+#undef RTMI_ADVVAR_
+#undef RTMI_REFILL_
 // field_path 0 (auto): the LDS tile pays when the step loop also streams trajectory rows (its lookups then stay off
 // the vector-memory queue the stores occupy: 27.0 vs 29.0 ms at full record); without dense recording the plain
 // gather is ahead (18.9 vs 20.3 ms) because the kernel is VALU-bound and the tile costs ~25 integer instructions.
@@ -685,6 +706,7 @@ static bool use_lds_tile(const rtmi_batch* b) {
 }
 static const void* pick_advance(const rtmi_batch* b) {
     const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
+    if (b->vstep) return b->p.dtype == RTMI_F64 ? advance_var_fn<double>(b->p.method, iso) : advance_var_fn<float>(b->p.method, iso);
     return b->p.dtype == RTMI_F64 ? advance_fn<double>(b->p.method, iso, lds) : advance_fn<float>(b->p.method, iso, lds);
 }
 static const void* pick_refill(const rtmi_batch* b) {
@@ -714,6 +736,7 @@ RTMI_EXPORT void rtmi_batch_destroy(rtmi_batch* b) {
     (void)hipStreamSynchronize(b->stream);
     (void)hipFree(b->state); (void)hipFree(b->istep); (void)hipFree(b->alive); (void)hipFree(b->launch);
     (void)hipFree(b->perm);
+    (void)hipFree(b->vstep); (void)hipFree(b->vstep2h); (void)hipFree(b->vmax);
     (void)hipFree(b->counters);
     if (b->h_counters) (void)hipHostFree(b->h_counters);
     if (b->own_s) (void)hipFree(b->s_ray);
@@ -815,6 +838,59 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     return RTMI_OK;
 }
 
+template <typename T>
+__global__ void k_set_per_ray(BatchDev<T> a, const double* step, const double* step2h, const int* ms, T* vstep, T* vstep2h, int* vmax) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.R) return;
+    const long o = out_index(a, k);
+    vstep[k] = (T)step[o]; vstep2h[k] = (T)step2h[o]; vmax[k] = ms[o];
+    a.alive[k] = a.istep[k] + 1 < ms[o];
+}
+
+RTMI_EXPORT int rtmi_batch_set_per_ray(rtmi_batch* b, const double* step, const int32_t* max_size) {
+    ARG_TRY(b && step && max_size, "rtmi_batch_set_per_ray: null");
+    ARG_TRY(b->p.launch_mode == 0, "rtmi_batch_set_per_ray: per-ray steps run on the one-lane-per-ray kernel (launch_mode 0)");
+    const size_t R = (size_t)b->R;
+    std::vector<double> h2;
+    try {
+        h2.resize(R);
+    } catch (const std::exception& e) {
+        return fail(RTMI_ERR_ALLOC, std::string("rtmi_batch_set_per_ray: ") + e.what());
+    }
+    for (size_t k = 0; k < R; k++) {
+        ARG_TRY(step[k] > 0 && std::isfinite(step[k]), "rtmi_batch_set_per_ray: every step must be finite and > 0");
+        ARG_TRY(max_size[k] >= (b->p.method == 7 ? 4 : 2) && max_size[k] <= b->p.max_size,
+                "rtmi_batch_set_per_ray: every max_size must be in [2 (4 for op7), params.max_size]");
+        h2[k] = std::pow(step[k], 2.0) / 2.0;   // numpy scalar step**2 (:330)
+    }
+    if (!b->vstep) {
+        HIP_TRY(hipMalloc(&b->vstep, R * b->esz));
+        HIP_TRY(hipMalloc(&b->vstep2h, R * b->esz));
+        HIP_TRY(hipMalloc(&b->vmax, R * sizeof(int)));
+    }
+    double* d = nullptr;
+    int* di = nullptr;
+    HIP_TRY(hipMalloc(&d, 2 * R * sizeof(double)));
+    hipError_t e = hipMalloc(&di, R * sizeof(int));
+    if (e == hipSuccess) e = hipMemcpyAsync(d, step, R * 8, hipMemcpyHostToDevice, b->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d + R, h2.data(), R * 8, hipMemcpyHostToDevice, b->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(di, max_size, R * sizeof(int), hipMemcpyHostToDevice, b->stream);
+    if (e == hipSuccess) {
+        const dim3 g((unsigned)((R + 255) / 256)), blk(256);
+        if (b->p.dtype == RTMI_F64)
+            hipLaunchKernelGGL(k_set_per_ray<double>, g, blk, 0, b->stream, batch_dev<double>(b), d, d + R, di, (double*)b->vstep, (double*)b->vstep2h, b->vmax);
+        else
+            hipLaunchKernelGGL(k_set_per_ray<float>, g, blk, 0, b->stream, batch_dev<float>(b), d, d + R, di, (float*)b->vstep, (float*)b->vstep2h, b->vmax);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    (void)hipFree(d);
+    (void)hipFree(di);
+    if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_batch_set_per_ray: ") + hipGetErrorString(e));
+    b->kfn = pick_advance(b);
+    return RTMI_OK;
+}
+
 RTMI_EXPORT int rtmi_batch_reset(rtmi_batch* b) {
     ARG_TRY(b, "rtmi_batch_reset: null");
     return batch_init_state(b, b->dirty);
@@ -830,7 +906,7 @@ template <typename T> __global__ void k_set_state(BatchDev<T> a, const double* s
     if (a.hist && hist)
         for (int q = 0; q < 4; q++) a.hist[(size_t)q * a.R + k] = (T)hist[(size_t)q * a.R + o];
     if (istep) a.istep[k] = istep[o];
-    a.alive[k] = a.istep[k] + 1 < a.max_size;
+    a.alive[k] = a.istep[k] + 1 < max_size_of(a, k);
 }
 
 RTMI_EXPORT int rtmi_batch_set_state(rtmi_batch* b, const double* state9, const double* hist4, const int32_t* istep) {
@@ -1065,7 +1141,7 @@ template <typename T> __global__ void k_metric_closure(BatchDev<T> a, double* ou
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.R) return;
     // s_ray[-1, 0:2, k]: the last row of the array -- written only if the ray ran all max_size-1 steps
-    const bool full = a.istep[k] == a.max_size - 1;
+    const bool full = a.istep[k] == max_size_of(a, k) - 1;
     const double dx = 1.0 - (full ? (double)a.x[k] : 0.0), dy = 0.0 - (full ? (double)a.y[k] : 0.0);
     out[out_index(a, k)] = 100 * sqrt(fma(dy, dy, dx * dx)) / (2 * M_PI);
 }

@@ -308,6 +308,12 @@ class Batch:
         i = np.ascontiguousarray(istep, dtype=np.int32) if istep is not None else None
         check(lib().rtmi_batch_set_state(self._h, dptr(st), dptr(h), i.ctypes.data_as(_lib._ip) if i is not None else None))
 
+    def set_per_ray(self, step, max_size):
+        """Per-ray DELTA_S and max_size ([R] each, caller's ray order): rtmi_batch_set_per_ray."""
+        st = np.ascontiguousarray(np.broadcast_to(np.asarray(step, dtype=np.float64), (self.R,)))
+        ms = np.ascontiguousarray(np.broadcast_to(np.asarray(max_size, dtype=np.int32), (self.R,)))
+        check(lib().rtmi_batch_set_per_ray(self._h, dptr(st), ms.ctypes.data_as(_lib._ip)))
+
     def reset(self):
         check(lib().rtmi_batch_reset(self._h))
 
@@ -550,30 +556,46 @@ def delta_s_candidates(user_choice):
     return divisors, SIGMA / divisors
 
 
-def search_delta_sweep(option, z, grd, delta_s_options, divisors, user_choice):
+def search_delta_sweep(option, z, grd, delta_s_options, divisors, user_choice, batched=True):
     """What executor.map(search_delta, ...) returns (RT_bench.py:1317-1318): one entry per DELTA_S candidate --
     (mean, max) exit-angle error for interface, closure % for fisheye, mean p_x CV (%) for the vert scenarios
-    (the reference returns the p_x history there and reduces it at :1354-1360; the reduction runs on the device)."""
+    (the reference returns the p_x history there and reduces it at :1354-1360; the reduction runs on the device).
+
+    batched=True runs the whole sweep as ONE candidate x ray batch (every ray carries its candidate's DELTA_S and
+    max_size, rtmi_batch_set_per_ray) followed by one device metric; batched=False runs one small batch per
+    candidate.  Both give the same bits per ray."""
     c = constants(user_choice)
     g, ray_count, theta_v, pos_x, s, xi, xs, yi, ys, op_if, op_fish, _, _ = c
     fld = _field_of(z, grd)
-    out = []
-    for step, divisor in zip(delta_s_options, np.asarray(divisors) + 1):
-        step = float(step)
-        max_size = int(N * divisor) if op_fish else int(np.ceil(s / step) + 1)
-        x0, y0 = (float(pos_x[0]), float(pos_x[1])) if op_fish else (np.asarray(pos_x, float)[:ray_count], -2.0)
-        b = Batch(fld, option, step, max_size, (xi, xs, yi, ys), g, theta_v[:ray_count], x0, y0,
-                  record_stride=0 if op_fish else 1)
-        b.run()
+    steps = [float(v) for v in delta_s_options]
+    sizes = [int(N * d) if op_fish else int(np.ceil(s / st) + 1) for st, d in zip(steps, np.asarray(divisors) + 1)]
+    th = np.asarray(theta_v, dtype=np.float64)[:ray_count]
+    x0, y0 = (float(pos_x[0]), float(pos_x[1])) if op_fish else (np.asarray(pos_x, float)[:ray_count], -2.0)
+    stride = 0 if op_fish else 1
+    kind = "snell" if op_if else ("closure" if op_fish else "px_cv")
+
+    def reduce_(m):
         if op_if:
-            e = b.metric("snell")
-            out.append((np.mean(e), np.max(e)))
-        elif op_fish:
-            out.append(b.metric("closure")[0])
-        else:
-            out.append(np.mean(b.metric("px_cv")[1:ray_count - 1]))
-        b.close()
-    return out
+            return (np.mean(m), np.max(m))
+        return m[0] if op_fish else np.mean(m[1:ray_count - 1])
+
+    if not batched:
+        out = []
+        for st, ms in zip(steps, sizes):
+            b = Batch(fld, option, st, ms, (xi, xs, yi, ys), g, th, x0, y0, record_stride=stride)
+            b.run()
+            out.append(reduce_(b.metric(kind)))
+            b.close()
+        return out
+    nc = len(steps)
+    b = Batch(fld, option, steps[0], max(sizes), (xi, xs, yi, ys), g, np.tile(th, nc),
+              np.tile(np.broadcast_to(x0, (ray_count,)), nc), np.tile(np.broadcast_to(y0, (ray_count,)), nc),
+              record_stride=stride)
+    b.set_per_ray(np.repeat(steps, ray_count), np.repeat(sizes, ray_count))
+    b.run()
+    m = b.metric(kind).reshape(nc, ray_count)
+    b.close()
+    return [reduce_(m[i]) for i in range(nc)]
 
 
 def find_divisor(results, divisors, user_choice, max_deviation=None):

@@ -492,7 +492,9 @@ def test_delta_s_sweep_vs_reference(scen, rb, gpu_fields):
     div, opt = rb.delta_s_candidates(choice)
     assert np.array_equal(div, g["all_divisors"]) and np.array_equal(opt, g["all_options"])
     sel = g["sel"]
-    res = rb.search_delta_sweep(rb.op6, gpu_fields(scen), None, opt[sel], div[sel], choice)
+    res = rb.search_delta_sweep(rb.op6, gpu_fields(scen), None, opt[sel], div[sel], choice)           # one batch
+    seq = rb.search_delta_sweep(rb.op6, gpu_fields(scen), None, opt[sel], div[sel], choice, batched=False)
+    assert np.array_equal(np.array(res), np.array(seq))       # candidate x ray batch == one batch per candidate
     ref = g["results"]
     if scen == "interface":
         assert np.abs(np.array(res) - ref).max() < 1e-6           # degrees (mean, max)
@@ -750,3 +752,47 @@ def test_small_custom_grids_vs_oracle(qx, qy, rb):
             assert same.mean() > 0.98
             assert relerr(fin[:, same], o["final"][:, same]) < 1e-8      # noisy Z: gradients are O(1) per cell
     F.close()
+
+
+def test_per_ray_step_batch_equals_separate_batches(rb, gpu_fields):
+    """rtmi_batch_set_per_ray: rays of one batch with different DELTA_S / max_size are bit-identical to the same
+    rays traced in separate uniform batches (rows, d_ray, final state), also after reset and with sort_rays."""
+    F = gpu_fields("vert_heterogeneous")
+    lim = LIMITS["vert_heterogeneous"]
+    th = np.linspace(0.1, 1.4, 40)
+    cands = [(rb.DELTA_S, 700), (0.01, 300), (0.05, 60)]
+    ref = []
+    for st, ms in cands:
+        b = rb.Batch(F, 7, st, ms, lim, 1, th, -2.0, -2.0, record_stride=1, rec_rows=700)
+        b.run()
+        ref.append((b.d_ray(), b.final(), b.rows()))
+        b.close()
+    for srt in (False, True):
+        b = rb.Batch(F, 7, cands[0][0], 700, lim, 1, np.tile(th, 3), -2.0, -2.0, record_stride=1, sort_rays=srt)
+        b.set_per_ray(np.repeat([c[0] for c in cands], 40), np.repeat([c[1] for c in cands], 40))
+        for attempt in range(2):
+            b.run()
+            d, fin, rows = b.d_ray(), b.final(), b.rows()
+            for i in range(3):
+                sl = slice(40 * i, 40 * (i + 1))
+                assert np.array_equal(d[:, sl], ref[i][0]) and np.array_equal(fin[:, sl], ref[i][1])
+                assert np.array_equal(rows[:, :, sl], ref[i][2])
+            b.reset()
+        b.close()
+    from raytracing_amd._lib import RtmiError
+    b = rb.Batch(F, 6, rb.DELTA_S, 100, lim, 1, th, -2.0, -2.0, record_stride=0)
+    with pytest.raises(RtmiError, match="max_size"):
+        b.set_per_ray(0.01, 101)
+    b.close()
+
+
+def test_full_calibration_reproduces_reference_table(rb, gpu_fields):
+    """The whole DELTA_S search as one candidate x ray launch, op6: the divisor the find_index rules pick must be
+    the calibrated value the reference hard-codes -- SIGMA/2.55 for the interface (RT_bench.py:1424) and 182
+    segments for the fisheye's 5 % closure set (comment at :1444)."""
+    div, opt = rb.delta_s_candidates("1")
+    res = rb.search_delta_sweep(rb.op6, gpu_fields("interface"), None, opt, div, "1")
+    assert len(res) == 200 and rb.find_divisor(res, div, "1") == 2.55
+    div, opt = rb.delta_s_candidates("2")
+    res = rb.search_delta_sweep(rb.op6, gpu_fields("fisheye"), None, opt, div, "2")
+    assert len(res) == 300 and rb.find_divisor(res, div, "2") == 182
