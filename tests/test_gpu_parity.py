@@ -786,13 +786,22 @@ def test_per_ray_step_batch_equals_separate_batches(rb, gpu_fields):
     b.close()
 
 
-def test_full_calibration_reproduces_reference_table(rb, gpu_fields):
-    """The whole DELTA_S search as one candidate x ray launch, op6: the divisor the find_index rules pick must be
-    the calibrated value the reference hard-codes -- SIGMA/2.55 for the interface (RT_bench.py:1424) and 182
-    segments for the fisheye's 5 % closure set (comment at :1444)."""
-    div, opt = rb.delta_s_candidates("1")
-    res = rb.search_delta_sweep(rb.op6, gpu_fields("interface"), None, opt, div, "1")
-    assert len(res) == 200 and rb.find_divisor(res, div, "1") == 2.55
-    div, opt = rb.delta_s_candidates("2")
-    res = rb.search_delta_sweep(rb.op6, gpu_fields("fisheye"), None, opt, div, "2")
-    assert len(res) == 300 and rb.find_divisor(res, div, "2") == 182
+CALIBRATED = {"1": {1: 38.64, 2: 38.37, 3: 2.34, 4: 2.53, 5: 2.53, 6: 2.55, 7: 30.05, 8: 2.74, 9: 2.74},      # :1413-1430
+              "2": {1: 149, 2: 169, 3: 182, 4: 179, 5: 179, 6: 182, 7: 191, 8: 179, 9: 179}}                   # :1444 (5 % set)
+
+
+@pytest.mark.parametrize("choice,m", [(c, m) for c in ("1", "2") for m in range(1, 10)])
+def test_full_calibration_reproduces_reference_table(choice, m, rb, gpu_fields):
+    """The whole DELTA_S search (RT_bench.py:1296-1385) as one candidate x ray launch, for every isotropic method:
+    the divisor the find_index rules pick must be the calibrated value the reference hard-codes -- the interface
+    table at :1413-1430 and the fisheye's 5 %-closure set quoted at :1444.  For interface op1/op2/op7 the reference
+    says the search interval has to be narrowed around the recorded value (:1415-1420); +-1 is used here."""
+    scen = {"1": "interface", "2": "fisheye"}[choice]
+    want = CALIBRATED[choice][m]
+    div, opt = rb.delta_s_candidates(choice)
+    if choice == "1" and m in (1, 2, 7):
+        div = np.arange(want + 1.0, want - 1.0 - rb.DELTA_STEP, -rb.DELTA_STEP)
+        opt = rb.SIGMA / div
+    res = rb.search_delta_sweep(rb.METHODS[m], gpu_fields(scen), None, opt, div, choice)
+    assert len(res) == len(div)
+    assert rb.find_divisor(res, div, choice) == want
