@@ -888,6 +888,7 @@ RTMI_EXPORT int rtmi_batch_set_per_ray(rtmi_batch* b, const double* step, const 
     (void)hipFree(di);
     if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_batch_set_per_ray: ") + hipGetErrorString(e));
     b->kfn = pick_advance(b);
+    b->dirty = true;   // rows written under the previous steps would no longer be rewritten: clear on the next reset
     return RTMI_OK;
 }
 
