@@ -805,3 +805,12 @@ def test_full_calibration_reproduces_reference_table(choice, m, rb, gpu_fields):
     res = rb.search_delta_sweep(rb.METHODS[m], gpu_fields(scen), None, opt, div, choice)
     assert len(res) == len(div)
     assert rb.find_divisor(res, div, choice) == want
+
+
+def test_benchmark_statistic_runs(rb, gpu_fields):
+    """rt_bench.benchmark: the reference's protocol (:1516-1541 -- rounds of runs, IQR filter, median of the last
+    30 %, stop when two successive medians agree to 0.5 %) over device propagation times of the preset batch."""
+    F = gpu_fields("vert_heterogeneous")
+    z, grd = rb.FieldSpline(F, "n"), (rb.FieldSpline(F, "dy"), rb.FieldSpline(F, "dx"))
+    t = rb.benchmark(rb.op6, z, grd, rb.DELTA_S, 91, "3", trial=8, replicas=2, max_rounds=6)
+    assert 1e-5 < t < 0.5          # 31 rays, ~2 900 sequential steps: a few milliseconds of device time
