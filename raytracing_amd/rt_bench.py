@@ -290,6 +290,10 @@ class Batch:
             p.box[i] = float(box[i])
         p.launch_mode = int(launch_mode); p.block_size = int(block_size); p.refill_min = int(refill_min)
         p.exact_basis = int(exact_basis); p.field_path = int(field_path)
+        if isinstance(sort_rays, str):
+            if sort_rays != "auto":
+                raise ValueError("sort_rays must be True, False or 'auto'")
+            sort_rays = not launch_is_coherent(x0, y0, th)
         p.sort_rays = int(bool(sort_rays))
         p.ext_s_ray = ext_s_ray; p.ext_n_ray = ext_n_ray
         self.params = p
@@ -403,6 +407,26 @@ class Batch:
             pass
 
 
+def launch_is_coherent(x0, y0, theta, group=64):
+    """True when consecutive rays already travel together (sorted fans do): within most groups of `group`
+    consecutive rays the launch points coincide to a fraction of a cell and the angles span no more than a few
+    times the batch's mean angular spacing per group.  Used by sort_rays="auto"."""
+    th = np.asarray(theta, dtype=np.float64)
+    R = len(th)
+    if R < 2 * group:
+        return True
+    n = (R // group) * group
+    g = th[:n].reshape(-1, group)
+    with np.errstate(invalid="ignore"):
+        spread = np.nanmax(g, axis=1) - np.nanmin(g, axis=1)
+        total = np.nanmax(th) - np.nanmin(th)
+    fair = 8.0 * total * group / R + 1e-12
+    xs = np.asarray(x0, dtype=np.float64)[:n].reshape(-1, group)
+    ys = np.asarray(y0, dtype=np.float64)[:n].reshape(-1, group)
+    same_origin = (np.ptp(xs, axis=1) < DELTA) & (np.ptp(ys, axis=1) < DELTA)
+    return bool(np.mean((spread <= fair) & same_origin) > 0.75)
+
+
 def max_rows(user_choice, step, divisor):
     """max_size of trazar (:796-799)."""
     c = constants(user_choice)
@@ -490,7 +514,8 @@ def trazar(selected_func, z, grd, show, step, divisor, user_choice, *, thetas=No
     if max_size is None:
         max_size = N * divisor if op_fish else int(np.ceil(s / step) + 1)   # :796-799
     stride = 0 if record is None else (1 if record == "full" else int(record))
-    b = Batch(fld, selected_func, step, max_size, box, gamma, theta_v[:ray_count], x0, y0, record_stride=stride)
+    b = Batch(fld, selected_func, step, max_size, box, gamma, theta_v[:ray_count], x0, y0, record_stride=stride,
+              sort_rays="auto")
     t1 = time.perf_counter()
     b.run()
     b.sync()

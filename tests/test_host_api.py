@@ -92,3 +92,15 @@ def test_find_divisor_rules():
     assert rb.find_divisor([0.01, 0.02, 0.03, 0.06, 0.07], div, "3") == 2.8      # first CV above 0.05 % at i=3 -> i-1
     x = np.array([1.0, 1.1, 0.9, 1.05, 5.0, 0.95])
     assert 5.0 not in rb.remove_outliers_iqr(x) and len(rb.remove_outliers_iqr(x)) == 5
+
+
+def test_launch_coherence_heuristic():
+    """sort_rays="auto": sorted fans are left alone, shuffled or multi-origin batches get sorted."""
+    fan = np.linspace(0, np.pi / 2, 4096)
+    assert rb.launch_is_coherent(-2.0 * np.ones(4096), -2.0 * np.ones(4096), fan)
+    assert rb.launch_is_coherent(np.ones(31), np.zeros(31), np.linspace(0, 1, 31))          # small batches: never sorted
+    rng = np.random.default_rng(0)
+    assert not rb.launch_is_coherent(-2.0 * np.ones(4096), -2.0 * np.ones(4096), rng.permutation(fan))
+    assert not rb.launch_is_coherent(rng.uniform(-2, 5, 4096), -2.0 * np.ones(4096), fan)   # scattered origins
+    blocks = np.repeat(np.array([-2.0, 0.0, 3.0, 4.0]), 1024)                                # fans from 4 origins, in blocks
+    assert rb.launch_is_coherent(blocks, -2.0 * np.ones(4096), np.tile(np.linspace(0, 1, 1024), 4))
