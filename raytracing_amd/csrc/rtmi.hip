@@ -378,8 +378,12 @@ template <typename T> struct BatchDev {
     int stride;       // record stride (0 = none)
     long rec_rows;
     // SoA state
-    T *x, *y, *th, *n, *gx, *gy, *dsim, *dreal, *tt;
-    T* hist;          // [4][R] (op7 only): hx0, hy0, hx1, hy1
+    // SoA state: ONE slab pointer (arrays x, y, theta, n, gx, gy, dist_sim, dist_real, T, then op7's four history
+    // arrays, each [R]); the per-array pointers are formed where they are used so that the step loop keeps two
+    // scalar registers live instead of twenty
+    T* st;
+    int has_hist;     // op7 only: hx0, hy0, hx1, hy1 follow the nine state arrays
+    __device__ __forceinline__ T* arr(int q) const { return st + (size_t)q * R; }
     int* istep;
     unsigned char* alive;
     T *s_ray, *n_ray;
@@ -406,9 +410,9 @@ template <typename T> __global__ void k_init(BatchDev<T> a) {
     rt::n_gradient(a.F, gg, true, r.x, r.y, r.n, r.gx, r.gy);
     rt::derive<T, false>(a.K, r);
     r.dsim = 0; r.dreal = 0; r.tt = 0;
-    a.x[k] = r.x; a.y[k] = r.y; a.th[k] = r.th; a.n[k] = r.n; a.gx[k] = r.gx; a.gy[k] = r.gy;
-    a.dsim[k] = 0; a.dreal[k] = 0; a.tt[k] = 0;
-    if (a.hist) { a.hist[k] = 0; a.hist[a.R + k] = 0; a.hist[2 * a.R + k] = 0; a.hist[3 * a.R + k] = 0; }
+    a.arr(0)[k] = r.x; a.arr(1)[k] = r.y; a.arr(2)[k] = r.th; a.arr(3)[k] = r.n; a.arr(4)[k] = r.gx; a.arr(5)[k] = r.gy;
+    a.arr(6)[k] = 0; a.arr(7)[k] = 0; a.arr(8)[k] = 0;
+    if (a.has_hist) { a.arr(9)[k] = 0; a.arr(10)[k] = 0; a.arr(11)[k] = 0; a.arr(12)[k] = 0; }
     a.istep[k] = 0;
     a.alive[k] = max_size_of(a, k) > 1;
     if (a.stride && a.rec_rows > 0) write_row(a, 0, k, r);
@@ -439,18 +443,18 @@ __global__ void k_stats(const int* istep, const unsigned char* alive, long R, un
 
 template <typename T, int METHOD, bool ISO>
 __device__ __forceinline__ void load_ray(const BatchDev<T>& a, long k, rt::Ray<T>& r, int& i) {
-    r.x = a.x[k]; r.y = a.y[k]; r.th = a.th[k]; r.n = a.n[k]; r.gx = a.gx[k]; r.gy = a.gy[k];
-    r.dsim = a.dsim[k]; r.dreal = a.dreal[k]; r.tt = a.tt[k];
-    if (METHOD == 7) { r.hx0 = a.hist[k]; r.hy0 = a.hist[a.R + k]; r.hx1 = a.hist[2 * a.R + k]; r.hy1 = a.hist[3 * a.R + k]; }
+    r.x = a.arr(0)[k]; r.y = a.arr(1)[k]; r.th = a.arr(2)[k]; r.n = a.arr(3)[k]; r.gx = a.arr(4)[k]; r.gy = a.arr(5)[k];
+    r.dsim = a.arr(6)[k]; r.dreal = a.arr(7)[k]; r.tt = a.arr(8)[k];
+    if (METHOD == 7) { r.hx0 = a.arr(9)[k]; r.hy0 = a.arr(10)[k]; r.hx1 = a.arr(11)[k]; r.hy1 = a.arr(12)[k]; }
     else { r.hx0 = r.hy0 = r.hx1 = r.hy1 = 0; }
     rt::derive<T, ISO>(a.K, r);
     i = a.istep[k];
 }
 template <typename T, int METHOD>
 __device__ __forceinline__ void store_ray(const BatchDev<T>& a, long k, const rt::Ray<T>& r, int i, bool alive) {
-    a.x[k] = r.x; a.y[k] = r.y; a.th[k] = r.th; a.n[k] = r.n; a.gx[k] = r.gx; a.gy[k] = r.gy;
-    a.dsim[k] = r.dsim; a.dreal[k] = r.dreal; a.tt[k] = r.tt;
-    if (METHOD == 7) { a.hist[k] = r.hx0; a.hist[a.R + k] = r.hy0; a.hist[2 * a.R + k] = r.hx1; a.hist[3 * a.R + k] = r.hy1; }
+    a.arr(0)[k] = r.x; a.arr(1)[k] = r.y; a.arr(2)[k] = r.th; a.arr(3)[k] = r.n; a.arr(4)[k] = r.gx; a.arr(5)[k] = r.gy;
+    a.arr(6)[k] = r.dsim; a.arr(7)[k] = r.dreal; a.arr(8)[k] = r.tt;
+    if (METHOD == 7) { a.arr(9)[k] = r.hx0; a.arr(10)[k] = r.hy0; a.arr(11)[k] = r.hx1; a.arr(12)[k] = r.hy1; }
     a.istep[k] = i;
     a.alive[k] = alive;
 }
@@ -595,13 +599,13 @@ template <typename T> __global__ void k_pack_d_ray(BatchDev<T> a, double* out) {
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.R) return;
     const long o = out_index(a, k);
-    out[o] = (double)a.dreal[k]; out[a.R + o] = (double)a.dsim[k]; out[2 * a.R + o] = (double)a.istep[k];  // :888-890
+    out[o] = (double)a.arr(7)[k]; out[a.R + o] = (double)a.arr(6)[k]; out[2 * a.R + o] = (double)a.istep[k];  // :888-890
 }
 template <typename T> __global__ void k_pack_final(BatchDev<T> a, double* out) {
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.R) return;
     rt::Ray<T> r;
-    r.x = a.x[k]; r.y = a.y[k]; r.th = a.th[k]; r.n = a.n[k]; r.gx = a.gx[k]; r.gy = a.gy[k]; r.tt = a.tt[k];
+    r.x = a.arr(0)[k]; r.y = a.arr(1)[k]; r.th = a.arr(2)[k]; r.n = a.arr(3)[k]; r.gx = a.arr(4)[k]; r.gy = a.arr(5)[k]; r.tt = a.arr(8)[k];
     rt::derive<T, false>(a.K, r);
     const double v[9] = {(double)r.x, (double)r.y, (double)r.th, (double)r.n, (double)r.gx, (double)r.gy,
                          (double)r.mx, (double)r.my, (double)r.tt};
@@ -653,9 +657,7 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     a.R = b->R; a.max_size = p.max_size; a.stride = p.record_stride; a.rec_rows = p.rec_rows;
     T* s = (T*)b->state;
     const size_t R = (size_t)b->R;
-    a.x = s; a.y = s + R; a.th = s + 2 * R; a.n = s + 3 * R; a.gx = s + 4 * R; a.gy = s + 5 * R;
-    a.dsim = s + 6 * R; a.dreal = s + 7 * R; a.tt = s + 8 * R;
-    a.hist = p.method == 7 ? s + 9 * R : nullptr;
+    a.st = s; a.has_hist = p.method == 7;
     a.istep = b->istep; a.alive = b->alive;
     a.s_ray = (T*)b->s_ray; a.n_ray = (T*)b->n_ray;
     a.counters = b->counters;
@@ -900,12 +902,11 @@ RTMI_EXPORT int rtmi_batch_reset(rtmi_batch* b) {
 template <typename T> __global__ void k_set_state(BatchDev<T> a, const double* st, const double* hist, const int* istep) {
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.R) return;
-    T* dst[9] = {a.x, a.y, a.th, a.n, a.gx, a.gy, a.dsim, a.dreal, a.tt};
     const long o = out_index(a, k);
 #pragma unroll
-    for (int q = 0; q < 9; q++) dst[q][k] = (T)st[(size_t)q * a.R + o];
-    if (a.hist && hist)
-        for (int q = 0; q < 4; q++) a.hist[(size_t)q * a.R + k] = (T)hist[(size_t)q * a.R + o];
+    for (int q = 0; q < 9; q++) a.arr(q)[k] = (T)st[(size_t)q * a.R + o];
+    if (a.has_hist && hist)
+        for (int q = 0; q < 4; q++) a.arr(9 + q)[k] = (T)hist[(size_t)q * a.R + o];
     if (istep) a.istep[k] = istep[o];
     a.alive[k] = a.istep[k] + 1 < max_size_of(a, k);
 }
@@ -1143,7 +1144,7 @@ template <typename T> __global__ void k_metric_closure(BatchDev<T> a, double* ou
     if (k >= a.R) return;
     // s_ray[-1, 0:2, k]: the last row of the array -- written only if the ray ran all max_size-1 steps
     const bool full = a.istep[k] == max_size_of(a, k) - 1;
-    const double dx = 1.0 - (full ? (double)a.x[k] : 0.0), dy = 0.0 - (full ? (double)a.y[k] : 0.0);
+    const double dx = 1.0 - (full ? (double)a.arr(0)[k] : 0.0), dy = 0.0 - (full ? (double)a.arr(1)[k] : 0.0);
     out[out_index(a, k)] = 100 * sqrt(fma(dy, dy, dx * dx)) / (2 * M_PI);
 }
 template <typename T> __global__ void k_metric_px_cv(BatchDev<T> a, double* out) {    // RT_bench.py:1354-1360, :1398-1402
