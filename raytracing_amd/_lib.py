@@ -4,7 +4,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtmi.so")
+# RTMI_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants in one session)
+LIB_PATH = os.environ.get("RTMI_LIB_PATH") or os.path.join(_HERE, "librtmi.so")
 
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
