@@ -89,8 +89,8 @@ def trace_step(args, rb):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--rays", type=int, default=1048576, help="rays per GPU")
     ap.add_argument("--scenario", default="vert_heterogeneous", choices=sorted(SCEN))
     ap.add_argument("--method", type=int, default=None)
