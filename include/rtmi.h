@@ -166,6 +166,11 @@ typedef struct {
 int rtmi_batch_stats(rtmi_batch *b, rtmi_stats *s);
 void rtmi_batch_destroy(rtmi_batch *b);
 
+/* Diagnostic: the library's libm-identical fp64 sin and cos (the functions op3/4/5/9/10/11 step with; they reproduce
+ * glibc 2.35's sin()/cos(), i.e. numpy's np.sin/np.cos, bit for bit for |x| < 105414350) evaluated on the device
+ * for n host values.  s[n], c[n]: host, fp64. */
+int rtmi_debug_sincos(int64_t n, const double *x, double *s, double *c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -176,6 +176,18 @@ def main():
         th = np.linspace(2 * (np.pi / 60), np.pi / 2, 17)[:16]
         d, s_ray = run_traj(R, "interface", 6, R.DELTA_S, 91, rays=(th, np.ones(16) * -2))
         save("traj_interface_op6_16", d)
+    if want("traj_interface_curv"):
+        # the curvature advancement (op3/op4/op5) on the sigmoid interface, where its conditioning is worst (round 2)
+        th = np.linspace(2 * (np.pi / 60), np.pi / 2, 17)[:16]
+        for m in (3, 4, 5):
+            d, s_ray = run_traj(R, "interface", m, R.DELTA_S, 91, rays=(th, np.ones(16) * -2))
+            save(f"traj_interface_op{m}_16", d)
+    if want("traj_fisheye_fan"):
+        # the 9-ray fisheye fan (both terminations) for every isotropic method (round 2)
+        th = np.linspace(np.pi / 4, 3 * np.pi / 4, 9)
+        for m in (1, 2, 3, 4, 5, 7, 8, 9):
+            d, s_ray = run_traj(R, "fisheye", m, 2 * np.pi / 303, 304, rays=(th, np.array((1, 0))))
+            save(f"traj_fisheye_op{m}_fan9", d)
     if want("traj_vert"):
         for m in range(1, 10):
             d, s_ray = run_traj(R, "vert_heterogeneous", m, R.DELTA_S, 91)

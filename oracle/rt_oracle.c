@@ -16,9 +16,13 @@
  * were measured against numpy 2.2.6 / scipy 1.15.3 in the build container:
  *   - np.dot / np.linalg.norm on 2-vectors round as fma(a1,b1, a0*b0)
  *     (OpenBLAS ddot tail loop) -> DOT2 below;
- *   - `x**2` on a numpy float64 scalar is libm pow(x, 2.0), not x*x -> SQ();
- *   - np.sin/np.cos/np.sqrt equal glibc's; np.arctan2 and np.exp do not
+ *   - `x**2` on a numpy float64 scalar is libm pow(x, 2.0), not x*x -> see SQ() and libm_square();
+ *   - np.sin/np.cos/np.sqrt equal glibc's sin()/cos()/sqrt(); np.arctan2 and np.exp do not
  *     (<= 1 ulp apart), so atan2-based methods match to ~1e-15, not bit for bit.
+ *     glibc's sincos() is NOT bit-identical to its sin() and cos() (0.14 % of arguments differ, FMA
+ *     build), and gcc merges sin(x), cos(x) pairs into sincos(x): the Makefile therefore passes
+ *     -fno-builtin-sin -fno-builtin-cos so that every call below is the separate libm function the
+ *     reference calls (tools/check_libm_sincos.cpp counts the difference).
  * Build with -ffp-contract=off so the compiler adds no fusions of its own.
  *
  * Third-party arithmetic restated here (absent from /root/reference):
@@ -45,7 +49,13 @@ static const double GOLD_TOL = 1.4901161193847656e-08;  /* sqrt(eps) = 2^-26, :6
 #define DELTA_G (M_PI / 2)                               /* :64 */
 static double gold_ratio(void) { return (sqrt(5.0) - 1.0) / 2.0; } /* :65 */
 
-static inline double SQ(double x) { return pow(x, 2.0); }           /* numpy scalar x**2 */
+/* numpy's scalar x**2 is libm pow(x, 2.0).  On glibc 2.35 that differs from the rounded product x*x by one ulp for
+ * ~0.09 % of arguments.  gcc folds pow(x, 2.0) into x*x, so SQ() below IS the rounded product: a known deviation
+ * from the reference, kept because the device path reproduces x*x bit for bit and not glibc's pow (measured effect:
+ * none of the reference's trajectory or single-step fixtures moves by more than 2e-13).  The one place where the
+ * reference's pow is honoured is DELTA_S**2 (:330), computed once per call through libm_square(). */
+static inline double SQ(double x) { return x * x; }
+static double libm_square(double x) { volatile double two = 2.0; return pow(x, two); }
 static inline double DOT2(double a0, double a1, double b0, double b1) {
     return fma(a1, b1, a0 * b0);                                    /* np.dot, 2 elements */
 }
@@ -436,7 +446,7 @@ static void state_init(const rto_ctx *c, rto_state *s, double x0, double y0, dou
  * the newest equals (x,y)); out[] = fx,fy,ftheta,fn,fgx,fgy */
 RTO_API void rto_single_step(const rto_field *f, int method, double gamma, double step,
                              const double *st, const double *hist, double *out) {
-    rto_ctx c = { f, method, gamma, gamma, step, pow(step, 2.0) };
+    rto_ctx c = { f, method, gamma, gamma, step, libm_square(step) };
     rto_state s; memset(&s, 0, sizeof s);
     s.x = st[0]; s.y = st[1]; s.theta = st[2]; s.n = st[3]; s.gx = st[4]; s.gy = st[5]; s.coef = st[6];
     s.ux = cos(s.theta); s.uy = sin(s.theta);
@@ -475,7 +485,7 @@ RTO_API long rto_trazar(const rto_field *f, const rto_params *p, int R, const do
 #pragma omp parallel for schedule(dynamic, 16) reduction(+ : total) num_threads(p->nthreads > 0 ? p->nthreads : 1)
 #endif
     for (int k = 0; k < R; k++) {
-        rto_ctx c = { f, p->method, p->gamma, p->gamma_step, p->step, pow(p->step, 2.0) };
+        rto_ctx c = { f, p->method, p->gamma, p->gamma_step, p->step, libm_square(p->step) };
         rto_state s;
         state_init(&c, &s, x0[k], y0[k], th0[k]);
         write_row(p, s_ray, n_ray, R, k, 0, &s);

@@ -68,6 +68,7 @@ SYMBOLS = {
     "rtmi_batch_view": (C.c_int, [C.c_void_p, C.POINTER(DeviceView)]),
     "rtmi_batch_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "rtmi_batch_destroy": (None, [C.c_void_p]),
+    "rtmi_debug_sincos": (C.c_int, [C.c_int64, _dp, _dp, _dp]),
 }
 
 _lib = None

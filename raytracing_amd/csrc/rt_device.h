@@ -452,6 +452,7 @@ template <typename T> struct Ray {
 
 template <typename T> struct Consts {
     T step, step2h;          // DELTA_S and pow(DELTA_S, 2)/2 (host-computed from numpy's step**2, :330)
+    T step2;                 // pow(DELTA_S, 2) itself (= 2*step2h exactly), for the reference-order arithmetic of rt_exact.h
     T gamma, g2m1;           // trazar's gamma, gamma**2-1 (:230)
     T gamma_s, g2m1_s;       // module-global gamma of op10/op11 (Q12)
     T box[4];
@@ -620,12 +621,27 @@ template <typename T> __device__ __forceinline__ bool outside(const Consts<T>& k
     return r.x > k.box[1] || r.x < k.box[0] || r.y > k.box[3] || r.y < k.box[2];
 }
 
+}  // namespace rt
+#include "rt_exact.h"
+namespace rt {
+
+// Methods that run in the reference's own operation order (rt_exact.h): curvature advancement and/or golden-section
+// angle search, fp64 only (the reference has no fp32).
+template <typename T, int METHOD> struct IsExact { static constexpr bool value = false; };
+template <int METHOD> struct IsExact<double, METHOD> {
+    static constexpr bool value = METHOD == 3 || METHOD == 4 || METHOD == 5 || METHOD == 9 || METHOD == 10 || METHOD == 11;
+};
+inline bool is_exact_method(int method) { return method == 3 || method == 4 || method == 5 || method >= 9; }
+
 // One iteration of trazar's loop for row index i (the row being produced); returns "still inside the box".
 // For op7 rows 1 and 2 are the bootstrap steps (:833-864): first- and second-order backward differences and
 // no boundary test.  Every lane of a wave calls this together (the gather policy may vote); `active` marks
 // the lanes whose ray is really stepping -- an idle lane just evolves a stale, finite state nobody reads.
 template <typename T, int METHOD, bool ISO, typename G>
 __device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& k, G& gather, bool active, Ray<T>& r, int i) {
+    if constexpr (IsExact<T, METHOD>::value) {
+        return ex::ray_step<METHOD>(F, k, gather, active, r);
+    } else {
     T fx, fy, fth, fn, fgx, fgy;
     const bool flag = op_advance<T, METHOD>(k, r, fx, fy);
     n_gradient(F, gather, active, fx, fy, fn, fgx, fgy);
@@ -642,6 +658,7 @@ __device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& 
     }
     store_update<T, ISO>(k, r, fx, fy, fth, fn, fgx, fgy, frn);
     return boot || !outside(k, r);
+    }
 }
 
 }  // namespace rt

@@ -1,0 +1,334 @@
+// rt_exact.h -- the step arithmetic of the methods whose results hinge on last bits, in the reference's own
+// operation order (fp64 only).  Included by rt_device.h.
+//
+// For op3/4/5/9/10/11 (curvature advancement and/or golden-section angle search) a 1-ulp difference in an
+// intermediate value can move a trajectory by 1e-8 .. 1e-6, so those methods do not use the
+// fused / reciprocal / uniform-knot forms of rt_device.h.  Everything here is written operation by operation like
+// the reference's scalar numpy code as restated in oracle/rt_oracle.c (same association, no contraction, IEEE
+// division and square root, libm-identical sin/cos from rt_libm.h), so that a ray's state is the SAME BITS as the
+// oracle's after every step (atan2, used by op4 only, is ocml's and within 1 ulp).  Reference lines are RT_bench.py.
+//
+// The golden-section search keeps the reference's comparison sequence without paying for 74 such cost evaluations
+// per step: see golden_filtered below.
+#pragma once
+#include "rt_libm.h"
+
+namespace rt {
+namespace ex {
+
+__device__ const double kSinCosTab[4 * RT_SINCOS_TAB_ENTRIES] = {RT_SINCOS_TAB_VALUES};
+
+__device__ __forceinline__ double sin_(double x) { return gl::in_range(x) ? gl::sin(kSinCosTab, x) : ::sin(x); }
+__device__ __forceinline__ double cos_(double x) { return gl::in_range(x) ? gl::cos(kSinCosTab, x) : ::cos(x); }
+__device__ __forceinline__ double sqrt_(double x) { return __dsqrt_rn(x); }            // correctly rounded
+__device__ __forceinline__ double sq(double x) { return x * x; }                        // oracle SQ()
+__device__ __forceinline__ double dot2(double a0, double a1, double b0, double b1) { return __builtin_fma(a1, b1, a0 * b0); }
+__device__ __forceinline__ double norm2(double a0, double a1) { return sqrt_(dot2(a0, a1, a0, a1)); }
+__device__ __forceinline__ double aniso(double s, double c, double gamma) { return sqrt_(sq(gamma * s) + sq(c)); }   // :118-119
+// moment() (:217-230) with coef = anisotropy(theta, gamma) passed in
+__device__ __forceinline__ double moment(double n, double coef, double g2m1, double o0, double o1) {
+    return n * coef * o0 * (1.0 + o1 * g2m1 / sq(coef));
+}
+__device__ __forceinline__ double impulse(double a, double b, double step) { return step * (a + b) / 2.0; }          // :214
+
+// ---------------------------------------------------------------- n_gradient in FITPACK's arithmetic
+// One axis: fpbisp's clamp + interval search (through rt::locate, exact on the true knots) and fpbspl for k = 1
+// and k = 3 with IEEE divisions and separate multiply/add, exactly as oracle/rt_oracle.c fpbspl().
+__device__ __forceinline__ void axis_exact(double v, int q, double a, double h, double b, double ih, int& j, int& l,
+                                           double wl[2], double w[4]) {
+    double t0, t1;
+    j = locate(v, q, a, h, b, ih, t0, t1);      // v is clamped in place (quirk Q4)
+    {   // k = 1 on [t0, t1]
+        const double f = 1.0 / (t1 - t0);
+        wl[0] = 0.0 + f * (t1 - v);
+        wl[1] = f * (v - t0);
+    }
+    l = j + 2;
+    l = l < 3 ? 3 : (l > q - 1 ? q - 1 : l);
+    const double tm2 = knot3(l - 2, q, a, h, b), tm1 = knot3(l - 1, q, a, h, b), k0 = knot3(l, q, a, h, b);
+    const double k1 = knot3(l + 1, q, a, h, b), k2 = knot3(l + 2, q, a, h, b), k3 = knot3(l + 3, q, a, h, b);
+    // j = 1
+    double f = 1.0 / (k1 - k0);
+    double h0 = 0.0 + f * (k1 - v), h1 = f * (v - k0), h2, h3;
+    // j = 2
+    double hh0 = h0, hh1 = h1, hh2;
+    f = hh0 / (k1 - tm1);
+    h0 = 0.0 + f * (k1 - v);
+    h1 = f * (v - tm1);
+    f = hh1 / (k2 - k0);
+    h1 = h1 + f * (k2 - v);
+    h2 = f * (v - k0);
+    // j = 3
+    hh0 = h0; hh1 = h1; hh2 = h2;
+    f = hh0 / (k1 - tm2);
+    h0 = 0.0 + f * (k1 - v);
+    h1 = f * (v - tm2);
+    f = hh1 / (k2 - tm1);
+    h1 = h1 + f * (k2 - v);
+    h2 = f * (v - tm1);
+    f = hh2 / (k3 - k0);
+    h2 = h2 + f * (k3 - v);
+    h3 = f * (v - k0);
+    w[0] = h0; w[1] = h1; w[2] = h2; w[3] = h3;
+}
+
+__device__ __forceinline__ void field_locate(const FieldDev<double>& F, double x, double y, Cell<double>& c) {
+    axis_exact(x, F.qx, F.ax, F.hx, F.bx, F.inv_hx, c.jx, c.lx, c.lwx, c.wx);
+    axis_exact(y, F.qy, F.ay, F.hy, F.by, F.inv_hy, c.jy, c.ly, c.lwy, c.wy);
+}
+
+// fpbisp's double sum: sp += c * wy[i] * wx[j], y index outer (splines are built as (y, x), :455)
+__device__ __forceinline__ void field_combine(const Cell<double>& c, const double z[4], const Pair<double> g[4][4],
+                                              double& n, double& gx, double& gy) {
+    double sp = 0.0;
+    sp += z[0] * c.lwy[0] * c.lwx[0];
+    sp += z[1] * c.lwy[0] * c.lwx[1];
+    sp += z[2] * c.lwy[1] * c.lwx[0];
+    sp += z[3] * c.lwy[1] * c.lwx[1];
+    n = sp;
+    double sx = 0.0, sy = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            sx += g[r][q].x * c.wy[r] * c.wx[q];
+            sy += g[r][q].y * c.wy[r] * c.wx[q];
+        }
+    }
+    gx = sx;
+    gy = sy;
+}
+
+template <typename G>
+__device__ __forceinline__ void n_gradient(const FieldDev<double>& F, G& gather, bool active, double x, double y,
+                                           double& n, double& gx, double& gy) {
+    Cell<double> c;
+    ex::field_locate(F, x, y, c);
+    double z[4];
+    Pair<double> g[4][4];
+    gather.fetch(F, c, active, z, g);
+    ex::field_combine(c, z, g, n, gx, gy);
+}
+
+// ---------------------------------------------------------------- advancement (:300-365)
+__device__ __forceinline__ void adv_first(const Ray<double>& r, double step, double& fx, double& fy) {
+    fx = r.x + r.ux * step;
+    fy = r.y + r.uy * step;
+}
+__device__ __forceinline__ void adv_second(const Ray<double>& r, const Consts<double>& k, double& fx, double& fy) {   // :330
+    const double d = dot2(r.gx, r.gy, r.ux, r.uy);
+    fx = (r.x + r.ux * k.step) + (r.gx - d * r.ux) * k.step2 / (2.0 * r.n);
+    fy = (r.y + r.uy * k.step) + (r.gy - d * r.uy) * k.step2 / (2.0 * r.n);
+}
+// returns the reference's flag: true == curvature NOT negligible (quirk Q14)
+__device__ __forceinline__ bool adv_curv(const Ray<double>& r, const Consts<double>& k, double& fx, double& fy) {
+    const double d = dot2(r.gx, r.gy, r.ux, r.uy);
+    const double curv = norm2(r.gx - d * r.ux, r.gy - d * r.uy) / r.n;
+    if (curv < 1.4901161193847656e-08) {   // GOLD_TOL (:355)
+        adv_first(r, k.step, fx, fy);
+        return false;
+    }
+    const double dc = curv * k.step;
+    if (r.gx * r.uy - r.gy * r.ux > 0) {   // np.cross (:360)
+        const double t = r.th - dc;
+        fx = r.x + (r.uy - sin_(t)) / curv;             // r.uy == sin(theta), r.ux == cos(theta): same function, same bits
+        fy = r.y + (cos_(t) - r.ux) / curv;
+    } else {
+        const double t = r.th + dc;
+        fx = r.x + (sin_(t) - r.uy) / curv;
+        fy = r.y + (-cos_(t) + r.ux) / curv;
+    }
+    return true;
+}
+
+// ---------------------------------------------------------------- angle determination (:370-407)
+__device__ __forceinline__ double ang_rk2(const Ray<double>& r, double step, double fn, double fgx, double fgy) {
+    const double k1 = step * (r.ux * r.gy - r.uy * r.gx) / r.n;
+    const double t = r.th + k1;
+    const double k2 = step * (cos_(t) * fgy - sin_(t) * fgx) / fn;
+    return r.th + (k1 + k2) / 2.0;
+}
+__device__ __forceinline__ double ang_cost(const Ray<double>& r, double step, double fgx, double fgy) {
+    return ::atan2(r.n * r.uy + impulse(r.gy, fgy, step), r.n * r.ux + impulse(r.gx, fgx, step));
+}
+
+// ---------------------------------------------------------------- golden() (:175-199), filtered
+// The reference evaluates func(c) and func(d) afresh in each of its 37 iterations and keeps [a, d] when
+// func(c) < func(d), else [c, b]; the returned midpoint depends only on that sequence of outcomes.  Here every
+// comparison is first attempted with a fast evaluation (the fused forms and 1-ulp sincos of rt_device.h, ONE new
+// point per iteration: the other point of the new bracket is the previous iteration's surviving point up to a few
+// ulps of t) together with a bound on how far the fast value can be from the value the reference's arithmetic
+// gives at the CURRENT point.  When the two fast values are further apart than the two bounds the outcome is
+// decided; otherwise (per lane, rare: the costs must agree to ~1e-15 of their terms) both costs are recomputed at
+// the current points in the reference's arithmetic (`exact`) and compared like the reference does.  Either way the
+// outcome is the reference's, so a, b, c, d -- advanced with the reference's own unfused bracket arithmetic -- are
+// its bits.
+//
+// Fast(t, f, g): cost f and g = |e_x| + |e_y| of the residual vector at t.
+// The bound for a stored evaluation made at tev and used at t, with l = LIP*|t - tev|:  (g + l)*(K1 + l) + f*K2 + K3
+//   K1  = 2 x (absolute error bound of one residual component, reference arithmetic + fast arithmetic),
+//   LIP = 2 x (bound on |d e/dt|), K2 = relative error of squaring and adding, K3 = second-order terms.
+struct GoldBounds { double K1, LIP, K2, K3; };
+
+template <typename Fast, typename Exact>
+__device__ __forceinline__ double golden_filtered(Fast fast, Exact exact, const GoldBounds& B, double a, double b) {
+    const double GR = kGoldRatio;
+    double c = b - (b - a) * GR, d = a + (b - a) * GR;
+    double fc, gc, fd, gd;
+    fast(c, fc, gc);
+    fast(d, fd, gd);
+    double tc = c, td = d;                      // where the stored values were evaluated
+    for (int it = 0; it < kGoldMaxIter && __builtin_fabs(c - d) > M<double>::gold_tol; ++it) {
+        const double lc = B.LIP * __builtin_fabs(c - tc), ld = B.LIP * __builtin_fabs(d - td);
+        const double bound = fma_(gc + lc, B.K1 + lc, fc * B.K2) + fma_(gd + ld, B.K1 + ld, fd * B.K2) + B.K3;
+        bool lt = fc < fd;
+        if (!(__builtin_fabs(fc - fd) > bound)) lt = exact(c) < exact(d);   // also taken when anything is NaN
+        if (lt) {   // keep [a, d]: the new d is the old c (up to rounding), the new c is fresh
+            b = d;
+            c = b - (b - a) * GR;
+            d = a + (b - a) * GR;
+            fd = fc; gd = gc; td = tc;
+            fast(c, fc, gc); tc = c;
+        } else {    // keep [c, b]
+            a = c;
+            c = b - (b - a) * GR;
+            d = a + (b - a) * GR;
+            fc = fd; gc = gd; tc = td;
+            fast(d, fd, gd); td = d;
+        }
+    }
+    return (b + a) / 2.0;
+}
+
+constexpr double kU = 1.1102230246251565e-16;   // 2^-53
+
+// isotropic cost (:595, :697): (n' cos t - n u_x - I_x)^2 + (n' sin t - n u_y - I_y)^2
+__device__ __forceinline__ double ang_golden_iso(const Ray<double>& r, double step, double fn, double fgx, double fgy) {
+    const double px = r.n * r.ux, py = r.n * r.uy;
+    const double ix = impulse(r.gx, fgx, step), iy = impulse(r.gy, fgy, step);
+    auto exact = [=](double t) { return sq(fn * cos_(t) - px - ix) + sq(fn * sin_(t) - py - iy); };
+    auto fast = [=](double t, double& f, double& g) {
+        double s, c;
+        sincos_k(t, &s, &c);
+        const double e0 = fma_(fn, c, -px) - ix, e1 = fma_(fn, s, -py) - iy;
+        f = fma_(e1, e1, e0 * e0);
+        g = __builtin_fabs(e0) + __builtin_fabs(e1);
+    };
+    // one residual component: |n' cos t| carries the sincos error (libm <= 0.55 ulp, sincos_k <= 1 ulp) and a product
+    // rounding, the two subtractions round at most u * (|n'| + |p| + |I|) each -- in both arithmetics
+    const double afn = __builtin_fabs(fn);
+    const double mag = afn + __builtin_fmax(__builtin_fabs(px), __builtin_fabs(py)) + __builtin_fmax(__builtin_fabs(ix), __builtin_fabs(iy));
+    const double e1 = 12.0 * kU * mag;
+    GoldBounds B;
+    B.K1 = 2.0 * e1; B.LIP = 2.0 * afn; B.K2 = 8.0 * kU; B.K3 = 16.0 * e1 * e1;
+    return golden_filtered(fast, exact, B, r.th - kHalfPi, r.th + kHalfPi);
+}
+
+// anisotropic cost (:725-728 / :758-761); the step functions read the module-global gamma (quirk Q12)
+__device__ __forceinline__ double ang_golden_aniso(const Ray<double>& r, const Consts<double>& k, double fn, double fgx,
+                                                   double fgy) {
+    const double gam = k.gamma_s, g2 = k.g2m1_s, step = k.step;
+    const double c0 = aniso(r.uy, r.ux, gam);
+    const double mix = moment(r.n, c0, g2, r.ux, -sq(r.uy));
+    const double miy = moment(r.n, c0, g2, r.uy, sq(r.ux));
+    const double cgx = r.coef * r.gx, cgy = r.coef * r.gy;
+    auto exact = [=](double t) {
+        const double s = sin_(t), c = cos_(t);
+        const double a = aniso(s, c, gam);
+        const double mx = moment(fn, a, g2, c, -sq(s));
+        const double my = moment(fn, a, g2, s, sq(c));
+        return sq(mx - mix - impulse(cgx, a * fgx, step)) + sq(my - miy - impulse(cgy, a * fgy, step));
+    };
+    const double hstep = step * 0.5;
+    auto fast = [=](double t, double& f, double& g) {
+        double s, c;
+        sincos_k(t, &s, &c);
+        const double gs = gam * s;
+        const double a = M<double>::sqrt_(fma_(gs, gs, c * c));
+        const double q = fn * a, w = g2 * rcp_full(a * a);
+        const double e0 = q * c * fma_(-(s * s), w, 1.0) - mix - (cgx + a * fgx) * hstep;
+        const double e1 = q * s * fma_(c * c, w, 1.0) - miy - (cgy + a * fgy) * hstep;
+        f = fma_(e1, e1, e0 * e0);
+        g = __builtin_fabs(e0) + __builtin_fabs(e1);
+    };
+    // Error of one residual component (u = 2^-53, relative errors unless stated).  Reference arithmetic: s, c <= 1.1u
+    // (libm); a <= 4.1u; n'*a*o0 <= 7.2u; w = o1*(gamma^2-1)/a^2 <= 14.4u with |w| <= wmax = |gamma^2-1| / min(1, gamma^2);
+    // the bracket F = 1 + w cancels, |dF| <= 14.4u*wmax + u*|F|, |F| <= 1 + wmax; so |dm| <= |n'|*gmax*(14.4u*wmax +
+    // 9.2u*(1 + wmax)).  Fast arithmetic (sincos_k taken as <= 2 ulp, rsq/rcp Newton forms as <= 1 ulp): |dm| <=
+    // |n'|*gmax*(28u*wmax + 15.5u*(1 + wmax)).  Both together stay below |n'|*gmax*(48*wmax + 28*(1 + wmax))*u.
+    // The impulse and the two subtractions add 4u*(|m| + |m_i| + |I|) + 22u*step*(|coef g| + gmax*|g'|).
+    const double afn = __builtin_fabs(fn), g2a = __builtin_fabs(g2);
+    const double gam2 = gam * gam, amin = __builtin_fmin(1.0, gam), gmax = __builtin_fmax(1.0, gam);
+    const double wmax = g2a / __builtin_fmin(1.0, gam2);
+    const double mom = afn * gmax * (24.0 * wmax + 14.0 * (1.0 + wmax));
+    const double gsum = __builtin_fabs(fgx) + __builtin_fabs(fgy);
+    const double oth = 4.0 * (__builtin_fabs(mix) + __builtin_fabs(miy) + afn * gmax * (1.0 + wmax)) +
+                       11.0 * step * (__builtin_fabs(cgx) + __builtin_fabs(cgy) + gmax * gsum);
+    const double e1 = 2.0 * kU * (mom + oth);
+    GoldBounds B;
+    B.K1 = 2.0 * e1;
+    // m_x = n' cos t / a(t), m_y = n' gamma^2 sin t / a(t), |a'| <= |gamma^2-1| / (2 amin):
+    // |dm/dt| <= n' max(1, gamma^2) (1/amin + |gamma^2-1| / (2 amin^3)); the impulse varies with a(t) only
+    B.LIP = 3.0 * (afn * __builtin_fmax(1.0, gam2) * (1.0 / amin + g2a / (2.0 * amin * amin * amin)) + step * g2a / amin * gsum);
+    B.K2 = 8.0 * kU; B.K3 = 16.0 * e1 * e1;
+    return golden_filtered(fast, exact, B, r.th - kHalfPi, r.th + kHalfPi);
+}
+
+// ---------------------------------------------------------------- opN around the field lookup
+template <int METHOD>
+__device__ __forceinline__ bool op_advance(const Consts<double>& k, const Ray<double>& r, double& fx, double& fy) {
+    if constexpr (METHOD == 3 || METHOD == 4 || METHOD == 5 || METHOD == 10) return ex::adv_curv(r, k, fx, fy);
+    else { ex::adv_second(r, k, fx, fy); return true; }
+}
+template <int METHOD>
+__device__ __forceinline__ double op_angle(const Consts<double>& k, const Ray<double>& r, bool flag, double fn, double fgx,
+                                           double fgy) {
+    if constexpr (METHOD == 3) return flag ? ex::ang_rk2(r, k.step, fn, fgx, fgy) : r.th;
+    else if constexpr (METHOD == 4) return flag ? ex::ang_cost(r, k.step, fgx, fgy) : r.th;
+    else if constexpr (METHOD == 5) return flag ? ex::ang_golden_iso(r, k.step, fn, fgx, fgy) : r.th;
+    else if constexpr (METHOD == 9) return ex::ang_golden_iso(r, k.step, fn, fgx, fgy);
+    else if constexpr (METHOD == 10) return flag ? ex::ang_golden_aniso(r, k, fn, fgx, fgy) : r.th;
+    else return ex::ang_golden_aniso(r, k, fn, fgx, fgy);   // 11
+}
+
+// store_update_results (:783-790) + the row bookkeeping of the loop body (:871-875)
+__device__ __forceinline__ void store_update(const Consts<double>& k, Ray<double>& r, double fx, double fy, double fth,
+                                             double fn, double fgx, double fgy) {
+    const double dist = norm2(r.x - fx, r.y - fy);
+    r.dsim += dist;
+    r.dreal += k.step;
+    const double c = cos_(fth), s = sin_(fth);
+    const double coef = aniso(s, c, k.gamma);
+    r.mx = moment(fn, coef, k.g2m1, c, -sq(s));
+    r.my = moment(fn, coef, k.g2m1, s, sq(c));
+    r.hx0 = r.hx1; r.hy0 = r.hy1; r.hx1 = r.x; r.hy1 = r.y;
+    r.x = fx; r.y = fy; r.th = fth; r.n = fn; r.gx = fgx; r.gy = fgy;
+    r.ux = c; r.uy = s; r.coef = coef;
+    const double nray = coef * fn;                              // (:873)
+    r.tt = r.tt + dist * (r.nray + nray) / 2.0;                 // (:874) quirk Q6
+    r.nray = nray;
+}
+
+// derived quantities from the stored state: the same functions of the same bits as when they were first formed
+__device__ __forceinline__ void derive(const Consts<double>& k, Ray<double>& r) {
+    r.ux = cos_(r.th); r.uy = sin_(r.th);
+    r.coef = aniso(r.uy, r.ux, k.gamma);
+    r.nray = r.coef * r.n;
+    r.rn = 0;
+    r.mx = moment(r.n, r.coef, k.g2m1, r.ux, -sq(r.uy));
+    r.my = moment(r.n, r.coef, k.g2m1, r.uy, sq(r.ux));
+}
+
+template <int METHOD, typename G>
+__device__ __forceinline__ bool ray_step(const FieldDev<double>& F, const Consts<double>& k, G& gather, bool active,
+                                         Ray<double>& r) {
+    double fx, fy, fn, fgx, fgy;
+    const bool flag = ex::op_advance<METHOD>(k, r, fx, fy);
+    ex::n_gradient(F, gather, active, fx, fy, fn, fgx, fgy);
+    const double fth = ex::op_angle<METHOD>(k, r, flag, fn, fgx, fgy);
+    ex::store_update(k, r, fx, fy, fth, fn, fgx, fgy);
+    return !outside(k, r);
+}
+
+}  // namespace ex
+}  // namespace rt

@@ -36,6 +36,13 @@ static int fail(int code, const std::string& msg) {
         if (!(cond)) return fail(RTMI_ERR_ARG, (msg));  \
     } while (0)
 
+// numpy's scalar x**2 calls libm pow(x, 2.0), which is not always the rounded product x*x (it differs by one ulp for
+// ~0.1 % of arguments on glibc 2.35); the exponent is volatile so that no compiler folds the call into a multiply.
+static double libm_square(double x) {
+    volatile double two = 2.0;
+    return std::pow(x, two);
+}
+
 // ------------------------------------------------------------------ handles
 struct rtmi_field {
     int device = 0;
@@ -383,6 +390,7 @@ template <typename T> struct BatchDev {
     // scalar registers live instead of twenty
     T* st;
     int has_hist;     // op7 only: hx0, hy0, hx1, hy1 follow the nine state arrays
+    int exact;        // fp64 op3/4/5/9/10/11: derived values and lookups in the reference's operation order (rt_exact.h)
     __device__ __forceinline__ T* arr(int q) const { return st + (size_t)q * R; }
     int* istep;
     unsigned char* alive;
@@ -400,15 +408,28 @@ template <typename T> __device__ __forceinline__ void write_row(const BatchDev<T
     if (a.n_ray) a.n_ray[(size_t)row * a.R + k] = r.nray;
 }
 
+// derived values / lookups outside the step loop, where the method is a run-time property of the batch
+template <typename T> __device__ __forceinline__ void derive_rt(const BatchDev<T>& a, rt::Ray<T>& r) { rt::derive<T, false>(a.K, r); }
+template <> __device__ __forceinline__ void derive_rt<double>(const BatchDev<double>& a, rt::Ray<double>& r) {
+    if (a.exact) rt::ex::derive(a.K, r); else rt::derive<double, false>(a.K, r);
+}
+template <typename T> __device__ __forceinline__ void n_gradient_rt(const BatchDev<T>& a, T x, T y, T& n, T& gx, T& gy) {
+    rt::GlobalGather<T> gg;
+    rt::n_gradient(a.F, gg, true, x, y, n, gx, gy);
+}
+template <> __device__ __forceinline__ void n_gradient_rt<double>(const BatchDev<double>& a, double x, double y, double& n, double& gx, double& gy) {
+    rt::GlobalGather<double> gg;
+    if (a.exact) rt::ex::n_gradient(a.F, gg, true, x, y, n, gx, gy); else rt::n_gradient(a.F, gg, true, x, y, n, gx, gy);
+}
+
 // initial conditions (:809-826): one lane per ray
 template <typename T> __global__ void k_init(BatchDev<T> a) {
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.R) return;
     rt::Ray<T> r;
     r.x = (T)a.x0[k]; r.y = (T)a.y0[k]; r.th = (T)a.th0[k];
-    rt::GlobalGather<T> gg;
-    rt::n_gradient(a.F, gg, true, r.x, r.y, r.n, r.gx, r.gy);
-    rt::derive<T, false>(a.K, r);
+    n_gradient_rt(a, r.x, r.y, r.n, r.gx, r.gy);
+    derive_rt(a, r);
     r.dsim = 0; r.dreal = 0; r.tt = 0;
     a.arr(0)[k] = r.x; a.arr(1)[k] = r.y; a.arr(2)[k] = r.th; a.arr(3)[k] = r.n; a.arr(4)[k] = r.gx; a.arr(5)[k] = r.gy;
     a.arr(6)[k] = 0; a.arr(7)[k] = 0; a.arr(8)[k] = 0;
@@ -447,7 +468,7 @@ __device__ __forceinline__ void load_ray(const BatchDev<T>& a, long k, rt::Ray<T
     r.dsim = a.arr(6)[k]; r.dreal = a.arr(7)[k]; r.tt = a.arr(8)[k];
     if (METHOD == 7) { r.hx0 = a.arr(9)[k]; r.hy0 = a.arr(10)[k]; r.hx1 = a.arr(11)[k]; r.hy1 = a.arr(12)[k]; }
     else { r.hx0 = r.hy0 = r.hx1 = r.hy1 = 0; }
-    rt::derive<T, ISO>(a.K, r);
+    if constexpr (rt::IsExact<T, METHOD>::value) rt::ex::derive(a.K, r); else rt::derive<T, ISO>(a.K, r);
     i = a.istep[k];
 }
 template <typename T, int METHOD>
@@ -495,7 +516,7 @@ __global__ __launch_bounds__(256, LDS ? 2 : 3) void k_advance(BatchDev<T> a, int
     // VAR: every ray carries its own DELTA_S and max_size (the calibration sweep as one candidate x ray batch)
     rt::Consts<T> K = a.K;
     int max_size = a.max_size;
-    if (VAR && k < a.R) { K.step = a.vstep[k]; K.step2h = a.vstep2h[k]; max_size = a.vmax[k]; }
+    if (VAR && k < a.R) { K.step = a.vstep[k]; K.step2h = a.vstep2h[k]; K.step2 = K.step2h * T(2); max_size = a.vmax[k]; }
     if (alive) {
         load_ray<T, METHOD, ISO>(a, k, r, i);
         until = RECORD ? a.stride - (i % a.stride) : 0;  // steps until the next recorded row
@@ -606,7 +627,7 @@ template <typename T> __global__ void k_pack_final(BatchDev<T> a, double* out) {
     if (k >= a.R) return;
     rt::Ray<T> r;
     r.x = a.arr(0)[k]; r.y = a.arr(1)[k]; r.th = a.arr(2)[k]; r.n = a.arr(3)[k]; r.gx = a.arr(4)[k]; r.gy = a.arr(5)[k]; r.tt = a.arr(8)[k];
-    rt::derive<T, false>(a.K, r);
+    derive_rt(a, r);
     const double v[9] = {(double)r.x, (double)r.y, (double)r.th, (double)r.n, (double)r.gx, (double)r.gy,
                          (double)r.mx, (double)r.my, (double)r.tt};
     const long o = out_index(a, k);
@@ -650,7 +671,8 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     a.F = field_dev<T>(b->field, b->p.exact_basis);
     const rtmi_params& p = b->p;
     a.K.step = (T)p.step;
-    a.K.step2h = (T)(std::pow(p.step, 2.0) / 2.0);  // numpy scalar step**2 is libm pow (:330); /2 is exact
+    a.K.step2h = (T)(libm_square(p.step) / 2.0);    // numpy scalar step**2 is libm pow (:330); /2 is exact
+    a.K.step2 = (T)libm_square(p.step);
     a.K.gamma = (T)p.gamma; a.K.g2m1 = (T)(p.gamma * p.gamma - 1.0);
     a.K.gamma_s = (T)p.gamma_step; a.K.g2m1_s = (T)(p.gamma_step * p.gamma_step - 1.0);
     for (int i = 0; i < 4; i++) a.K.box[i] = (T)p.box[i];
@@ -658,6 +680,7 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     T* s = (T*)b->state;
     const size_t R = (size_t)b->R;
     a.st = s; a.has_hist = p.method == 7;
+    a.exact = p.dtype == RTMI_F64 && rt::is_exact_method(p.method);
     a.istep = b->istep; a.alive = b->alive;
     a.s_ray = (T*)b->s_ray; a.n_ray = (T*)b->n_ray;
     a.counters = b->counters;
@@ -863,7 +886,7 @@ RTMI_EXPORT int rtmi_batch_set_per_ray(rtmi_batch* b, const double* step, const 
         ARG_TRY(step[k] > 0 && std::isfinite(step[k]), "rtmi_batch_set_per_ray: every step must be finite and > 0");
         ARG_TRY(max_size[k] >= (b->p.method == 7 ? 4 : 2) && max_size[k] <= b->p.max_size,
                 "rtmi_batch_set_per_ray: every max_size must be in [2 (4 for op7), params.max_size]");
-        h2[k] = std::pow(step[k], 2.0) / 2.0;   // numpy scalar step**2 (:330)
+        h2[k] = libm_square(step[k]) / 2.0;   // numpy scalar step**2 (:330)
     }
     if (!b->vstep) {
         HIP_TRY(hipMalloc(&b->vstep, R * b->esz));
@@ -1309,5 +1332,32 @@ RTMI_EXPORT int rtmi_batch_stats(rtmi_batch* b, rtmi_stats* s) {
     hipFuncAttributes fa;
     s->vgprs = s->sgprs = s->lds_bytes = 0;
     if (hipFuncGetAttributes(&fa, b->p.launch_mode == 1 ? b->kfn_refill : b->kfn) == hipSuccess) { s->vgprs = fa.numRegs; s->lds_bytes = (uint32_t)fa.sharedSizeBytes; }
+    return RTMI_OK;
+}
+
+// ------------------------------------------------------------------ diagnostic: libm-identical sin/cos on the device
+__global__ void k_debug_sincos(long n, const double* x, double* s, double* c) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    s[i] = rt::ex::sin_(x[i]);
+    c[i] = rt::ex::cos_(x[i]);
+}
+
+RTMI_EXPORT int rtmi_debug_sincos(int64_t n, const double* x, double* s, double* c) {
+    ARG_TRY(x && s && c, "rtmi_debug_sincos: null");
+    ARG_TRY(n >= 0, "rtmi_debug_sincos: n < 0");
+    if (n == 0) return RTMI_OK;
+    double* d = nullptr;
+    const size_t nb = (size_t)n * sizeof(double);
+    HIP_TRY(hipMalloc(&d, 3 * nb));
+    hipError_t e = hipMemcpy(d, x, nb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_sincos, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (long)n, d, d + n, d + 2 * n);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(s, d + n, nb, hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(c, d + 2 * n, nb, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_debug_sincos: ") + hipGetErrorString(e));
     return RTMI_OK;
 }

@@ -407,6 +407,14 @@ class Batch:
             pass
 
 
+def device_sincos(x):
+    """The library's libm-identical fp64 sin and cos (rtmi_debug_sincos), evaluated on the device -> (sin, cos)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    s = np.empty_like(x); c = np.empty_like(x)
+    check(lib().rtmi_debug_sincos(x.size, dptr(x), dptr(s), dptr(c)))
+    return s, c
+
+
 def launch_is_coherent(x0, y0, theta, group=64):
     """True when consecutive rays already travel together (sorted fans do): within most groups of `group`
     consecutive rays the launch points coincide to a fraction of a cell and the angles span no more than a few

@@ -2,8 +2,9 @@
 golden vectors captured from the reference.  Tolerances (fp64):
   * field build / n_gradient: 1e-13 of the coefficient scale (pure arithmetic, FMA contraction only);
   * trajectories, non-golden methods: 1e-9 relative (north_star); measured ~1e-13;
-  * golden-section methods (op5/9/10/11): a flipped cost comparison moves that step's angle by <= 6e-8
-    (SURVEY.md section 7), so the test states the fraction of rays within 1e-9 and bounds the worst ray.
+  * golden-section methods (op5/9/10/11): a flipped cost comparison would move that step's angle by <= 6e-8
+    (SURVEY.md section 7); they run in the reference's own operation order (rt_exact.h) and are held to 1e-9 on
+    every ray here and to the oracle's exact bits in tests/test_gpu_exact.py.
 """
 import numpy as np
 import pytest
@@ -119,12 +120,8 @@ def test_single_step_parity(m, rb, gpu_fields):
     out = fin[:6].T
     err = np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)
     err[:, 2] = np.abs(out[:, 2] - ref[:, 2])                          # angles: absolute (radians)
-    if m in (5, 9, 10, 11):
-        # golden-section: angle is the midpoint of a 6e-8 bracket; bit-stable unless a comparison flips
-        assert err[:, [0, 1, 3, 4, 5]].max() < 1e-12
-        assert np.mean(err[:, 2] < REL) >= 0.95 and err[:, 2].max() < 2e-7
-    else:
-        assert err.max() < 1e-12
+    # golden-section methods included: their comparison sequence is the reference's (rt_exact.h), on all 64 states
+    assert err.max() < 1e-12
 
 
 def test_step_token_call_surface(rb, gpu_fields):
@@ -150,16 +147,13 @@ def test_trajectory_vs_reference(name, scen, m, rb, gpu_fields):
     b.close()
     assert s.shape == (int(t["max_size"]), 6, len(th))
     strided, last = sub_rows(s, d, int(t["stride"]))
-    if m in (5, 9, 10, 11):
-        ok = d[2] == t["d_ray"][2]
-        per_ray = np.max(np.abs(last - t["last"]) / np.maximum(np.abs(t["last"]), 1.0), axis=(0, 1))
-        frac = np.mean(ok & (per_ray < REL))
-        print(f"{name}: rays within 1e-9 and same step count: {frac:.3f}; worst ray {per_ray.max():.2e}")
-        assert frac >= 0.9 and per_ray[ok].max() < 1e-5
-    else:
-        assert np.array_equal(d[2], t["d_ray"][2])
-        assert relerr(strided, t["strided"]) < REL and relerr(last, t["last"]) < REL
-        assert relerr(d[:2], t["d_ray"][:2]) < REL
+    # every ray of every method, golden-section ones included (north star: 1e-9 on every ray).  The one exception is
+    # the curvature advancement on the interface sigmoid, where the reference's own formula amplifies last-bit
+    # differences of the FIELD to ~1e-7 (tests/test_gpu_exact.py::test_interface_curvature_conditioning).
+    tol = 2e-6 if scen == "interface" and m in (3, 4, 5) else REL
+    assert np.array_equal(d[2], t["d_ray"][2])
+    assert relerr(strided, t["strided"]) < tol and relerr(last, t["last"]) < tol
+    assert relerr(d[:2], t["d_ray"][:2]) < tol
     k = int(np.argmin(d[2])); i = int(d[2, k])
     assert not s[i + 1:, :, k].any()                                   # rows after termination stay zero (Q7)
 
@@ -203,14 +197,11 @@ def test_batch_vs_oracle(scen, m, R, gam, rb, gpu_fields, oracle_fields):
     b.close()
     o = O.trazar(oracle_fields(scen), m, gam, rb.DELTA_S, max_size, lim, -2.0, -2.0, th, record_stride=0, nthreads=8)
     assert st["ray_steps"] == int(d[2].sum()) and st["live_rays"] == 0
-    if m in (9, 11):
-        ok = d[2] == o["d_ray"][2]
-        per_ray = np.max(np.abs(fin - o["final"]) / np.maximum(np.abs(o["final"]), 1.0), axis=0)
-        assert np.mean(ok & (per_ray < REL)) >= 0.9
-    else:
-        assert np.array_equal(d[2], o["d_ray"][2])
-        assert relerr(fin, o["final"]) < REL
-        assert relerr(d[:2], o["d_ray"][:2]) < REL
+    assert np.array_equal(d[2], o["d_ray"][2])
+    if m in (3, 9, 11):       # reference-order methods on a device-built vert field: the oracle's bits
+        assert np.array_equal(fin, o["final"]) and np.array_equal(d, o["d_ray"])
+    assert relerr(fin, o["final"]) < REL
+    assert relerr(d[:2], o["d_ray"][:2]) < REL
 
 
 def test_fisheye_fan_vs_oracle(rb, gpu_fields, oracle_fields):
@@ -551,10 +542,8 @@ def test_cfg5_anisotropy_shard_properties(rb, gpu_fields, oracle_fields):
     assert np.max(np.abs(fin[6] - px0)) / n0 < 5e-4               # drift relative to p_x's scale (p_x -> 0 at pi/2)
     sub = slice(0, R, 1024)
     o = O.trazar(oracle_fields("anisotropy"), 11, 3, rb.DELTA_S, ms, lim, -2.0, -2.0, th[sub], record_stride=0, nthreads=8)
-    same = d[2][sub] == o["d_ray"][2]
-    per_ray = np.max(np.abs(fin[:, sub] - o["final"]) / np.maximum(np.abs(o["final"]), 1.0), axis=0)
-    print(f"cfg5 subsample: {np.mean(same & (per_ray < REL)):.3f} of rays within 1e-9, worst {per_ray.max():.2e}")
-    assert np.mean(same & (per_ray < REL)) >= 0.9
+    assert np.array_equal(d[2][sub], o["d_ray"][2])
+    assert np.array_equal(fin[:, sub], o["final"])               # every sampled ray: the oracle's bits
 
 
 def test_cfg4_fp32_shard_properties(rb, gpu_fields):
@@ -705,17 +694,16 @@ def test_random_rays_through_grid_ends_vs_oracle(scen, m, rb, gpu_fields, oracle
     same = d[2] == o["d_ray"][2]
     assert same.mean() > 0.99                        # a ray grazing the rim may leave one step apart
     err = np.abs(fin[:, same] - o["final"][:, same]) / np.maximum(np.abs(o["final"][:, same]), 1.0)
-    if m in (5, 9, 10, 11):
-        per_ray = err.max(axis=0)
-        frac = np.mean(per_ray < REL)
-        print(f"{scen} op{m} (golden section): {frac:.3f} of rays within 1e-9, worst {per_ray.max():.2e}")
-        assert frac >= 0.9 and per_ray.max() < 1e-4
-        return
     print(f"{scen} op{m}: {same.sum()}/{R} same step count, max rel err {err.max():.2e}")
-    # op7 differentiates positions (roundoff / step).  The curvature advancement (op3/4/5/10, RT_bench.py:361-363)
-    # computes [sin(th) - sin(th -+ curv*step)] / curv, which amplifies a 1-ulp difference in sin/cos by 1/curv --
-    # up to 1/GOLD_TOL = 6.7e7 just above the straight-step threshold (the flat flanks of the interface sigmoid sit
-    # there): that is the reference's own conditioning, so those methods are reproducible to ~1e-8 per such step.
+    if m in (3, 5, 9, 10, 11) and scen != "interface":
+        # reference-order methods on a field whose coefficients are the oracle's bits: every ray bit-identical
+        assert same.all() and np.array_equal(fin, o["final"])
+        return
+    # op7 differentiates positions (roundoff / step).  On the interface the device samples the sigmoid with its own
+    # exp() (within 1 ulp of libm's), so field coefficients differ from the oracle's in last bits; the curvature
+    # advancement (op3/4/5/10, RT_bench.py:361-363) turns such a difference into ~1e-8 of position per step on the flat
+    # flanks of the sigmoid (tests/test_gpu_exact.py::test_interface_curvature_conditioning; with the oracle's samples
+    # the same rays are bit-identical, test_trajectories_are_the_oracles_bits).
     tol = 1e-7 if m == 7 else (2e-5 if m in (3, 4, 5, 10) and scen == "interface" else REL)
     assert err.max() < tol
 
