@@ -12,14 +12,28 @@
 // per step: see golden_filtered below.
 #pragma once
 #include "rt_libm.h"
+#include "rt_golden_rot.h"
 
 namespace rt {
 namespace ex {
 
 __device__ const double kSinCosTab[4 * RT_SINCOS_TAB_ENTRIES] = {RT_SINCOS_TAB_VALUES};
 
-__device__ __forceinline__ double sin_(double x) { return gl::in_range(x) ? gl::sin(kSinCosTab, x) : ::sin(x); }
-__device__ __forceinline__ double cos_(double x) { return gl::in_range(x) ? gl::cos(kSinCosTab, x) : ::cos(x); }
+// Real (not inlined) functions: each is ~150 instructions with four argument ranges, called a handful of times per
+// step; inlining them at every call site multiplied the kernels' code size and register pressure for nothing.
+// Beyond the range rt_libm.h reproduces (|x| >= 1.05e8, never reached by the path) the value is sincos_k's.
+__device__ __attribute__((noinline)) double sin_(double x) {
+    if (gl::in_range(x)) return gl::sin(kSinCosTab, x);
+    double s, c;
+    sincos_k(x, &s, &c);
+    return s;
+}
+__device__ __attribute__((noinline)) double cos_(double x) {
+    if (gl::in_range(x)) return gl::cos(kSinCosTab, x);
+    double s, c;
+    sincos_k(x, &s, &c);
+    return c;
+}
 __device__ __forceinline__ double sqrt_(double x) { return __dsqrt_rn(x); }            // correctly rounded
 __device__ __forceinline__ double sq(double x) { return x * x; }                        // oracle SQ()
 __device__ __forceinline__ double dot2(double a0, double a1, double b0, double b1) { return __builtin_fma(a1, b1, a0 * b0); }
@@ -155,73 +169,134 @@ __device__ __forceinline__ double ang_cost(const Ray<double>& r, double step, do
 // ---------------------------------------------------------------- golden() (:175-199), filtered
 // The reference evaluates func(c) and func(d) afresh in each of its 37 iterations and keeps [a, d] when
 // func(c) < func(d), else [c, b]; the returned midpoint depends only on that sequence of outcomes.  Here every
-// comparison is first attempted with a fast evaluation (the fused forms and 1-ulp sincos of rt_device.h, ONE new
-// point per iteration: the other point of the new bracket is the previous iteration's surviving point up to a few
-// ulps of t) together with a bound on how far the fast value can be from the value the reference's arithmetic
-// gives at the CURRENT point.  When the two fast values are further apart than the two bounds the outcome is
-// decided; otherwise (per lane, rare: the costs must agree to ~1e-15 of their terms) both costs are recomputed at
-// the current points in the reference's arithmetic (`exact`) and compared like the reference does.  Either way the
-// outcome is the reference's, so a, b, c, d -- advanced with the reference's own unfused bracket arithmetic -- are
-// its bits.
+// comparison is first attempted with FAST cost values that carry a bound on their distance from what the reference's
+// arithmetic gives at the current points; when the two fast values are further apart than the bounds allow, the
+// outcome is decided.  Otherwise (per lane, rare: the costs must agree to ~1e-14 of their terms) both costs are
+// recomputed at the current points in the reference's arithmetic (`exact`) and compared like the reference does.
+// Either way the outcome is the reference's, so a, b, c, d -- advanced with the reference's own unfused bracket
+// arithmetic -- are its bits, and so is the returned midpoint.
 //
-// Fast(t, f, g): cost f and g = |e_x| + |e_y| of the residual vector at t.
-// The bound for a stored evaluation made at tev and used at t, with l = LIP*|t - tev|:  (g + l)*(K1 + l) + f*K2 + K3
-//   K1  = 2 x (absolute error bound of one residual component, reference arithmetic + fast arithmetic),
+// One new point per iteration: of the two points of the new bracket one is the previous iteration's better point
+// ("survivor"; equal up to a few ulps of t to the point the reference would evaluate again), the other is the
+// survivor moved by h_j = pi*GR^(j+4) towards the kept side.
+//   Phase A (first kGoldRotIters iterations, bracket >= 2e-5): sin/cos of the new point by rotating the survivor's
+//     sin/cos through h_j (table rt_golden_rot.h), no sincos evaluation at all.  The tracked angle drifts from the
+//     actual point by rounding (bounded by DPHI below), which only loosens the bound -- harmless while the bracket,
+//     and with it the gap between the two costs, is wide.
+//   Phase B (the rest): sincos_k at the actual point, tight bound, the survivor's value reused with its actual
+//     distance |t - t_eval| priced in.
+//
+// FastSC(s, c, f, g): cost f and g = |e_x| + |e_y| of the residual vector from sin/cos of the evaluation angle.
+// Bound of one stored value: (g + l)*(K1 + l) + f*K2, l = LIP*|t - t_eval|, plus K3 once, where
+//   K1  = 2 x (absolute error bound of one residual component: reference arithmetic + fast arithmetic),
 //   LIP = 2 x (bound on |d e/dt|), K2 = relative error of squaring and adding, K3 = second-order terms.
 struct GoldBounds { double K1, LIP, K2, K3; };
 
-template <typename Fast, typename Exact>
-__device__ __forceinline__ double golden_filtered(Fast fast, Exact exact, const GoldBounds& B, double a, double b) {
-    const double GR = kGoldRatio;
+constexpr int kGoldRotIters = 24;
+__device__ const double kGoldRot[2 * RT_GOLD_ROT_ENTRIES] = {RT_GOLD_ROT_VALUES};
+constexpr double kU = 1.1102230246251565e-16;   // 2^-53
+
+template <typename FastSC, typename Exact>
+__device__ __forceinline__ double golden_filtered(FastSC fast_sc, Exact exact, const GoldBounds& B, double th, double s0,
+                                                  double c0) {
+    const double GR = kGoldRatio, tol = M<double>::gold_tol;
+    double a = th - kHalfPi, b = th + kHalfPi;
     double c = b - (b - a) * GR, d = a + (b - a) * GR;
-    double fc, gc, fd, gd;
-    fast(c, fc, gc);
-    fast(d, fd, gd);
-    double tc = c, td = d;                      // where the stored values were evaluated
-    for (int it = 0; it < kGoldMaxIter && __builtin_fabs(c - d) > M<double>::gold_tol; ++it) {
+    int it = 0;
+    {   // ---- phase A.  X: survivor, Y: the newer point; x_is_c: X is the lower point c
+        // tracked angle vs actual point: rotation arithmetic (<= 6u each, table constants included) and the bracket
+        // arithmetic's roundings (<= ulp(t) per update, t up to |theta| + pi/2)
+        const double dphi = kU * (8.0 + kGoldRotIters * (6.0 + 2.0 * (__builtin_fabs(th) + 2.0)));
+        const double lA = B.LIP * dphi;
+        const double K1A = B.K1 + lA, K3A = 4.0 * K1A * K1A;
+        const double sk = RT_GOLD_KAPPA_SIN, ck = RT_GOLD_KAPPA_COS;
+        double sX = fma_(-c0, sk, s0 * ck), cX = fma_(s0, sk, c0 * ck);   // theta0 - kappa
+        double sY = fma_(c0, sk, s0 * ck), cY = fma_(-s0, sk, c0 * ck);   // theta0 + kappa
+        double fX, gX, fY, gY;
+        fast_sc(sX, cX, fX, gX);
+        fast_sc(sY, cY, fY, gY);
+        bool x_is_c = true;
+        for (; it < kGoldRotIters && __builtin_fabs(c - d) > tol; ++it) {
+            const double bound = fma_(gX + gY, K1A, fma_(fX + fY, B.K2, K3A));
+            bool xless = fX < fY;
+            bool lt = xless == x_is_c;
+            if (!(__builtin_fabs(fX - fY) > bound)) {        // also taken when anything is NaN
+                lt = exact(c) < exact(d);
+                xless = lt == x_is_c;
+            }
+            if (lt) b = d; else a = c;
+            c = b - (b - a) * GR;
+            d = a + (b - a) * GR;
+            if (!xless) { fX = fY; gX = gY; sX = sY; cX = cY; }
+            const double ch = kGoldRot[2 * it + 1];
+            const double sh = lt ? -kGoldRot[2 * it] : kGoldRot[2 * it];
+            sY = fma_(cX, sh, sX * ch);
+            cY = fma_(-sX, sh, cX * ch);
+            fast_sc(sY, cY, fY, gY);
+            x_is_c = !lt;
+        }
+    }
+    // ---- phase B
+    double fc, gc, fd, gd, tc = c, td = d;
+    {
+        double s, cs;
+        sincos_k(c, &s, &cs); fast_sc(s, cs, fc, gc);
+        sincos_k(d, &s, &cs); fast_sc(s, cs, fd, gd);
+    }
+    for (; it < kGoldMaxIter && __builtin_fabs(c - d) > tol; ++it) {
         const double lc = B.LIP * __builtin_fabs(c - tc), ld = B.LIP * __builtin_fabs(d - td);
         const double bound = fma_(gc + lc, B.K1 + lc, fc * B.K2) + fma_(gd + ld, B.K1 + ld, fd * B.K2) + B.K3;
         bool lt = fc < fd;
-        if (!(__builtin_fabs(fc - fd) > bound)) lt = exact(c) < exact(d);   // also taken when anything is NaN
+        if (!(__builtin_fabs(fc - fd) > bound)) lt = exact(c) < exact(d);
+        double s, cs;
         if (lt) {   // keep [a, d]: the new d is the old c (up to rounding), the new c is fresh
             b = d;
             c = b - (b - a) * GR;
             d = a + (b - a) * GR;
             fd = fc; gd = gc; td = tc;
-            fast(c, fc, gc); tc = c;
+            sincos_k(c, &s, &cs); fast_sc(s, cs, fc, gc); tc = c;
         } else {    // keep [c, b]
             a = c;
             c = b - (b - a) * GR;
             d = a + (b - a) * GR;
             fc = fd; gc = gd; tc = td;
-            fast(d, fd, gd); td = d;
+            sincos_k(d, &s, &cs); fast_sc(s, cs, fd, gd); td = d;
         }
     }
     return (b + a) / 2.0;
 }
 
-constexpr double kU = 1.1102230246251565e-16;   // 2^-53
+// The two cost functions in the reference's arithmetic -- the rare path of golden_filtered, kept out of line.
+__device__ __attribute__((noinline)) double exact_cost_iso(double t, double fn, double px, double py, double ix, double iy) {
+    return sq(fn * cos_(t) - px - ix) + sq(fn * sin_(t) - py - iy);                                   // (:595, :697)
+}
+__device__ __attribute__((noinline)) double exact_cost_aniso(double t, double fn, double gam, double g2, double mix, double miy,
+                                                            double cgx, double cgy, double fgx, double fgy, double step) {
+    const double s = sin_(t), c = cos_(t);                                                            // (:728, :761)
+    const double a = aniso(s, c, gam);
+    const double mx = moment(fn, a, g2, c, -sq(s));
+    const double my = moment(fn, a, g2, s, sq(c));
+    return sq(mx - mix - impulse(cgx, a * fgx, step)) + sq(my - miy - impulse(cgy, a * fgy, step));
+}
 
 // isotropic cost (:595, :697): (n' cos t - n u_x - I_x)^2 + (n' sin t - n u_y - I_y)^2
 __device__ __forceinline__ double ang_golden_iso(const Ray<double>& r, double step, double fn, double fgx, double fgy) {
     const double px = r.n * r.ux, py = r.n * r.uy;
     const double ix = impulse(r.gx, fgx, step), iy = impulse(r.gy, fgy, step);
-    auto exact = [=](double t) { return sq(fn * cos_(t) - px - ix) + sq(fn * sin_(t) - py - iy); };
-    auto fast = [=](double t, double& f, double& g) {
-        double s, c;
-        sincos_k(t, &s, &c);
+    auto exact = [=](double t) { return exact_cost_iso(t, fn, px, py, ix, iy); };
+    auto fast_sc = [=](double s, double c, double& f, double& g) {
         const double e0 = fma_(fn, c, -px) - ix, e1 = fma_(fn, s, -py) - iy;
         f = fma_(e1, e1, e0 * e0);
         g = __builtin_fabs(e0) + __builtin_fabs(e1);
     };
-    // one residual component: |n' cos t| carries the sincos error (libm <= 0.55 ulp, sincos_k <= 1 ulp) and a product
-    // rounding, the two subtractions round at most u * (|n'| + |p| + |I|) each -- in both arithmetics
+    // one residual component: |n' cos t| carries the sincos error (libm <= 0.55 ulp, sincos_k taken as <= 2 ulp) and a
+    // product rounding, the two subtractions round at most u * (|n'| + |p| + |I|) each -- in both arithmetics
     const double afn = __builtin_fabs(fn);
     const double mag = afn + __builtin_fmax(__builtin_fabs(px), __builtin_fabs(py)) + __builtin_fmax(__builtin_fabs(ix), __builtin_fabs(iy));
     const double e1 = 12.0 * kU * mag;
     GoldBounds B;
     B.K1 = 2.0 * e1; B.LIP = 2.0 * afn; B.K2 = 8.0 * kU; B.K3 = 16.0 * e1 * e1;
-    return golden_filtered(fast, exact, B, r.th - kHalfPi, r.th + kHalfPi);
+    return golden_filtered(fast_sc, exact, B, r.th, r.uy, r.ux);
 }
 
 // anisotropic cost (:725-728 / :758-761); the step functions read the module-global gamma (quirk Q12)
@@ -232,46 +307,43 @@ __device__ __forceinline__ double ang_golden_aniso(const Ray<double>& r, const C
     const double mix = moment(r.n, c0, g2, r.ux, -sq(r.uy));
     const double miy = moment(r.n, c0, g2, r.uy, sq(r.ux));
     const double cgx = r.coef * r.gx, cgy = r.coef * r.gy;
-    auto exact = [=](double t) {
-        const double s = sin_(t), c = cos_(t);
-        const double a = aniso(s, c, gam);
-        const double mx = moment(fn, a, g2, c, -sq(s));
-        const double my = moment(fn, a, g2, s, sq(c));
-        return sq(mx - mix - impulse(cgx, a * fgx, step)) + sq(my - miy - impulse(cgy, a * fgy, step));
-    };
-    const double hstep = step * 0.5;
-    auto fast = [=](double t, double& f, double& g) {
-        double s, c;
-        sincos_k(t, &s, &c);
+    auto exact = [=](double t) { return exact_cost_aniso(t, fn, gam, g2, mix, miy, cgx, cgy, fgx, fgy, step); };
+    // Fast form: with a^2 = gamma^2 s^2 + c^2 the reference's brackets are 1 - s^2 (gamma^2-1)/a^2 = 1/a^2 and
+    // 1 + c^2 (gamma^2-1)/a^2 = gamma^2/a^2, so m_x = n' c / a and m_y = n' gamma^2 s / a: no cancellation, one rsq.
+    const double hstep = step * 0.5, gam2 = gam * gam, fng2 = fn * gam2;
+    auto fast_sc = [=](double s, double c, double& f, double& g) {
         const double gs = gam * s;
-        const double a = M<double>::sqrt_(fma_(gs, gs, c * c));
-        const double q = fn * a, w = g2 * rcp_full(a * a);
-        const double e0 = q * c * fma_(-(s * s), w, 1.0) - mix - (cgx + a * fgx) * hstep;
-        const double e1 = q * s * fma_(c * c, w, 1.0) - miy - (cgy + a * fgy) * hstep;
+        const double q2 = fma_(gs, gs, c * c);
+        double ra = __builtin_amdgcn_rsq(q2);                       // 1/a: hardware estimate + two Newton steps (< 2 ulp)
+        ra = fma_(ra * 0.5, fma_(-q2 * ra, ra, 1.0), ra);
+        ra = fma_(ra * 0.5, fma_(-q2 * ra, ra, 1.0), ra);
+        const double a = q2 * ra;
+        const double e0 = fn * c * ra - mix - fma_(a, fgx, cgx) * hstep;
+        const double e1 = fng2 * s * ra - miy - fma_(a, fgy, cgy) * hstep;
         f = fma_(e1, e1, e0 * e0);
         g = __builtin_fabs(e0) + __builtin_fabs(e1);
     };
     // Error of one residual component (u = 2^-53, relative errors unless stated).  Reference arithmetic: s, c <= 1.1u
     // (libm); a <= 4.1u; n'*a*o0 <= 7.2u; w = o1*(gamma^2-1)/a^2 <= 14.4u with |w| <= wmax = |gamma^2-1| / min(1, gamma^2);
     // the bracket F = 1 + w cancels, |dF| <= 14.4u*wmax + u*|F|, |F| <= 1 + wmax; so |dm| <= |n'|*gmax*(14.4u*wmax +
-    // 9.2u*(1 + wmax)).  Fast arithmetic (sincos_k taken as <= 2 ulp, rsq/rcp Newton forms as <= 1 ulp): |dm| <=
-    // |n'|*gmax*(28u*wmax + 15.5u*(1 + wmax)).  Both together stay below |n'|*gmax*(48*wmax + 28*(1 + wmax))*u.
-    // The impulse and the two subtractions add 4u*(|m| + |m_i| + |I|) + 22u*step*(|coef g| + gmax*|g'|).
+    // 9.2u*(1 + wmax)).  Fast arithmetic (s, c taken as <= 2 ulp = 4u; q2 <= 11u; 1/a <= 7.5u): |dm| <= 14.5u*|m| with
+    // |m| <= |n'|*max(1, gamma^2)/amin.  The impulse and the two subtractions add, in both arithmetics together,
+    // 4u*(|m| + |m_i| + |I|) + 22u*step*(|coef g| + gmax*|g'|).
     const double afn = __builtin_fabs(fn), g2a = __builtin_fabs(g2);
-    const double gam2 = gam * gam, amin = __builtin_fmin(1.0, gam), gmax = __builtin_fmax(1.0, gam);
+    const double amin = __builtin_fmin(1.0, gam), gmax = __builtin_fmax(1.0, gam), g2max = __builtin_fmax(1.0, gam2);
     const double wmax = g2a / __builtin_fmin(1.0, gam2);
-    const double mom = afn * gmax * (24.0 * wmax + 14.0 * (1.0 + wmax));
+    const double mom = afn * (gmax * (15.0 * wmax + 10.0 * (1.0 + wmax)) + 16.0 * g2max / amin);
     const double gsum = __builtin_fabs(fgx) + __builtin_fabs(fgy);
     const double oth = 4.0 * (__builtin_fabs(mix) + __builtin_fabs(miy) + afn * gmax * (1.0 + wmax)) +
-                       11.0 * step * (__builtin_fabs(cgx) + __builtin_fabs(cgy) + gmax * gsum);
-    const double e1 = 2.0 * kU * (mom + oth);
+                       22.0 * step * (__builtin_fabs(cgx) + __builtin_fabs(cgy) + gmax * gsum);
+    const double e1 = kU * (mom + oth);
     GoldBounds B;
     B.K1 = 2.0 * e1;
-    // m_x = n' cos t / a(t), m_y = n' gamma^2 sin t / a(t), |a'| <= |gamma^2-1| / (2 amin):
-    // |dm/dt| <= n' max(1, gamma^2) (1/amin + |gamma^2-1| / (2 amin^3)); the impulse varies with a(t) only
-    B.LIP = 3.0 * (afn * __builtin_fmax(1.0, gam2) * (1.0 / amin + g2a / (2.0 * amin * amin * amin)) + step * g2a / amin * gsum);
+    // |a'| <= |gamma^2-1| / (2 amin): |dm/dt| <= n' max(1, gamma^2) (1/amin + |gamma^2-1| / (2 amin^3)); the impulse
+    // varies with a(t) only
+    B.LIP = 3.0 * (afn * g2max * (1.0 / amin + g2a / (2.0 * amin * amin * amin)) + step * g2a / amin * gsum);
     B.K2 = 8.0 * kU; B.K3 = 16.0 * e1 * e1;
-    return golden_filtered(fast, exact, B, r.th - kHalfPi, r.th + kHalfPi);
+    return golden_filtered(fast_sc, exact, B, r.th, r.uy, r.ux);
 }
 
 // ---------------------------------------------------------------- opN around the field lookup
