@@ -3,17 +3,28 @@
 
 A "step" is one full propagation (initial conditions + every DELTA_S step to termination) of one batch of
 synthetic rays per GPU.  N=1 workload: vert_heterogeneous, 1 048 576 rays, op6 (HySA), default DELTA_S,
-fp64 -- the configuration the metric is quoted on (SURVEY.md 8d "north-star run").  For N>1 every rank
-owns 1 048 576 rays of an N-times finer fan, interleaved (ray k*N + rank), so per-GPU work is fixed
-("weak") and balanced; there is no data-path collective (rays are independent).
+fp64, full trajectory record -- the configuration the metric is quoted on (SURVEY.md 8d "north-star run").
+
+Multi-GPU (one process per GPU, no data-path collective -- rays are independent):
+  weak   (default): every rank owns --rays rays of an N-times finer fan, interleaved (ray k*N + rank), so per-GPU
+                    work is fixed and balanced;
+  strong (--total-rays R): the SAME R-ray fan at every N (the north star's 1 048 576 rays at 1/2/4/8 GPUs),
+                    rank r owns rays r, r+N, r+2N, ...
 
   python bench.py --gpus 1 --steps 5 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-      bench.py --gpus N --steps K --warmup W
+      bench.py --gpus N --steps K --warmup W [--total-rays 1048576]
 
-Rank 0 prints ONE JSON line.  `roofline` prices the advance kernel at SURVEY.md 8d's algorithmic bytes per
-ray-step against 8 TB/s; `cpu_baseline` times the CPU oracle (oracle/, a port of the reference's algorithm)
-on this host's cores over a bounded sample of the same workload.
+Rank 0 prints ONE JSON line.
+  roofline      what bounds the advance kernel, as a fraction <= 1 of a hardware peak: HBM bytes per launch (rocprofv3
+                counters, profiles/traffic.json; or, without a profile of this configuration, the bytes the launch must
+                write and read: recorded rows + state) over the kernel time measured here with HIP events, against
+                8 TB/s -- and the vector ALU's issue time from the profiled instruction counts.  `bound` names the
+                larger.  SURVEY.md 8d's ALGORITHMIC byte model (state in/out + coefficient gather per ray-step) is kept
+                under `alg_model`; it is not a bound for this kernel (state lives in registers across all steps of a
+                ray, the gather is served from LDS/L2), which is why it exceeds the HBM peak.
+  cpu_baseline  the CPU oracle (oracle/, a port of the reference's algorithm) on this host's cores over a bounded
+                sample of the same workload.
 """
 import argparse
 import json
@@ -26,11 +37,9 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X vector fp64 (half the 157.3 TF fp32 vector peak of MI355X_MICROARCH.md)
-# fp64 flops per ray-step, from rocprofv3 SQ_INSTS_VALU_{FMA,MUL,ADD}_F64 per wave-step of the op6 kernel
-# (profiles/r01_d_final_pmc_summary.txt: 100 fma + 68 mul + 24 add wave-instructions per 64-ray wave-step)
-FLOPS_PER_RAY_STEP = {(6, "f64"): 2 * 100 + 68 + 24}
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured for a float4 copy)
+SIMDS = 256 * 4                  # CUs x SIMDs
+PEAK_CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md: max clock
 SCEN = {"vert_heterogeneous": dict(choice="3", theta=(0.0, np.pi / 2), start=(-2.0, -2.0), gamma=1),
         "anisotropy": dict(choice="4", theta=(0.0, np.pi / 2), start=(-2.0, -2.0), gamma=3),
         "interface": dict(choice="1", theta=(2 * np.pi / 60, np.pi / 2), start=(-2.0, -2.0), gamma=1),
@@ -43,6 +52,15 @@ def alg_bytes_per_step(dtype, stride):
     return (9 + 9 + 36) * e + (7 * e / stride if stride else 0.0)
 
 
+def min_hbm_bytes(dtype, stride, ray_steps, rays, method):
+    """Bytes one launch cannot avoid moving: the recorded rows (7 values per stored row) and the ray state once in
+    and once out (9 values, 13 for op7, + istep + alive).  The field (<= 26 MB) is L2/MALL-resident."""
+    e = 8 if dtype == "f64" else 4
+    rows = ray_steps / stride if stride else 0.0
+    narr = 13 if method == 7 else 9
+    return rows * 7 * e + 2.0 * rays * (narr * e + 5)
+
+
 def fan(scen, R_total, rank, world):
     lo, hi = SCEN[scen]["theta"]
     step = (hi - lo) / (R_total - 1)
@@ -53,7 +71,7 @@ def fan(scen, R_total, rank, world):
     return th
 
 
-def cpu_baseline(args, rb, budget_s):
+def cpu_baseline(args, rb, budget_s, rays):
     """The oracle (kind "port") on this host's cores, same scenario/method/DELTA_S, a subsample of the fan."""
     from oracle import rt_oracle as O
     sc = SCEN[args.scenario]
@@ -71,9 +89,9 @@ def cpu_baseline(args, rb, budget_s):
         dt = time.perf_counter() - t0
         used += dt
         rate = r["steps"] / dt
-        if dt >= 0.4 * budget_s or used >= budget_s or R >= args.rays:
+        if dt >= 0.4 * budget_s or used >= budget_s or R >= rays:
             break
-        R = int(min(args.rays, max(2 * R, R * 0.6 * budget_s / max(dt, 1e-3))))
+        R = int(min(rays, max(2 * R, R * 0.6 * budget_s / max(dt, 1e-3))))
     return {"value": rate, "unit": "ray-steps/s", "cores": cores, "kind": "port",
             "sample": f"{args.scenario} op{args.method} fp64, {R} rays of the same fan, {r['steps']} ray-steps in "
                       f"{dt:.2f} s, OpenMP over rays, final-state mode"}
@@ -91,7 +109,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rays", type=int, default=1048576, help="rays per GPU")
+    ap.add_argument("--rays", type=int, default=1048576, help="rays per GPU (weak scaling)")
+    ap.add_argument("--total-rays", type=int, default=0,
+                    help="strong scaling: this many rays in total, split over the ranks (0 = weak scaling with --rays per GPU)")
     ap.add_argument("--scenario", default="vert_heterogeneous", choices=sorted(SCEN))
     ap.add_argument("--method", type=int, default=None)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
@@ -153,16 +173,20 @@ def main():
     rec_rows = args.rec_rows
     if stride and not rec_rows and args.scenario in ("vert_heterogeneous", "anisotropy"):
         rec_rows = (3072 + stride - 1) // stride     # the fan's longest ray takes 2 938 steps
-    R_total = args.rays * world
-    th = fan(args.scenario, R_total, rank, world)
+    strong = args.total_rays > 0
+    R_total = args.total_rays if strong else args.rays * world
+    th = fan(args.scenario, R_total, rank, world)    # rank r owns rays r, r+world, ... of the R_total-ray fan
+    R_local = len(th)
     if args.order == "shuffled":
         th = np.random.default_rng(1234 + rank).permutation(th)
     fld = rb.Field.build(args.scenario, lim, rb.DELTA, dtype)
+
     def make_batch(stride_, rec_rows_):
         return rb.Batch(fld, args.method, step, max_size, lim, sc["gamma"], th, sc["start"][0], sc["start"][1],
                         record_stride=stride_, rec_rows=rec_rows_, block_size=args.block,
                         launch_mode=1 if args.mode == "refill" else 0, refill_min=args.refill_min,
-                        field_path={"auto": 0, "global": 1, "lds": 2}[args.field_path], sort_rays=args.sort)
+                        field_path={"auto": 0, "global": 1, "lds": 2}[args.field_path], sort_rays=args.sort,
+                        lazy_clear=True)    # every pass re-runs the same launch conditions: same rows rewritten
 
     try:
         batch = make_batch(stride, rec_rows)
@@ -181,16 +205,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    longest = {"vert_heterogeneous": 2953, "anisotropy": 2900}.get(args.scenario, max_size - 1)
-
     def one_pass():
         batch.reset()
         if args.chunk <= 0:
             batch.run()
-        else:   # enough launches for the longest ray of the fan; launches after the last ray stopped exit at once
-            for _ in range((longest + args.chunk - 1) // args.chunk + 1):
+            return
+        # host-stepped: launches of `chunk` steps until no ray is live (checked every `group` launches: the check is a
+        # reduction kernel + a host sync, which a real stepping caller would not pay per launch either)
+        group = max(1, 256 // args.chunk)
+        while True:
+            for _ in range(group):
                 batch.step(args.chunk)
-            batch.sync()
+            if batch.stats()["live_rays"] == 0:
+                break
 
     for _ in range(args.warmup):
         one_pass()
@@ -201,68 +228,86 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     st = batch.stats()                       # counters and kernel time of the LAST pass (reset clears them)
+    assert st["live_rays"] == 0, "a pass ended with live rays"
     steps_per_pass = st["ray_steps"]
-    kern_ms = st["kernel_ms"] / max(st["launches"], 1)
+    kern_ms = st["kernel_ms"]                # all advance launches of the pass together
+    launches = max(st["launches"], 1)
     if world > 1:
         dt = rd.max_over_ranks(dt, cdev)
         total_steps = rd.sum_over_ranks(steps_per_pass, cdev) * args.steps
-        # read-back of the sharded layout: d_ray gathered to rank 0 over RCCL (outside the timed region)
-        d_local = torch.as_tensor(batch.d_ray(), device=cdev)
-        g = [torch.empty_like(d_local) for _ in range(world)] if rank == 0 else None
-        dist.gather(d_local, g, dst=0)
-        if rank == 0:
-            d_all = torch.stack(g, dim=-1).reshape(3, R_total)      # ray k*world + r  <-  rank r, slot k
-            assert int(d_all[2].sum().item()) * args.steps == total_steps
-        if args.backend == "nccl":
-            # end points gathered device-to-device: zero-copy views of the library's SoA state into RCCL
-            try:
-                dt_ = batch.device_tensors()
-                xy = torch.stack((dt_["x"], dt_["y"]))                 # [2, R] on this rank's GPU
-                gx_ = [torch.empty_like(xy) for _ in range(world)] if rank == 0 else None
-                dist.gather(xy, gx_, dst=0)
-                if rank == 0:
-                    xy_all = torch.stack(gx_, dim=-1).reshape(2, R_total)
-                    assert torch.isfinite(xy_all).all()
-            except Exception as e:   # the timed result is already in hand; report and carry on
-                print(f"bench.py: device-side gather skipped: {e}", file=sys.stderr)
+        # Read-back of the sharded layout (outside the timed region): d_ray = (dist_real, dist_sim, last row) and the
+        # end points, gathered to rank 0 device-to-device from zero-copy views of the library's SoA state.
+        try:
+            t_ = batch.device_tensors()
+            loc = torch.stack((t_["dist_real"].double(), t_["dist_sim"].double(), t_["istep"].double(),
+                               t_["x"].double(), t_["y"].double())).to(cdev)            # [5, R_local]
+            Rmax = (R_total + world - 1) // world
+            if loc.shape[1] < Rmax:                                                      # ragged strong split: pad
+                loc = torch.cat((loc, torch.full((5, Rmax - loc.shape[1]), float("nan"), dtype=loc.dtype, device=loc.device)), 1)
+            g = [torch.empty_like(loc) for _ in range(world)] if rank == 0 else None
+            dist.gather(loc.contiguous(), g, dst=0)
+            if rank == 0:
+                allr = rd.interleave(g, R_total)                                         # ray k*world + r  <-  rank r, slot k
+                assert int(allr[2].sum().item()) * args.steps == total_steps
+                assert torch.isfinite(allr[3:5]).all()
+        except Exception as e:   # the timed result is already in hand; report and carry on
+            print(f"bench.py: read-back gather failed: {e}", file=sys.stderr)
     else:
         total_steps = steps_per_pass * args.steps
 
     if rank == 0:
         balg = alg_bytes_per_step(args.dtype, stride)
-        achieved = balg * steps_per_pass / (kern_ms * 1e-3) / 1e9
+        ksec = kern_ms * 1e-3
+        key = f"{args.scenario}:{R_local}:{args.record}:{args.dtype}:op{args.method}"
+        prof = {}
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}) or {}
+        except Exception:
+            prof = {}
+        if not isinstance(prof, dict):        # round-1 format: a bare byte count
+            prof = {"hbm_bytes": prof, "source": "profiles/r01_f_head_pmc_summary.txt"}
+        measured = prof.get("hbm_bytes") if args.chunk <= 0 and args.mode == "lane" else None
+        model = min_hbm_bytes(args.dtype, stride, steps_per_pass, R_local, args.method)
+        hbm_bytes = measured if measured else model
+        hbm = {"achieved": hbm_bytes / ksec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": hbm_bytes / ksec / 1e9 / HBM_PEAK_GBS,
+               "bytes_per_pass": hbm_bytes,
+               "bytes_source": prof.get("source") if measured else "model: recorded rows x 7 values + ray state in and out"}
+        roof = dict(hbm, bound="hbm", traffic=measured, traffic_source=prof.get("source") if measured else None)
+        # vector-ALU issue time from the profiled instruction mix: an fp64 wave-instruction holds its SIMD for 4 cycles
+        # (16 lanes/clk), any other VALU instruction for 2
+        if measured and prof.get("valu_insts"):
+            f64 = prof.get("valu_f64_insts", 0)
+            cyc = 4.0 * f64 + 2.0 * (prof["valu_insts"] - f64)
+            frac = cyc / SIMDS / PEAK_CLOCK_HZ / ksec
+            valu = {"achieved": cyc / ksec / 1e9, "peak": SIMDS * PEAK_CLOCK_HZ / 1e9, "unit": "G SIMD-cycles/s", "frac": frac,
+                    "valu_wave_insts_per_pass": prof["valu_insts"], "fp64_wave_insts_per_pass": f64}
+            roof["valu_issue"] = valu
+            if frac > roof["frac"]:
+                roof.update(bound="valu", achieved=valu["achieved"], peak=valu["peak"], unit=valu["unit"], frac=frac)
+        roof.update(kernel="k_trace_refill" if args.mode == "refill" else "k_advance", kernel_ms=kern_ms / launches,
+                    kernel_ms_per_pass=kern_ms, launches_per_pass=launches, ray_steps_per_pass=int(steps_per_pass),
+                    vgprs=st["vgprs"], hbm=hbm,
+                    alg_model={"bytes_per_ray_step": balg, "GB_per_s": balg * steps_per_pass / ksec / 1e9,
+                               "note": "SURVEY.md 8d accounting (state in/out + 36-coefficient gather per ray-step); not a "
+                                       "bound for this kernel: state stays in registers for all steps of a ray and the "
+                                       "gather is served from LDS/L2, so these bytes never reach HBM"})
         out = {
             "metric": "ray-steps/sec (whole node) on vert_heterogeneous, 1M rays; % HBM roofline",
             "value": total_steps / dt, "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.scenario}, {args.rays} rays/GPU (fan linspace over {R_total} rays, "
-                                   f"interleaved across ranks), op{args.method}, DELTA_S={step:.12g}, "
+            "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.scenario}, {R_total} rays in total ({R_local} on rank 0; fan linspace over {R_total} "
+                                   f"rays, interleaved across ranks), op{args.method}, DELTA_S={step:.12g}, "
                                    f"box={tuple(float(v) for v in lim)}, record={args.record}",
-                       "rays_per_gpu": args.rays, "ray_steps_per_pass_rank0": int(steps_per_pass),
+                       "rays_total": R_total, "rays_rank0": R_local, "ray_steps_per_pass_rank0": int(steps_per_pass),
                        "method": f"op{args.method}", "record": args.record, "launch_mode": args.mode,
-                       "ray_order": args.order, "sort_rays": bool(args.sort), "field_path": args.field_path, "steps_per_launch": args.chunk or "all", "parallelism": f"ray-shard x{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "k_trace_refill" if args.mode == "refill" else "k_advance", "kernel_ms": kern_ms, "alg_bytes_per_ray_step": balg,
-                         "ray_steps_per_launch": int(steps_per_pass), "vgprs": st["vgprs"]},
+                       "ray_order": args.order, "sort_rays": bool(args.sort), "field_path": args.field_path,
+                       "steps_per_launch": args.chunk or "all", "parallelism": f"ray-shard x{world}"},
+            "roofline": roof,
         }
-        fl = FLOPS_PER_RAY_STEP.get((args.method, args.dtype))
-        if fl:   # what actually limits the kernel: the fp64 vector ALU (reported beside the contract's HBM line)
-            tf = fl * steps_per_pass / (kern_ms * 1e-3) / 1e12
-            out["roofline"]["valu_fp64"] = {"achieved": tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                                            "frac": tf / FP64_VECTOR_PEAK_TFLOPS, "flops_per_ray_step": fl}
-        prof = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(prof):
-            try:
-                tr = json.load(open(prof))
-                key = f"{args.scenario}:{args.rays}:{args.record}:{args.dtype}:op{args.method}"
-                if key in tr:
-                    out["roofline"]["traffic"] = tr[key]
-            except Exception:
-                pass
         if world == 1 and args.cpu_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(args, rb, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(args, rb, args.cpu_seconds, R_local)
         print(json.dumps(out), flush=True)
     batch.close()
     fld.close()

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 1
+#define RTMI_ABI_VERSION 2
 
 typedef enum {
     RTMI_OK = 0,
@@ -95,6 +95,12 @@ typedef struct {
     /* optional caller-owned DEVICE buffers (e.g. torch tensors); NULL -> the library allocates */
     void *ext_s_ray;         /* [rec_rows][6][R] of dtype: x, y, p_x, p_y, T, theta (:802, :871-875) */
     void *ext_n_ray;         /* [rec_rows][R]   of dtype: coef*n (:803, :873) */
+    int32_t lazy_clear;      /* 0 (default): rtmi_batch_reset zeroes s_ray/n_ray like the reference's np.zeros (:802-803), so rows
+                                past a ray's last written row read 0 at every moment.  1: reset skips that memset when the re-run
+                                rewrites exactly the rows the previous run wrote (same launch conditions and steps; set_state /
+                                set_per_ray force a clear); until the re-run has finished, rows beyond a ray's CURRENT row still
+                                hold the previous pass's (identical) values -- for timed re-runs of one batch (bench.py) */
+    int32_t reserved0;       /* must be 0 */
 } rtmi_params;
 
 /* Upload R launch conditions (host pointers; x0/y0 per ray -- pos_x[k], -2 or the fisheye start, :809-813),
@@ -109,9 +115,12 @@ int rtmi_batch_create(const rtmi_field *f, const rtmi_params *p, int64_t R, cons
 int rtmi_batch_set_state(rtmi_batch *b, const double *state9, const double *hist4, const int32_t *istep);
 /* Give every ray its own DELTA_S and max_size (host arrays [R], caller's ray order): one batch then holds the whole
  * DELTA_S calibration sweep, candidate x ray (search_delta over delta_s_options, RT_bench.py:950-958, 1317-1318).
- * max_size[k] <= params.max_size (which sizes the trajectory arrays).  Survives rtmi_batch_reset. */
+ * max_size[k] <= params.max_size (which sizes the trajectory arrays).  Survives rtmi_batch_reset.  Only valid on a
+ * fresh or reset batch (RTMI_ERR_STATE after rtmi_step / rtmi_run / rtmi_batch_set_state): changing the steps of rays
+ * that are under way, or reviving rays that already left the box, has no counterpart in the reference. */
 int rtmi_batch_set_per_ray(rtmi_batch *b, const double *step, const int32_t *max_size);
-/* Back to row 0 with the same launch conditions (re-runs the initial conditions; clears trajectories). */
+/* Back to row 0 with the same launch conditions: re-runs the initial conditions and zeroes the trajectory arrays
+ * (caller-owned ext_s_ray / ext_n_ray included) unless params.lazy_clear is set, see there. */
 int rtmi_batch_reset(rtmi_batch *b);
 /* One launch that advances every live ray by at most nsteps DELTA_S steps (the body of the loop at :866-879;
  * nsteps = 1 is exactly one call of selected_func + store_update_results per ray). */
@@ -144,8 +153,9 @@ int rtmi_isochrones(rtmi_batch *b, int32_t ntimes, const double *times, double *
 
 typedef struct {
     void *s_ray, *n_ray;                 /* device, dtype, layouts above */
-    void *x, *y, *theta, *n, *gx, *gy;   /* device SoA ray state, dtype, length R */
-    void *dist_sim, *dist_real, *T;
+    double *x, *y, *theta;               /* device SoA ray state, length R: the accumulated quantities are fp64 in */
+    void *n, *gx, *gy;                   /*   BOTH precisions (fp32 batches add fp32 increments onto fp64 sums); */
+    double *dist_sim, *dist_real, *T;    /*   n and its gradient are of the batch's dtype */
     int32_t *istep;                      /* device, last written row per ray */
     const int32_t *perm;                 /* device [R] or NULL: with sort_rays, slot k of every array above holds the
                                             caller's ray perm[k] */

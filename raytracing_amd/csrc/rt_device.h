@@ -43,12 +43,14 @@ __device__ __forceinline__ void sincos_k(double x, double* sp, double* cp) {
     *cp = ((q + 1) & 2) ? -cc : cc;
 }
 
-// fp32 sincos: the reduction by pi/2 is done in fp64 (one fma, exact enough for any |x| < 2^30), the minimax
+// fp32 sincos of an fp64 angle (the angle is one of the fp64 accumulators of a ray): the reduction by pi/2 is done in
+// fp64 (one fma, exact enough for any |x| < 2^30) so the angle's low bits are not lost before the trig, the minimax
 // kernels on [-pi/4, pi/4] in fp32; ~1 ulp.  The reference has no fp32 path, so this defines it.
-__device__ __forceinline__ void sincos_kf(float x, float* sp, float* cp) {
-    const float n = __builtin_rintf(x * 6.3661977237e-01f);
-    float r = (float)fma_(-(double)n, 1.57079632679489655800e+00, (double)x);
-    r = __builtin_fabsf(x) < 1073741824.0f ? r : __builtin_nanf("");
+__device__ __forceinline__ void sincos_kf(double x, float* sp, float* cp) {
+    const float xf = (float)x;
+    const float n = __builtin_rintf(xf * 6.3661977237e-01f);
+    float r = (float)fma_(-(double)n, 1.57079632679489655800e+00, x);
+    r = __builtin_fabsf(xf) < 1073741824.0f ? r : __builtin_nanf("");
     const float z = r * r;
     float ps = fma_(z, 2.7557314297e-06f, -1.9841270114e-04f);
     ps = fma_(z, ps, 8.3333337680e-03f);
@@ -94,7 +96,7 @@ template <> struct M<float> {
     // fp32 is the reduced-precision path (no reference to match bit for bit): hardware sqrt/rcp (1 ulp)
     static __device__ __forceinline__ float sqrt_(float x) { return __builtin_amdgcn_sqrtf(x); }
     static __device__ __forceinline__ float sqrt_full(float x) { return __builtin_amdgcn_sqrtf(x); }
-    static __device__ __forceinline__ void sincos_(float x, float* s, float* c) { sincos_kf(x, s, c); }
+    static __device__ __forceinline__ void sincos_(double x, float* s, float* c) { sincos_kf(x, s, c); }
     static __device__ __forceinline__ float atan2_(float y, float x) { return ::atan2f(y, x); }
     static __device__ __forceinline__ float abs_(float x) { return __builtin_fabsf(x); }
     static __device__ __forceinline__ float max_(float x, float y) { return __builtin_fmaxf(x, y); }
@@ -106,7 +108,7 @@ template <> struct M<float> {
 
 // sin/cos of (theta + k) given s = sin(theta), c = cos(theta): for |k| < 2^-6 the angle-addition formulas
 // with 4-term series of sin k and 1 - cos k (truncation < 1e-19 relative), else a full evaluation.
-template <typename T> __device__ __forceinline__ void sincos_add(T theta, T s, T c, T k, T* so, T* co) {
+template <typename T> __device__ __forceinline__ void sincos_add(double theta, T s, T c, T k, T* so, T* co) {
     if (M<T>::abs_(k) < M<T>::small_angle) {
         const T z = k * k;
         T ps = fma_(z, T(-1.0 / 5040.0), T(1.0 / 120.0));
@@ -119,7 +121,7 @@ template <typename T> __device__ __forceinline__ void sincos_add(T theta, T s, T
         *so = fma_(c, sk, fma_(-s, ck1, s));
         *co = fma_(-s, sk, fma_(-c, ck1, c));
     } else {
-        M<T>::sincos_(theta + k, so, co);
+        M<T>::sincos_(theta + (double)k, so, co);
     }
 }
 
@@ -441,14 +443,21 @@ __device__ __forceinline__ void n_gradient(const FieldDev<T>& F, G& gather, bool
 }
 
 // ---------------------------------------------------------------- per-ray state
+// The six quantities a ray ACCUMULATES over thousands of steps -- position, angle, the two arclengths, traveltime --
+// are fp64 in both precisions (in registers and in HBM).  With T = float the field, its lookup and the whole step
+// arithmetic are fp32 and each step's increment is formed in fp32, then added to the fp64 accumulator: adding 2.6e-3
+// steps onto coordinates of order 5 in fp32 would round every step to 2.4e-7.  With T = double nothing changes.
+using Acc = double;
 template <typename T> struct Ray {
-    T x, y, th, n, gx, gy;   // position, angle, index, gradient at the current point
+    Acc x, y, th;            // position, angle (accumulators)
+    T n, gx, gy;             // index, gradient at the current point
     T ux, uy, coef, nray;    // derived: unit tangent, anisotropy(theta,gamma), coef*n
     T rn;                    // derived: 1/n (rcp_full, < 1 ulp), shared by the three divisions by n of a step
-    T dsim, dreal, tt;       // simulated / expected arclength, traveltime
+    Acc dsim, dreal, tt;     // simulated / expected arclength, traveltime (accumulators)
     T mx, my;                // momenta of the current row (output only)
     T hx0, hy0, hx1, hy1;    // op7: the two positions before (x,y), oldest first (VECTOR_LIST, Q11)
 };
+template <typename T> constexpr bool kMixed = !__is_same(T, double);   // fp32 arithmetic on fp64 accumulators
 
 template <typename T> struct Consts {
     T step, step2h;          // DELTA_S and pow(DELTA_S, 2)/2 (host-computed from numpy's step**2, :330)
@@ -472,18 +481,28 @@ template <typename T, bool ISO> __device__ __forceinline__ T moment(T n, T coef,
 template <typename T> __device__ __forceinline__ T impulse(T a, T b, T step) { return step * (a + b) * T(0.5); }
 
 // ---- advancement (:300-365)
-template <typename T> __device__ __forceinline__ void adv_first(const Ray<T>& r, T step, T& fx, T& fy) {
-    fx = fma_(r.ux, step, r.x);
-    fy = fma_(r.uy, step, r.y);
+template <typename T> __device__ __forceinline__ void adv_first(const Ray<T>& r, T step, Acc& fx, Acc& fy) {
+    if constexpr (kMixed<T>) {
+        fx = r.x + (Acc)(r.ux * step);
+        fy = r.y + (Acc)(r.uy * step);
+    } else {
+        fx = fma_(r.ux, step, r.x);
+        fy = fma_(r.uy, step, r.y);
+    }
 }
-template <typename T> __device__ __forceinline__ void adv_second(const Ray<T>& r, const Consts<T>& k, T& fx, T& fy) {
+template <typename T> __device__ __forceinline__ void adv_second(const Ray<T>& r, const Consts<T>& k, Acc& fx, Acc& fy) {
     const T d = fma_(r.gy, r.uy, r.gx * r.ux);  // np.dot on 2 elements rounds exactly like this
     const T s = k.step2h * r.rn;                // step**2 / (2 n)
-    fx = fma_(fma_(-d, r.ux, r.gx), s, fma_(r.ux, k.step, r.x));
-    fy = fma_(fma_(-d, r.uy, r.gy), s, fma_(r.uy, k.step, r.y));
+    if constexpr (kMixed<T>) {
+        fx = r.x + (Acc)fma_(fma_(-d, r.ux, r.gx), s, r.ux * k.step);
+        fy = r.y + (Acc)fma_(fma_(-d, r.uy, r.gy), s, r.uy * k.step);
+    } else {
+        fx = fma_(fma_(-d, r.ux, r.gx), s, fma_(r.ux, k.step, r.x));
+        fy = fma_(fma_(-d, r.uy, r.gy), s, fma_(r.uy, k.step, r.y));
+    }
 }
 // returns the reference's flag: true == curvature NOT negligible (quirk Q14)
-template <typename T> __device__ __forceinline__ bool adv_curv(const Ray<T>& r, const Consts<T>& k, T& fx, T& fy) {
+template <typename T> __device__ __forceinline__ bool adv_curv(const Ray<T>& r, const Consts<T>& k, Acc& fx, Acc& fy) {
     const T d = fma_(r.gy, r.uy, r.gx * r.ux);
     const T vx = fma_(-d, r.ux, r.gx), vy = fma_(-d, r.uy, r.gy);
     const T curv = M<T>::sqrt_full(fma_(vy, vy, vx * vx)) * r.rn;   // may be exactly 0: full-range sqrt
@@ -494,25 +513,30 @@ template <typename T> __device__ __forceinline__ bool adv_curv(const Ray<T>& r, 
     const T dc = curv * k.step;
     const bool neg = r.gx * r.uy - r.gy * r.ux > T(0);  // np.cross (:360), two rounded products
     T s2, c2;
-    M<T>::sincos_(neg ? r.th - dc : r.th + dc, &s2, &c2);
+    M<T>::sincos_(neg ? r.th - (Acc)dc : r.th + (Acc)dc, &s2, &c2);
     // (:361) [sin th - sin(th-dc), cos(th-dc) - cos th]/curv ; (:363) [sin(th+dc) - sin th, -cos(th+dc) + cos th]/curv
     const T rc = T(1) / curv;
-    fx = fma_(neg ? (r.uy - s2) : (s2 - r.uy), rc, r.x);
-    fy = fma_(neg ? (c2 - r.ux) : (-c2 + r.ux), rc, r.y);
+    if constexpr (kMixed<T>) {
+        fx = r.x + (Acc)((neg ? (r.uy - s2) : (s2 - r.uy)) * rc);
+        fy = r.y + (Acc)((neg ? (c2 - r.ux) : (-c2 + r.ux)) * rc);
+    } else {
+        fx = fma_(neg ? (r.uy - s2) : (s2 - r.uy), rc, r.x);
+        fy = fma_(neg ? (c2 - r.ux) : (-c2 + r.ux), rc, r.y);
+    }
     return true;
 }
 
 // ---- angle determination (:370-407)
 // fn_rcp = 1/fn; the intermediate angle theta+k1 is never stored, so its sin/cos come from sincos_add.
-template <typename T> __device__ __forceinline__ T ang_rk2(const Ray<T>& r, T step, T fn_rcp, T fgx, T fgy) {
+template <typename T> __device__ __forceinline__ Acc ang_rk2(const Ray<T>& r, T step, T fn_rcp, T fgx, T fgy) {
     const T k1 = step * fma_(r.ux, r.gy, -(r.uy * r.gx)) * r.rn;
     T s2, c2;
     sincos_add(r.th, r.uy, r.ux, k1, &s2, &c2);
     const T k2 = step * fma_(c2, fgy, -(s2 * fgx)) * fn_rcp;
-    return r.th + (k1 + k2) * T(0.5);
+    return r.th + (Acc)((k1 + k2) * T(0.5));
 }
-template <typename T> __device__ __forceinline__ T ang_cost(const Ray<T>& r, T step, T fgx, T fgy) {
-    return M<T>::atan2_(fma_(r.n, r.uy, impulse(r.gy, fgy, step)), fma_(r.n, r.ux, impulse(r.gx, fgx, step)));
+template <typename T> __device__ __forceinline__ Acc ang_cost(const Ray<T>& r, T step, T fgx, T fgy) {
+    return (Acc)M<T>::atan2_(fma_(r.n, r.uy, impulse(r.gy, fgy, step)), fma_(r.n, r.ux, impulse(r.gx, fgx, step)));
 }
 
 // golden() (:175-199) on a cost functor; recomputes both cost values every iteration like the
@@ -539,7 +563,7 @@ template <typename T> __device__ __forceinline__ T ang_golden_iso(const Ray<T>& 
         const T ex = fma_(fn, c, -px) - ix, ey = fma_(fn, s, -py) - iy;
         return fma_(ey, ey, ex * ex);
     };
-    return golden<T>(cost, r.th - T(kHalfPi), r.th + T(kHalfPi));
+    return golden<T>(cost, (T)r.th - T(kHalfPi), (T)r.th + T(kHalfPi));
 }
 template <typename T>
 __device__ __forceinline__ T ang_golden_aniso(const Ray<T>& r, const Consts<T>& k, T fn, T fgx, T fgy) {
@@ -559,51 +583,51 @@ __device__ __forceinline__ T ang_golden_aniso(const Ray<T>& r, const Consts<T>& 
         const T ey = q * s * fma_(c * c, w, T(1)) - miy - (cgy + a * fgy) * hstep;
         return fma_(ey, ey, ex * ex);
     };
-    return golden<T>(cost, r.th - T(kHalfPi), r.th + T(kHalfPi));
+    return golden<T>(cost, (T)r.th - T(kHalfPi), (T)r.th + T(kHalfPi));
 }
 
 // ---- opN (:469-764), split around the field lookup: advancement, then angle determination
 template <typename T, int METHOD>
-__device__ __forceinline__ bool op_advance(const Consts<T>& k, const Ray<T>& r, T& fx, T& fy) {
+__device__ __forceinline__ bool op_advance(const Consts<T>& k, const Ray<T>& r, Acc& fx, Acc& fy) {
     if constexpr (METHOD == 1 || METHOD == 2) { adv_first(r, k.step, fx, fy); return true; }
     else if constexpr (METHOD == 3 || METHOD == 4 || METHOD == 5 || METHOD == 10) return adv_curv(r, k, fx, fy);
     else { adv_second(r, k, fx, fy); return true; }
 }
 template <typename T, int METHOD>
-__device__ __forceinline__ T op_angle(const Consts<T>& k, const Ray<T>& r, bool flag, T fx, T fy, T fn, T fgx, T fgy, T frn) {
+__device__ __forceinline__ Acc op_angle(const Consts<T>& k, const Ray<T>& r, bool flag, Acc fx, Acc fy, T fn, T fgx, T fgy, T frn) {
     if constexpr (METHOD == 1 || METHOD == 8) return ang_cost(r, k.step, fgx, fgy);
     else if constexpr (METHOD == 2 || METHOD == 6) return ang_rk2(r, k.step, frn, fgx, fgy);
     else if constexpr (METHOD == 3) return flag ? ang_rk2(r, k.step, frn, fgx, fgy) : r.th;
     else if constexpr (METHOD == 4) return flag ? ang_cost(r, k.step, fgx, fgy) : r.th;
-    else if constexpr (METHOD == 5) return flag ? ang_golden_iso(r, k.step, fn, fgx, fgy) : r.th;
-    else if constexpr (METHOD == 9) return ang_golden_iso(r, k.step, fn, fgx, fgy);
-    else if constexpr (METHOD == 10) return flag ? ang_golden_aniso(r, k, fn, fgx, fgy) : r.th;
-    else if constexpr (METHOD == 11) return ang_golden_aniso(r, k, fn, fgx, fgy);
-    else {  // 7: finite_diff (:370-372) over [P0, P1, P2, P3] = [h0, h1, (x,y), f]
-        const T vx = T(11) * fx - T(18) * r.x + T(9) * r.hx1 - T(2) * r.hx0;
-        const T vy = T(11) * fy - T(18) * r.y + T(9) * r.hy1 - T(2) * r.hy0;
-        return M<T>::atan2_(vy, vx);
+    else if constexpr (METHOD == 5) return flag ? (Acc)ang_golden_iso(r, k.step, fn, fgx, fgy) : r.th;
+    else if constexpr (METHOD == 9) return (Acc)ang_golden_iso(r, k.step, fn, fgx, fgy);
+    else if constexpr (METHOD == 10) return flag ? (Acc)ang_golden_aniso(r, k, fn, fgx, fgy) : r.th;
+    else if constexpr (METHOD == 11) return (Acc)ang_golden_aniso(r, k, fn, fgx, fgy);
+    else {  // 7: finite_diff (:370-372) over [P0, P1, P2, P3] = [h0, h1, (x,y), f]; position differences in fp64
+        const T vx = (T)(Acc(11) * fx - Acc(18) * r.x + Acc(9) * (Acc)r.hx1 - Acc(2) * (Acc)r.hx0);
+        const T vy = (T)(Acc(11) * fy - Acc(18) * r.y + Acc(9) * (Acc)r.hy1 - Acc(2) * (Acc)r.hy0);
+        return (Acc)M<T>::atan2_(vy, vx);
     }
 }
 
 // store_update_results (:783-790) + the row bookkeeping of the loop body (:871-875)
 template <typename T, bool ISO>
-__device__ __forceinline__ void store_update(const Consts<T>& k, Ray<T>& r, T fx, T fy, T fth, T fn, T fgx, T fgy,
+__device__ __forceinline__ void store_update(const Consts<T>& k, Ray<T>& r, Acc fx, Acc fy, Acc fth, T fn, T fgx, T fgy,
                                              T frn) {
-    const T dx = r.x - fx, dy = r.y - fy;
+    const T dx = (T)(r.x - fx), dy = (T)(r.y - fy);
     const T dist = M<T>::sqrt_(fma_(dy, dy, dx * dx));  // np.linalg.norm on 2 elements
-    r.dsim += dist;
-    r.dreal += k.step;  // quirk Q16: accumulated, not i*step
+    r.dsim += (Acc)dist;
+    r.dreal += (Acc)k.step;  // quirk Q16: accumulated, not i*step
     T s, c;
     M<T>::sincos_(fth, &s, &c);
     const T coef = aniso<T, ISO>(s, c, k.gamma);
     r.mx = moment<T, ISO>(fn, coef, k.g2m1, c, -(s * s));
     r.my = moment<T, ISO>(fn, coef, k.g2m1, s, c * c);
-    r.hx0 = r.hx1; r.hy0 = r.hy1; r.hx1 = r.x; r.hy1 = r.y;
+    r.hx0 = r.hx1; r.hy0 = r.hy1; r.hx1 = (T)r.x; r.hy1 = (T)r.y;
     r.x = fx; r.y = fy; r.th = fth; r.n = fn; r.gx = fgx; r.gy = fgy; r.rn = frn;
     r.ux = c; r.uy = s; r.coef = coef;
     const T nray = coef * fn;                               // (:873)
-    r.tt = r.tt + dist * (r.nray + nray) * T(0.5);          // (:874) quirk Q6
+    r.tt = r.tt + (Acc)(dist * (r.nray + nray) * T(0.5));   // (:874) quirk Q6
     r.nray = nray;
 }
 
@@ -618,7 +642,7 @@ template <typename T, bool ISO> __device__ __forceinline__ void derive(const Con
 }
 
 template <typename T> __device__ __forceinline__ bool outside(const Consts<T>& k, const Ray<T>& r) {  // (:878)
-    return r.x > k.box[1] || r.x < k.box[0] || r.y > k.box[3] || r.y < k.box[2];
+    return r.x > (Acc)k.box[1] || r.x < (Acc)k.box[0] || r.y > (Acc)k.box[3] || r.y < (Acc)k.box[2];
 }
 
 }  // namespace rt
@@ -642,16 +666,17 @@ __device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& 
     if constexpr (IsExact<T, METHOD>::value) {
         return ex::ray_step<METHOD>(F, k, gather, active, r);
     } else {
-    T fx, fy, fth, fn, fgx, fgy;
+    Acc fx, fy, fth;
+    T fn, fgx, fgy;
     const bool flag = op_advance<T, METHOD>(k, r, fx, fy);
-    n_gradient(F, gather, active, fx, fy, fn, fgx, fgy);
+    n_gradient(F, gather, active, (T)fx, (T)fy, fn, fgx, fgy);
     const T frn = rcp_full(fn);
     bool boot = false;
     if (METHOD == 7 && i <= 2) {
         T vx, vy;
-        if (i == 1) { vx = fx - r.x; vy = fy - r.y; }                                          // (:843)
-        else { vx = T(3) * fx - T(4) * r.x + r.hx1; vy = T(3) * fy - T(4) * r.y + r.hy1; }     // (:856)
-        fth = M<T>::atan2_(vy, vx);
+        if (i == 1) { vx = (T)(fx - r.x); vy = (T)(fy - r.y); }                                // (:843)
+        else { vx = (T)(Acc(3) * fx - Acc(4) * r.x + (Acc)r.hx1); vy = (T)(Acc(3) * fy - Acc(4) * r.y + (Acc)r.hy1); }   // (:856)
+        fth = (Acc)M<T>::atan2_(vy, vx);
         boot = true;  // no boundary test in the bootstrap
     } else {
         fth = op_angle<T, METHOD>(k, r, flag, fx, fy, fn, fgx, fgy, frn);

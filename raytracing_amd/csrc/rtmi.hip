@@ -56,6 +56,25 @@ struct rtmi_field {
     hipStream_t stream = nullptr;
 };
 
+// A field's device memory is only valid on the device it was built on; callers that switch devices
+// (rtmi_set_device, torch.cuda.set_device) get RTMI_ERR_ARG instead of a cross-device access.
+static hipError_t check_device_impl(const rtmi_field* f, const char* who, int* rc) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev != f->device) {
+        *rc = fail(RTMI_ERR_ARG, std::string(who) + ": the field lives on device " + std::to_string(f->device) +
+                                     " but the current device is " + std::to_string(dev));
+    }
+    return hipSuccess;
+}
+#define DEVICE_TRY(f, who)                                  \
+    do {                                                    \
+        int rc_ = RTMI_OK;                                  \
+        HIP_TRY(check_device_impl((f), (who), &rc_));       \
+        if (rc_) return rc_;                                \
+    } while (0)
+
 template <typename T> static rt::FieldDev<T> field_dev(const rtmi_field* f, int exact) {
     rt::FieldDev<T> F;
     F.exact = exact;
@@ -215,29 +234,34 @@ static int field_finish_impl(rtmi_field* f, double delta) {
     const std::vector<double> lux = collocation_lu(linspace(f->ax, f->bx, qx));
     const std::vector<double> luy = collocation_lu(linspace(f->ay, f->by, qy));
     double *dlux = nullptr, *dluy = nullptr;
-    HIP_TRY(hipMalloc(&dlux, lux.size() * sizeof(double)));
-    HIP_TRY(hipMalloc(&dluy, luy.size() * sizeof(double)));
-    HIP_TRY(hipMemcpyAsync(dlux, lux.data(), lux.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(dluy, luy.data(), luy.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    for (double* c : {f->dCdy, f->dCdx}) {
-        hipLaunchKernelGGL(k_solve_lines, dim3((qy + 63) / 64), dim3(64), 0, st, c, qx, qy, 1L, (long)qx, dlux);
-        hipLaunchKernelGGL(k_solve_lines, dim3((qx + 63) / 64), dim3(64), 0, st, c, qy, qx, (long)qx, 1L, dluy);
-    }
-    HIP_TRY(hipGetLastError());
-    const size_t esz = f->dtype == RTMI_F64 ? 8 : 4;
-    HIP_TRY(hipMalloc(&f->zn, nz * esz));
-    HIP_TRY(hipMalloc(&f->g, 2 * nz * esz));
-    if (f->dtype == RTMI_F64)
-        hipLaunchKernelGGL(k_pack<double>, dim3((nz + 255) / 256), dim3(256), 0, st, f->dZ, f->dCdy, f->dCdx,
-                           (double*)f->zn, (double*)f->g, nz);
-    else
-        hipLaunchKernelGGL(k_pack<float>, dim3((nz + 255) / 256), dim3(256), 0, st, f->dZ, f->dCdy, f->dCdx,
-                           (float*)f->zn, (float*)f->g, nz);
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));  // host vectors / LU buffers go out of scope
-    HIP_TRY(hipFree(dlux));
-    HIP_TRY(hipFree(dluy));
-    return RTMI_OK;
+    auto solve_and_pack = [&]() -> int {   // dlux/dluy are released below whatever this returns
+        HIP_TRY(hipMalloc(&dlux, lux.size() * sizeof(double)));
+        HIP_TRY(hipMalloc(&dluy, luy.size() * sizeof(double)));
+        HIP_TRY(hipMemcpyAsync(dlux, lux.data(), lux.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(dluy, luy.data(), luy.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        for (double* c : {f->dCdy, f->dCdx}) {
+            hipLaunchKernelGGL(k_solve_lines, dim3((qy + 63) / 64), dim3(64), 0, st, c, qx, qy, 1L, (long)qx, dlux);
+            hipLaunchKernelGGL(k_solve_lines, dim3((qx + 63) / 64), dim3(64), 0, st, c, qy, qx, (long)qx, 1L, dluy);
+        }
+        HIP_TRY(hipGetLastError());
+        const size_t esz = f->dtype == RTMI_F64 ? 8 : 4;
+        HIP_TRY(hipMalloc(&f->zn, nz * esz));
+        HIP_TRY(hipMalloc(&f->g, 2 * nz * esz));
+        if (f->dtype == RTMI_F64)
+            hipLaunchKernelGGL(k_pack<double>, dim3((nz + 255) / 256), dim3(256), 0, st, f->dZ, f->dCdy, f->dCdx,
+                               (double*)f->zn, (double*)f->g, nz);
+        else
+            hipLaunchKernelGGL(k_pack<float>, dim3((nz + 255) / 256), dim3(256), 0, st, f->dZ, f->dCdy, f->dCdx,
+                               (float*)f->zn, (float*)f->g, nz);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));  // host vectors / LU buffers go out of scope
+        return RTMI_OK;
+    };
+    const int rc = solve_and_pack();
+    if (rc) (void)hipStreamSynchronize(st);   // nothing may still read the LU buffers
+    (void)hipFree(dlux);
+    (void)hipFree(dluy);
+    return rc;
 }
 
 static int field_finish(rtmi_field* f, double delta) {
@@ -332,6 +356,7 @@ RTMI_EXPORT int rtmi_field_dims(const rtmi_field* f, int* qx, int* qy) {
 
 RTMI_EXPORT int rtmi_field_read(const rtmi_field* f, double* x, double* y, double* Z, double* cdy, double* cdx) {
     ARG_TRY(f, "rtmi_field_read: null field");
+    DEVICE_TRY(f, "rtmi_field_read");
     const size_t nz = (size_t)f->qx * f->qy * sizeof(double);
     HIP_TRY(hipStreamSynchronize(f->stream));
     try {
@@ -350,6 +375,7 @@ RTMI_EXPORT int rtmi_field_eval(const rtmi_field* f, int64_t npts, const double*
                                 double* gx, double* gy) {
     ARG_TRY(f && x && y && n && gx && gy, "rtmi_field_eval: null");
     ARG_TRY(npts >= 0, "rtmi_field_eval: npts < 0");
+    DEVICE_TRY(f, "rtmi_field_eval");
     if (npts == 0) return RTMI_OK;
     double* d = nullptr;
     const size_t nb = (size_t)npts * sizeof(double);
@@ -384,14 +410,14 @@ template <typename T> struct BatchDev {
     int max_size;
     int stride;       // record stride (0 = none)
     long rec_rows;
-    // SoA state
-    // SoA state: ONE slab pointer (arrays x, y, theta, n, gx, gy, dist_sim, dist_real, T, then op7's four history
-    // arrays, each [R]); the per-array pointers are formed where they are used so that the step loop keeps two
-    // scalar registers live instead of twenty
-    T* st;
-    int has_hist;     // op7 only: hx0, hy0, hx1, hy1 follow the nine state arrays
+    // SoA state in ONE slab: six fp64 accumulator arrays (x, y, theta, dist_sim, dist_real, T; fp64 in both precisions,
+    // see rt::Ray) followed by dtype arrays n, gx, gy and op7's four history arrays, each [R].  The per-array pointers
+    // are formed where they are used so that the step loop keeps a few scalar registers live instead of twenty.
+    double* st;
+    int has_hist;     // op7 only: hx0, hy0, hx1, hy1 follow n, gx, gy
     int exact;        // fp64 op3/4/5/9/10/11: derived values and lookups in the reference's operation order (rt_exact.h)
-    __device__ __forceinline__ T* arr(int q) const { return st + (size_t)q * R; }
+    __device__ __forceinline__ double* acc(int q) const { return st + (size_t)q * R; }                 // 0..5: x y th dsim dreal tt
+    __device__ __forceinline__ T* aux(int q) const { return reinterpret_cast<T*>(st + (size_t)6 * R) + (size_t)q * R; }   // 0..2: n gx gy; 3..6: history
     int* istep;
     unsigned char* alive;
     T *s_ray, *n_ray;
@@ -404,7 +430,7 @@ template <typename T> struct BatchDev {
 
 template <typename T> __device__ __forceinline__ void write_row(const BatchDev<T>& a, long row, long k, const rt::Ray<T>& r) {
     T* p = a.s_ray + (size_t)row * 6 * a.R + k;
-    p[0] = r.x; p[a.R] = r.y; p[2 * a.R] = r.mx; p[3 * a.R] = r.my; p[4 * a.R] = r.tt; p[5 * a.R] = r.th;
+    p[0] = (T)r.x; p[a.R] = (T)r.y; p[2 * a.R] = r.mx; p[3 * a.R] = r.my; p[4 * a.R] = (T)r.tt; p[5 * a.R] = (T)r.th;
     if (a.n_ray) a.n_ray[(size_t)row * a.R + k] = r.nray;
 }
 
@@ -427,13 +453,13 @@ template <typename T> __global__ void k_init(BatchDev<T> a) {
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.R) return;
     rt::Ray<T> r;
-    r.x = (T)a.x0[k]; r.y = (T)a.y0[k]; r.th = (T)a.th0[k];
-    n_gradient_rt(a, r.x, r.y, r.n, r.gx, r.gy);
+    r.x = a.x0[k]; r.y = a.y0[k]; r.th = a.th0[k];
+    n_gradient_rt(a, (T)r.x, (T)r.y, r.n, r.gx, r.gy);
     derive_rt(a, r);
     r.dsim = 0; r.dreal = 0; r.tt = 0;
-    a.arr(0)[k] = r.x; a.arr(1)[k] = r.y; a.arr(2)[k] = r.th; a.arr(3)[k] = r.n; a.arr(4)[k] = r.gx; a.arr(5)[k] = r.gy;
-    a.arr(6)[k] = 0; a.arr(7)[k] = 0; a.arr(8)[k] = 0;
-    if (a.has_hist) { a.arr(9)[k] = 0; a.arr(10)[k] = 0; a.arr(11)[k] = 0; a.arr(12)[k] = 0; }
+    a.acc(0)[k] = r.x; a.acc(1)[k] = r.y; a.acc(2)[k] = r.th; a.aux(0)[k] = r.n; a.aux(1)[k] = r.gx; a.aux(2)[k] = r.gy;
+    a.acc(3)[k] = 0; a.acc(4)[k] = 0; a.acc(5)[k] = 0;
+    if (a.has_hist) { a.aux(3)[k] = 0; a.aux(4)[k] = 0; a.aux(5)[k] = 0; a.aux(6)[k] = 0; }
     a.istep[k] = 0;
     a.alive[k] = max_size_of(a, k) > 1;
     if (a.stride && a.rec_rows > 0) write_row(a, 0, k, r);
@@ -464,18 +490,18 @@ __global__ void k_stats(const int* istep, const unsigned char* alive, long R, un
 
 template <typename T, int METHOD, bool ISO>
 __device__ __forceinline__ void load_ray(const BatchDev<T>& a, long k, rt::Ray<T>& r, int& i) {
-    r.x = a.arr(0)[k]; r.y = a.arr(1)[k]; r.th = a.arr(2)[k]; r.n = a.arr(3)[k]; r.gx = a.arr(4)[k]; r.gy = a.arr(5)[k];
-    r.dsim = a.arr(6)[k]; r.dreal = a.arr(7)[k]; r.tt = a.arr(8)[k];
-    if (METHOD == 7) { r.hx0 = a.arr(9)[k]; r.hy0 = a.arr(10)[k]; r.hx1 = a.arr(11)[k]; r.hy1 = a.arr(12)[k]; }
+    r.x = a.acc(0)[k]; r.y = a.acc(1)[k]; r.th = a.acc(2)[k]; r.n = a.aux(0)[k]; r.gx = a.aux(1)[k]; r.gy = a.aux(2)[k];
+    r.dsim = a.acc(3)[k]; r.dreal = a.acc(4)[k]; r.tt = a.acc(5)[k];
+    if (METHOD == 7) { r.hx0 = a.aux(3)[k]; r.hy0 = a.aux(4)[k]; r.hx1 = a.aux(5)[k]; r.hy1 = a.aux(6)[k]; }
     else { r.hx0 = r.hy0 = r.hx1 = r.hy1 = 0; }
     if constexpr (rt::IsExact<T, METHOD>::value) rt::ex::derive(a.K, r); else rt::derive<T, ISO>(a.K, r);
     i = a.istep[k];
 }
 template <typename T, int METHOD>
 __device__ __forceinline__ void store_ray(const BatchDev<T>& a, long k, const rt::Ray<T>& r, int i, bool alive) {
-    a.arr(0)[k] = r.x; a.arr(1)[k] = r.y; a.arr(2)[k] = r.th; a.arr(3)[k] = r.n; a.arr(4)[k] = r.gx; a.arr(5)[k] = r.gy;
-    a.arr(6)[k] = r.dsim; a.arr(7)[k] = r.dreal; a.arr(8)[k] = r.tt;
-    if (METHOD == 7) { a.arr(9)[k] = r.hx0; a.arr(10)[k] = r.hy0; a.arr(11)[k] = r.hx1; a.arr(12)[k] = r.hy1; }
+    a.acc(0)[k] = r.x; a.acc(1)[k] = r.y; a.acc(2)[k] = r.th; a.aux(0)[k] = r.n; a.aux(1)[k] = r.gx; a.aux(2)[k] = r.gy;
+    a.acc(3)[k] = r.dsim; a.acc(4)[k] = r.dreal; a.acc(5)[k] = r.tt;
+    if (METHOD == 7) { a.aux(3)[k] = r.hx0; a.aux(4)[k] = r.hy0; a.aux(5)[k] = r.hx1; a.aux(6)[k] = r.hy1; }
     a.istep[k] = i;
     a.alive[k] = alive;
 }
@@ -620,13 +646,13 @@ template <typename T> __global__ void k_pack_d_ray(BatchDev<T> a, double* out) {
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.R) return;
     const long o = out_index(a, k);
-    out[o] = (double)a.arr(7)[k]; out[a.R + o] = (double)a.arr(6)[k]; out[2 * a.R + o] = (double)a.istep[k];  // :888-890
+    out[o] = a.acc(4)[k]; out[a.R + o] = a.acc(3)[k]; out[2 * a.R + o] = (double)a.istep[k];  // :888-890
 }
 template <typename T> __global__ void k_pack_final(BatchDev<T> a, double* out) {
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.R) return;
     rt::Ray<T> r;
-    r.x = a.arr(0)[k]; r.y = a.arr(1)[k]; r.th = a.arr(2)[k]; r.n = a.arr(3)[k]; r.gx = a.arr(4)[k]; r.gy = a.arr(5)[k]; r.tt = a.arr(8)[k];
+    r.x = a.acc(0)[k]; r.y = a.acc(1)[k]; r.th = a.acc(2)[k]; r.n = a.aux(0)[k]; r.gx = a.aux(1)[k]; r.gy = a.aux(2)[k]; r.tt = a.acc(5)[k];
     derive_rt(a, r);
     const double v[9] = {(double)r.x, (double)r.y, (double)r.th, (double)r.n, (double)r.gx, (double)r.gy,
                          (double)r.mx, (double)r.my, (double)r.tt};
@@ -645,7 +671,7 @@ struct rtmi_batch {
     int64_t R = 0;
     size_t esz = 8;
     hipStream_t stream = nullptr;
-    void* state = nullptr;       // one slab: 9 (+4) dtype arrays
+    void* state = nullptr;       // one slab: 6 fp64 accumulator arrays, then 3 (+4) dtype arrays
     int* istep = nullptr;
     unsigned char* alive = nullptr;
     void *s_ray = nullptr, *n_ray = nullptr;
@@ -663,7 +689,8 @@ struct rtmi_batch {
     const void* kfn = nullptr;
     const void* kfn_refill = nullptr;
     int persistent_blocks = 0;   // resident 256-thread blocks of the refill kernel on this device
-    bool dirty = false;          // rtmi_batch_set_state ran since the trajectories were last cleared
+    bool dirty = false;          // rows may hold data a re-run will not overwrite (set_state / set_per_ray since the last clear)
+    bool dirty_state = false;    // rtmi_batch_set_state ran since create / reset
 };
 
 template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
@@ -677,9 +704,8 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     a.K.gamma_s = (T)p.gamma_step; a.K.g2m1_s = (T)(p.gamma_step * p.gamma_step - 1.0);
     for (int i = 0; i < 4; i++) a.K.box[i] = (T)p.box[i];
     a.R = b->R; a.max_size = p.max_size; a.stride = p.record_stride; a.rec_rows = p.rec_rows;
-    T* s = (T*)b->state;
     const size_t R = (size_t)b->R;
-    a.st = s; a.has_hist = p.method == 7;
+    a.st = (double*)b->state; a.has_hist = p.method == 7;
     a.exact = p.dtype == RTMI_F64 && rt::is_exact_method(p.method);
     a.istep = b->istep; a.alive = b->alive;
     a.s_ray = (T*)b->s_ray; a.n_ray = (T*)b->n_ray;
@@ -752,7 +778,7 @@ static int batch_init_state(rtmi_batch* b, bool clear_traj) {
     if (b->p.dtype == RTMI_F64) hipLaunchKernelGGL(k_init<double>, g, blk, 0, st, batch_dev<double>(b));
     else hipLaunchKernelGGL(k_init<float>, g, blk, 0, st, batch_dev<float>(b));
     HIP_TRY(hipGetLastError());
-    b->kernel_ms = 0; b->launches = 0; b->ev_used = 0;
+    b->kernel_ms = 0; b->launches = 0; b->ev_used = 0; b->dirty_state = false;
     return RTMI_OK;
 }
 
@@ -787,6 +813,8 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     ARG_TRY(p->exact_basis == 0 || p->exact_basis == 1, "rtmi_batch_create: exact_basis must be 0 or 1");
     ARG_TRY(p->field_path >= 0 && p->field_path <= 2, "rtmi_batch_create: field_path must be 0 (auto), 1 (global) or 2 (LDS tile)");
     ARG_TRY(p->sort_rays == 0 || p->sort_rays == 1, "rtmi_batch_create: sort_rays must be 0 or 1");
+    ARG_TRY(p->lazy_clear == 0 || p->lazy_clear == 1, "rtmi_batch_create: lazy_clear must be 0 or 1");
+    DEVICE_TRY(f, "rtmi_batch_create");
     rtmi_batch* b = new (std::nothrow) rtmi_batch();
     if (!b) return fail(RTMI_ERR_ALLOC, "rtmi_batch_create: host allocation failed");
     b->field = f; b->p = *p; b->R = R; b->esz = p->dtype == RTMI_F64 ? 8 : 4; b->stream = (hipStream_t)stream;
@@ -796,8 +824,8 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     int rc = RTMI_OK;
     auto body = [&]() -> int {
         const size_t Rz = (size_t)R;
-        const int narr = p->method == 7 ? 13 : 9;
-        HIP_TRY(hipMalloc(&b->state, narr * Rz * b->esz));
+        const int naux = p->method == 7 ? 7 : 3;
+        HIP_TRY(hipMalloc(&b->state, 6 * Rz * sizeof(double) + naux * Rz * b->esz));
         HIP_TRY(hipMalloc(&b->istep, Rz * sizeof(int)));
         HIP_TRY(hipMalloc(&b->alive, Rz));
         HIP_TRY(hipMalloc(&b->launch, 3 * Rz * sizeof(double)));
@@ -875,6 +903,9 @@ __global__ void k_set_per_ray(BatchDev<T> a, const double* step, const double* s
 RTMI_EXPORT int rtmi_batch_set_per_ray(rtmi_batch* b, const double* step, const int32_t* max_size) {
     ARG_TRY(b && step && max_size, "rtmi_batch_set_per_ray: null");
     ARG_TRY(b->p.launch_mode == 0, "rtmi_batch_set_per_ray: per-ray steps run on the one-lane-per-ray kernel (launch_mode 0)");
+    if (b->launches != 0 || b->dirty_state)
+        return fail(RTMI_ERR_STATE, "rtmi_batch_set_per_ray: only valid on a fresh or reset batch (before any rtmi_step / rtmi_run / "
+                                    "rtmi_batch_set_state): rays that already stopped would be revived");
     const size_t R = (size_t)b->R;
     std::vector<double> h2;
     try {
@@ -888,10 +919,17 @@ RTMI_EXPORT int rtmi_batch_set_per_ray(rtmi_batch* b, const double* step, const 
                 "rtmi_batch_set_per_ray: every max_size must be in [2 (4 for op7), params.max_size]");
         h2[k] = libm_square(step[k]) / 2.0;   // numpy scalar step**2 (:330)
     }
-    if (!b->vstep) {
-        HIP_TRY(hipMalloc(&b->vstep, R * b->esz));
-        HIP_TRY(hipMalloc(&b->vstep2h, R * b->esz));
-        HIP_TRY(hipMalloc(&b->vmax, R * sizeof(int)));
+    if (!b->vstep) {   // all three or none: pick_advance keys on vstep alone
+        void *v1 = nullptr, *v2 = nullptr;
+        int* v3 = nullptr;
+        hipError_t ea = hipMalloc(&v1, R * b->esz);
+        if (ea == hipSuccess) ea = hipMalloc(&v2, R * b->esz);
+        if (ea == hipSuccess) ea = hipMalloc(&v3, R * sizeof(int));
+        if (ea != hipSuccess) {
+            (void)hipFree(v1); (void)hipFree(v2); (void)hipFree(v3);
+            return fail(RTMI_ERR_ALLOC, std::string("rtmi_batch_set_per_ray: ") + hipGetErrorString(ea));
+        }
+        b->vstep = v1; b->vstep2h = v2; b->vmax = v3;
     }
     double* d = nullptr;
     int* di = nullptr;
@@ -919,17 +957,22 @@ RTMI_EXPORT int rtmi_batch_set_per_ray(rtmi_batch* b, const double* step, const 
 
 RTMI_EXPORT int rtmi_batch_reset(rtmi_batch* b) {
     ARG_TRY(b, "rtmi_batch_reset: null");
-    return batch_init_state(b, b->dirty);
+    DEVICE_TRY(b->field, "rtmi_batch_reset");
+    // np.zeros (:802-803): rows past each ray's last written row must read 0.  lazy_clear skips the memset when the
+    // re-run is known to rewrite exactly the rows the previous run wrote (same launch conditions, same steps).
+    return batch_init_state(b, b->dirty || !b->p.lazy_clear);
 }
 
 template <typename T> __global__ void k_set_state(BatchDev<T> a, const double* st, const double* hist, const int* istep) {
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.R) return;
     const long o = out_index(a, k);
-#pragma unroll
-    for (int q = 0; q < 9; q++) a.arr(q)[k] = (T)st[(size_t)q * a.R + o];
+    // state9 order: x, y, theta, n, dn/dx, dn/dy, dist_sim, dist_real, T
+    a.acc(0)[k] = st[o]; a.acc(1)[k] = st[(size_t)a.R + o]; a.acc(2)[k] = st[(size_t)2 * a.R + o];
+    for (int q = 0; q < 3; q++) a.aux(q)[k] = (T)st[(size_t)(3 + q) * a.R + o];
+    for (int q = 0; q < 3; q++) a.acc(3 + q)[k] = st[(size_t)(6 + q) * a.R + o];
     if (a.has_hist && hist)
-        for (int q = 0; q < 4; q++) a.arr(9 + q)[k] = (T)hist[(size_t)q * a.R + o];
+        for (int q = 0; q < 4; q++) a.aux(3 + q)[k] = (T)hist[(size_t)q * a.R + o];
     if (istep) a.istep[k] = istep[o];
     a.alive[k] = a.istep[k] + 1 < max_size_of(a, k);
 }
@@ -938,6 +981,7 @@ RTMI_EXPORT int rtmi_batch_set_state(rtmi_batch* b, const double* state9, const 
     ARG_TRY(b && state9, "rtmi_batch_set_state: null");
     const size_t R = (size_t)b->R;
     b->dirty = true;
+    b->dirty_state = true;
     double* d = nullptr;
     int* di = nullptr;
     HIP_TRY(hipMalloc(&d, 13 * R * sizeof(double)));
@@ -988,7 +1032,12 @@ static int next_event_pair(rtmi_batch* b, std::pair<hipEvent_t, hipEvent_t>** ou
             hipEvent_t e0, e1;
             HIP_TRY(hipEventCreate(&e0));
             HIP_TRY(hipEventCreate(&e1));
-            b->events.emplace_back(e0, e1);
+            try {
+                b->events.emplace_back(e0, e1);
+            } catch (const std::exception& ex) {   // never unwind across the C ABI
+                (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+                return fail(RTMI_ERR_ALLOC, std::string("event list: ") + ex.what());
+            }
         }
     }
     *out = &b->events[b->ev_used++];
@@ -998,6 +1047,7 @@ static int next_event_pair(rtmi_batch* b, std::pair<hipEvent_t, hipEvent_t>** ou
 RTMI_EXPORT int rtmi_step(rtmi_batch* b, int32_t nsteps) {
     ARG_TRY(b, "rtmi_step: null");
     ARG_TRY(nsteps > 0, "rtmi_step: nsteps must be > 0");
+    DEVICE_TRY(b->field, "rtmi_step");
     ARG_TRY(b->p.block_size == 0 || (b->p.block_size % 64 == 0 && b->p.block_size <= 256),
             "rtmi_step: block_size must be a multiple of 64, at most 256");
     std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
@@ -1167,7 +1217,8 @@ template <typename T> __global__ void k_metric_closure(BatchDev<T> a, double* ou
     if (k >= a.R) return;
     // s_ray[-1, 0:2, k]: the last row of the array -- written only if the ray ran all max_size-1 steps
     const bool full = a.istep[k] == max_size_of(a, k) - 1;
-    const double dx = 1.0 - (full ? (double)a.arr(0)[k] : 0.0), dy = 0.0 - (full ? (double)a.arr(1)[k] : 0.0);
+    // the row itself is stored in dtype: round the accumulator the way write_row did
+    const double dx = 1.0 - (full ? (double)(T)a.acc(0)[k] : 0.0), dy = 0.0 - (full ? (double)(T)a.acc(1)[k] : 0.0);
     out[out_index(a, k)] = 100 * sqrt(fma(dy, dy, dx * dx)) / (2 * M_PI);
 }
 template <typename T> __global__ void k_metric_px_cv(BatchDev<T> a, double* out) {    // RT_bench.py:1354-1360, :1398-1402
@@ -1255,7 +1306,8 @@ template <typename T> __device__ __forceinline__ double pchip_deriv(const Column
 template <typename T> __global__ void k_isochrone(BatchDev<T> a, int ntimes, const double* times, double* out) {
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.R) return;
-    const long n = a.istep[k] + 1;                      // rows 0..last_i of this ray (:993)
+    // rows 0..last_i of this ray (:993); a batch created with rec_rows < max_size holds only the first rec_rows of them
+    const long n = a.istep[k] + 1 < a.rec_rows ? a.istep[k] + 1 : a.rec_rows;
     const size_t pitch = (size_t)6 * a.R;
     const Column<T> tt{a.s_ray + (size_t)4 * a.R + k, pitch};
     const int qsel[3] = {0, 1, 5};                      // x, y, theta (:993)
@@ -1310,10 +1362,11 @@ RTMI_EXPORT int rtmi_isochrones(rtmi_batch* b, int32_t ntimes, const double* tim
 RTMI_EXPORT int rtmi_batch_view(rtmi_batch* b, rtmi_device_view* v) {
     ARG_TRY(b && v, "rtmi_batch_view: null");
     const size_t R = (size_t)b->R, e = b->esz;
-    char* s = (char*)b->state;
+    double* acc = (double*)b->state;
+    char* aux = (char*)(acc + 6 * R);
     v->s_ray = b->s_ray; v->n_ray = b->n_ray;
-    v->x = s; v->y = s + R * e; v->theta = s + 2 * R * e; v->n = s + 3 * R * e; v->gx = s + 4 * R * e; v->gy = s + 5 * R * e;
-    v->dist_sim = s + 6 * R * e; v->dist_real = s + 7 * R * e; v->T = s + 8 * R * e;
+    v->x = acc; v->y = acc + R; v->theta = acc + 2 * R; v->dist_sim = acc + 3 * R; v->dist_real = acc + 4 * R; v->T = acc + 5 * R;
+    v->n = aux; v->gx = aux + R * e; v->gy = aux + 2 * R * e;
     v->perm = b->perm;
     v->istep = b->istep; v->R = b->R; v->rec_rows = b->p.rec_rows; v->dtype = b->p.dtype; v->record_stride = b->p.record_stride;
     return RTMI_OK;

@@ -1,5 +1,6 @@
 """Ray sharding across GPUs: rays are independent (the reference's outer loop,
-RT_bench.py:807, carries nothing between rays), so each rank owns a contiguous block of ray indices,
+RT_bench.py:807, carries nothing between rays), so any partition gives the same bits: contiguous blocks
+(shard_range / fan_shard / gather_blocks) or the interleaved split bench.py uses for load balance (interleave);
 the field is rebuilt per rank (<= 26 MB), and the only collective is the read-back gather.
 One process per GPU; torch.distributed is plumbing ("nccl" == RCCL over xGMI on ROCm, "gloo" on CPU)."""
 import numpy as np
@@ -41,6 +42,17 @@ def gather_blocks(local, R_total, dst=0, group=None):
         lo, hi = shard_range(R_total, r, world)
         parts.append(out[r][..., :hi - lo])
     return torch.cat(parts, dim=-1)
+
+
+def interleave(per_rank, R_total):
+    """Inverse of the interleaved partition bench.py uses (rank r owns rays r, r+world, r+2*world, ...): per_rank is
+    the gathered list of [..., Rmax] tensors, Rmax = ceil(R_total / world), short ranks padded at the end.
+    Returns [..., R_total] in ray order."""
+    import torch
+    world = len(per_rank)
+    stacked = torch.stack(list(per_rank), dim=-1)                 # [..., Rmax, world]: slot k, rank r -> ray k*world + r
+    flat = stacked.reshape(*stacked.shape[:-2], stacked.shape[-2] * world)
+    return flat[..., :R_total]
 
 
 def max_over_ranks(seconds, device=None, group=None):

@@ -275,7 +275,7 @@ class Batch:
 
     def __init__(self, field, method, step, max_size, box, gamma, thetas, x0, y0, record_stride=1, rec_rows=0,
                  gamma_step=None, stream=None, ext_s_ray=None, ext_n_ray=None, block_size=0, launch_mode=0,
-                 refill_min=0, exact_basis=0, field_path=0, sort_rays=False):
+                 refill_min=0, exact_basis=0, field_path=0, sort_rays=False, lazy_clear=False):
         self.field = field
         th = np.ascontiguousarray(thetas, dtype=np.float64)
         self.R = len(th)
@@ -296,6 +296,7 @@ class Batch:
             sort_rays = not launch_is_coherent(x0, y0, th)
         p.sort_rays = int(bool(sort_rays))
         p.ext_s_ray = ext_s_ray; p.ext_n_ray = ext_n_ray
+        p.lazy_clear = int(bool(lazy_clear))
         self.params = p
         self._h = C.c_void_p()
         check(lib().rtmi_batch_create(field._h, C.byref(p), self.R, dptr(x0), dptr(y0), dptr(th), stream,
@@ -384,7 +385,8 @@ class Batch:
                 self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False),
                                                  "version": 2, "strides": None}
         dev = torch.device("cuda", torch.cuda.current_device())
-        out = {name: torch.as_tensor(_Cai(getattr(v, name), (self.R,), ts), device=dev)
+        # accumulated quantities are fp64 in both precisions (rtmi_device_view); n and its gradient are of the dtype
+        out = {name: torch.as_tensor(_Cai(getattr(v, name), (self.R,), "<f8" if name in _ACC else ts), device=dev)
                for name in ("x", "y", "theta", "n", "gx", "gy", "dist_sim", "dist_real", "T")}
         out["istep"] = torch.as_tensor(_Cai(v.istep, (self.R,), "<i4"), device=dev)
         if v.perm:   # sort_rays: slot k of every tensor here is the caller's ray perm[k]
@@ -413,6 +415,9 @@ def device_sincos(x):
     s = np.empty_like(x); c = np.empty_like(x)
     check(lib().rtmi_debug_sincos(x.size, dptr(x), dptr(s), dptr(c)))
     return s, c
+
+
+_ACC = ("x", "y", "theta", "dist_sim", "dist_real", "T")
 
 
 def launch_is_coherent(x0, y0, theta, group=64):

@@ -52,13 +52,23 @@ def _worker(rank, world, port, tmp):
         ti = torch.from_numpy(resi)
         gl = [torch.empty_like(ti) for _ in range(world)] if rank == 0 else None
         dist.gather(ti, gl, dst=0)
+        # --- strong-scaling split of bench.py --total-rays: the SAME 37-ray fan, ragged (19 + 18), padded gather
+        ths = bench.fan("vert_heterogeneous", R_TOTAL, rank, world)
+        assert np.array_equal(ths, full[rank::world])
+        ress, _ = _trace(ths)
+        ts = torch.from_numpy(ress)
+        Rmax = (R_TOTAL + world - 1) // world
+        if ts.shape[1] < Rmax:
+            ts = torch.cat((ts, torch.full((ts.shape[0], Rmax - ts.shape[1]), float("nan"), dtype=ts.dtype)), 1)
+        gs = [torch.empty_like(ts) for _ in range(world)] if rank == 0 else None
+        dist.gather(ts.contiguous(), gs, dst=0)
         if rank == 0:
             whole, wsteps = _trace(full)
+            assert np.array_equal(rd.interleave(gs, R_TOTAL).numpy(), whole)        # strong split: same bits, ray order
             assert g.shape == (12, R_TOTAL) and np.array_equal(g.numpy(), whole)    # bit-identical to unsharded
             assert total == wsteps
             wi, _ = _trace(np.linspace(0.0, np.pi / 2, R_TOTAL + 1))
-            inter = torch.stack(gl, dim=-1).reshape(12, R_TOTAL + 1)
-            assert np.array_equal(inter.numpy(), wi)
+            assert np.array_equal(rd.interleave(gl, R_TOTAL + 1).numpy(), wi)
             open(os.path.join(tmp, "ok"), "w").write("ok")
         else:
             assert g is None

@@ -261,7 +261,7 @@ def test_sharding_is_bit_identical(m, rb, gpu_fields):
 
 @pytest.mark.parametrize("scen,m,refill_min", [("vert_heterogeneous", 6, 0), ("vert_heterogeneous", 7, 1),
                                                ("interface", 6, 48), ("vert_heterogeneous", 9, 16)])
-def test_lane_refill_is_bit_identical(scen, m, refill_min, rb, gpu_fields):
+def test_lane_refill_is_bit_identical(scen, m, refill_min, rb, gpu_fields, oracle_fields):
     """launch_mode 1 (persistent waves, ballot/mbcnt compaction of terminated lanes) vs one lane per ray, on a
     batch whose rays are in random order (neighbouring lanes terminate hundreds of steps apart)."""
     rng = np.random.default_rng(5)
@@ -281,6 +281,14 @@ def test_lane_refill_is_bit_identical(scen, m, refill_min, rb, gpu_fields):
     assert np.array_equal(a.rows(), b.rows())
     b.reset(); b.run()                         # and from row 0
     assert np.array_equal(a.final(), b.final()) and np.array_equal(a.rows(), b.rows())
+    # the refill kernel against the oracle directly (not only against the other kernel)
+    from oracle import rt_oracle as O
+    o = O.trazar(oracle_fields(scen), m, 1, rb.DELTA_S, ms, lim, -2.0, -2.0, th, record_stride=16, nthreads=8)
+    assert np.array_equal(b.d_ray()[2], o["d_ray"][2])
+    if m == 9:                                  # reference-order method: the oracle's bits
+        assert np.array_equal(b.final(), o["final"]) and np.array_equal(b.rows(), o["s_ray"])
+    else:
+        assert relerr(b.final(), o["final"]) < REL and relerr(b.rows(), o["s_ray"]) < REL
     a.close(); b.close()
 
 
@@ -395,8 +403,9 @@ def test_cfg2_vert_65536_properties(rb, gpu_fields, oracle_fields):
 
 
 def test_fp32_path_tracks_fp64(rb, gpu_fields):
-    """cfg4 runs fp32 state + field; the reference is fp64-only, so the tolerance is measured, not inherited:
-    end points within 2e-3 of the fp64 trajectory (fp32 positions carry ~1e-4 relative step error)."""
+    """cfg4 runs an fp32 field and fp32 step arithmetic on fp64 accumulators (position, angle, arclengths, traveltime);
+    the reference is fp64-only, so the tolerance is measured, not inherited: same step count on (nearly) every ray
+    -- a ray may cross the box edge one row earlier or later -- and end points within 2e-5 of the fp64 trajectory."""
     R = 512
     th = np.linspace(0, np.pi / 2, R)
     lim = LIMITS["vert_heterogeneous"]
@@ -406,10 +415,12 @@ def test_fp32_path_tracks_fp64(rb, gpu_fields):
     a.run(); b.run()
     fa, fb, da, db = a.final(), b.final(), a.d_ray(), b.d_ray()
     a.close(); b.close()
-    assert np.max(np.abs(da[2] - db[2])) <= 3
-    err = np.abs(fa[:2] - fb[:2]).max()
-    print(f"fp32 vs fp64 end-point max abs error: {err:.3e}")
-    assert err < 2e-2
+    assert np.max(np.abs(da[2] - db[2])) <= 1
+    same = da[2] == db[2]
+    err = np.abs(fa[:2] - fb[:2])[:, same].max()
+    print(f"fp32 vs fp64: same step count on {same.sum()}/{R} rays, end-point max abs error {err:.3e}, "
+          f"traveltime {np.abs(fa[8] - fb[8])[same].max():.3e}")
+    assert same.mean() > 0.98 and err < 2e-5
 
 
 # ------------------------------------------------------------------ on-device validation metrics
@@ -548,8 +559,8 @@ def test_cfg5_anisotropy_shard_properties(rb, gpu_fields, oracle_fields):
 
 def test_cfg4_fp32_shard_properties(rb, gpu_fields):
     """cfg4 shard (vert_heterogeneous, fp32 state + field, 1 048 576 rays = 1/8 of 8 388 608).  The reference is
-    fp64-only; measured against this library's fp64 path on a 1/64 subsample: same step counts within +-3,
-    end points within 2e-2, p_x conserved to 1e-3."""
+    fp64-only; measured against this library's fp64 path on a 1/64 subsample: same step counts within one row,
+    end points within 2e-5 (fp64 accumulators under the fp32 arithmetic), p_x conserved to 1e-3."""
     R = 1 << 20
     th = np.linspace(0, np.pi / 2, R)
     lim = LIMITS["vert_heterogeneous"]
@@ -563,10 +574,11 @@ def test_cfg4_fp32_shard_properties(rb, gpu_fields):
     a.run()
     d64, f64 = a.d_ray(), a.final()
     a.close()
-    assert np.max(np.abs(d32[2][sub] - d64[2])) <= 3
-    err = np.abs(f32[:2, sub] - f64[:2]).max()
-    print(f"cfg4 fp32 vs fp64 end points: {err:.2e}")
-    assert err < 2e-2
+    assert np.max(np.abs(d32[2][sub] - d64[2])) <= 1
+    same = d32[2][sub] == d64[2]
+    err = np.abs(f32[:2, sub] - f64[:2])[:, same].max()
+    print(f"cfg4 fp32 vs fp64 end points: {err:.2e} on {same.sum()} rays with equal step count")
+    assert same.mean() > 0.99 and err < 2e-5
     n0 = 0.07142864686293911
     assert np.max(np.abs(f32[6] - n0 * np.cos(th))) / n0 < 1e-3
 
@@ -614,7 +626,7 @@ def test_bad_launch_conditions_do_not_disturb_neighbours(rb, gpu_fields):
 
 
 @pytest.mark.parametrize("scen,m,mode", [("vert_heterogeneous", 6, 0), ("interface", 7, 0), ("vert_heterogeneous", 6, 1)])
-def test_sort_rays_answers_in_caller_order(scen, m, mode, rb, gpu_fields):
+def test_sort_rays_answers_in_caller_order(scen, m, mode, rb, gpu_fields, oracle_fields):
     """sort_rays=1 reorders rays inside the batch (coherent lanes) but every read -- d_ray, final state, rows,
     n_ray, metrics, isochrones, set_state -- answers in the caller's order, bit-identical to the unsorted batch."""
     rng = np.random.default_rng(11)
@@ -639,6 +651,15 @@ def test_sort_rays_answers_in_caller_order(scen, m, mode, rb, gpu_fields):
     assert out[0][7] is None and sorted(out[1][7]) == list(range(R))
     for u, v in zip(out[0][:7], out[1][:7]):
         assert np.array_equal(u, v, equal_nan=True)
+    # the sorted batch against the oracle directly, in the caller's ray order (ray 7 has a NaN launch angle)
+    from oracle import rt_oracle as O
+    o = O.trazar(oracle_fields(scen), m, 1, rb.DELTA_S, ms, lim, x0, -2.0, th, record_stride=1, nthreads=8)
+    ok = np.ones(R, bool); ok[7] = False
+    d, fin, s = out[1][0], out[1][1], out[1][2]
+    assert np.array_equal(d[2][ok], o["d_ray"][2][ok])
+    tol = 1e-7 if m == 7 else REL
+    assert relerr(fin[:, ok], o["final"][:, ok]) < tol
+    assert relerr(s[:, :, ok], o["s_ray"][1000:1700][:, :, ok]) < tol
 
 
 def test_north_star_1m_rays_vs_oracle_subsample(rb, gpu_fields, oracle_fields):
@@ -802,3 +823,113 @@ def test_benchmark_statistic_runs(rb, gpu_fields):
     z, grd = rb.FieldSpline(F, "n"), (rb.FieldSpline(F, "dy"), rb.FieldSpline(F, "dx"))
     t = rb.benchmark(rb.op6, z, grd, rb.DELTA_S, 91, "3", trial=8, replicas=2, max_rounds=6)
     assert 1e-5 < t < 0.5          # 31 rays, ~2 900 sequential steps: a few milliseconds of device time
+
+
+def test_isochrones_on_truncated_record(rb, gpu_fields):
+    """rec_rows < max_size is allowed (rows beyond are simply not kept): the isochrone stage must then work on the
+    rows that exist and never read past the allocation.  A ray that outruns rec_rows answers from its
+    first rec_rows rows: times it reaches within them match the full record, later times are NaN."""
+    F = gpu_fields("vert_heterogeneous")
+    lim = LIMITS["vert_heterogeneous"]
+    th = np.linspace(0.2, 1.4, 64)
+    full = rb.Batch(F, 6, rb.DELTA_S, 30228, lim, 1, th, -2.0, -2.0, record_stride=1, rec_rows=3072)
+    cut = rb.Batch(F, 6, rb.DELTA_S, 30228, lim, 1, th, -2.0, -2.0, record_stride=1, rec_rows=900)
+    full.run(); cut.run()
+    assert full.d_ray()[2].min() > 900                       # every ray outruns the truncated record
+    times = np.array([0.02, 0.05, 0.08, 0.3])
+    a, b = full.isochrones(times), cut.isochrones(times)
+    T_end = cut.rows(899, 1)[0, 4]                           # traveltime of the last kept row, per ray
+    for it, t in enumerate(times):
+        inside = T_end >= t
+        assert np.array_equal(np.isnan(b[it, 0]), ~inside)
+        # away from the cut the two agree exactly; at the cut the end-point derivative rule applies to different rows
+        far = inside & (T_end - t > 5 * 0.07 * rb.DELTA_S)
+        assert np.array_equal(b[it][:, far], a[it][:, far])
+        if inside.any():
+            assert np.abs(b[it][:, inside] - a[it][:, inside]).max() < 1e-6
+    assert np.isnan(b[3]).all() and not np.isnan(a[3]).all()
+    full.close(); cut.close()
+
+
+def test_set_per_ray_only_on_a_fresh_batch_and_reset_clears_rows(rb, gpu_fields):
+    """rtmi_batch_set_per_ray after stepping would revive finished rays: RTMI_ERR_STATE.
+    rtmi_batch_reset restores the reference's np.zeros invariant (rows past the last written row read 0) at once;
+    lazy_clear=1 defers it to the re-run, which rewrites the same rows."""
+    from raytracing_amd._lib import RtmiError
+    F = gpu_fields("vert_heterogeneous")
+    lim = LIMITS["vert_heterogeneous"]
+    th = np.linspace(0.1, 1.4, 40)
+    b = rb.Batch(F, 6, rb.DELTA_S, 400, lim, 1, th, -2.0, -2.0, record_stride=1)
+    b.set_per_ray(0.01, 300)                                  # fresh: fine
+    b.step(5)
+    with pytest.raises(RtmiError, match="fresh or reset"):
+        b.set_per_ray(0.02, 200)
+    b.run()
+    first = b.rows()
+    assert first[1:].any()
+    b.reset()
+    assert not b.rows()[1:].any() and np.array_equal(b.rows()[0], first[0])     # zeros again, row 0 rewritten
+    b.set_per_ray(0.01, 300)                                  # reset: fine again
+    b.run()
+    assert np.array_equal(b.rows(), first)
+    b.close()
+    lz = rb.Batch(F, 6, 0.01, 300, lim, 1, th, -2.0, -2.0, record_stride=1, lazy_clear=True)
+    lz.run()
+    ref = lz.rows()
+    lz.reset()
+    assert np.array_equal(lz.rows()[5:], ref[5:])            # lazy: the previous pass's rows are still there ...
+    lz.run()
+    assert np.array_equal(lz.rows(), ref)                     # ... and the re-run reproduces them exactly
+    lz.close()
+
+
+# ------------------------------------------------------------------ BASELINE configs at FULL size on one GPU
+def test_cfg5_anisotropy_full_1m_rays(rb, gpu_fields, oracle_fields):
+    """cfg5 whole: anisotropy (gamma = 3), op11, 1 048 576 rays fp64 on ONE MI355X.  p_x (the ray parameter of a
+    vertically heterogeneous medium) conserved over the whole fan, the device step counter against sum(d_ray[2]), and
+    every 8192nd ray against the oracle: the oracle's bits (golden-section method, reference-order arithmetic)."""
+    from oracle import rt_oracle as O
+    R = 1 << 20
+    th = np.linspace(0, np.pi / 2, R)
+    lim = LIMITS["anisotropy"]
+    ms = int(np.ceil(80 / rb.DELTA_S) + 1)
+    b = rb.Batch(gpu_fields("anisotropy"), 11, rb.DELTA_S, ms, lim, 3, th, -2.0, -2.0, record_stride=0)
+    b.run()
+    d, fin, st = b.d_ray(), b.final(), b.stats()
+    b.close()
+    assert st["ray_steps"] == int(d[2].sum()) and st["live_rays"] == 0
+    assert 1100 <= d[2].min() and d[2].max() <= 2900
+    n0 = 0.07142864686293911
+    coef0 = np.sqrt((3 * np.sin(th)) ** 2 + np.cos(th) ** 2)
+    px0 = n0 * coef0 * np.cos(th) * (1 + (-np.sin(th) ** 2) * 8 / coef0 ** 2)
+    assert np.max(np.abs(fin[6] - px0)) / n0 < 5e-4
+    sub = slice(0, R, 8192)
+    o = O.trazar(oracle_fields("anisotropy"), 11, 3, rb.DELTA_S, ms, lim, -2.0, -2.0, th[sub], record_stride=0, nthreads=16)
+    assert np.array_equal(d[:, sub], o["d_ray"]) and np.array_equal(fin[:, sub], o["final"])
+
+
+def test_cfg4_fp32_full_8m_rays(rb, gpu_fields):
+    """cfg4 whole: vert_heterogeneous, 8 388 608 rays, fp32 field + step arithmetic on ONE MI355X (the config shards it
+    over 8).  The reference is fp64-only; against this library's fp64 path on every 512th ray: step counts within one
+    row, end points within 2e-5 (fp64 accumulators for position, angle, arclength and traveltime), p_x conserved."""
+    R = 1 << 23
+    th = np.linspace(0, np.pi / 2, R)
+    lim = LIMITS["vert_heterogeneous"]
+    ms = int(np.ceil(80 / rb.DELTA_S) + 1)
+    b = rb.Batch(gpu_fields("vert_heterogeneous", 1), 6, rb.DELTA_S, ms, lim, 1, th, -2.0, -2.0, record_stride=0)
+    b.run()
+    d32, f32, st = b.d_ray(), b.final(), b.stats()
+    b.close()
+    assert st["ray_steps"] == int(d32[2].sum()) and st["live_rays"] == 0
+    sub = slice(0, R, 512)
+    a = rb.Batch(gpu_fields("vert_heterogeneous", 0), 6, rb.DELTA_S, ms, lim, 1, th[sub], -2.0, -2.0, record_stride=0)
+    a.run()
+    d64, f64 = a.d_ray(), a.final()
+    a.close()
+    assert np.max(np.abs(d32[2][sub] - d64[2])) <= 1
+    same = d32[2][sub] == d64[2]
+    err = np.abs(f32[:2, sub] - f64[:2])[:, same].max()
+    print(f"cfg4 full, fp32 vs fp64 end points on {same.sum()} rays with equal step count: {err:.2e}")
+    assert same.mean() > 0.99 and err < 2e-5
+    n0 = 0.07142864686293911
+    assert np.max(np.abs(f32[6] - n0 * np.cos(th))) / n0 < 6e-4
