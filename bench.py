@@ -49,16 +49,16 @@ SCEN = {"vert_heterogeneous": dict(choice="3", theta=(0.0, np.pi / 2), start=(-2
 def alg_bytes_per_step(dtype, stride):
     """9 state values in + 9 out + 36 gathered coefficients, + 7 recorded values per stored row."""
     e = 8 if dtype == "f64" else 4
-    return (9 + 9 + 36) * e + (7 * e / stride if stride else 0.0)
+    return (9 + 9 + 36) * e + (7 * e / stride if stride else 0.0)   # SURVEY counts n_ray among the recorded values
 
 
-def min_hbm_bytes(dtype, stride, ray_steps, rays, method):
-    """Bytes one launch cannot avoid moving: the recorded rows (7 values per stored row) and the ray state once in
-    and once out (9 values, 13 for op7, + istep + alive).  The field (<= 26 MB) is L2/MALL-resident."""
+def min_hbm_bytes(dtype, stride, ray_steps, rays, method, n_ray):
+    """Bytes one launch cannot avoid moving: the recorded rows (6 values per stored row, 7 with n_ray) and the ray state
+    once in and once out (6 fp64 accumulators + 3 values, +4 for op7, + istep + alive).  The field (<= 26 MB) is
+    L2/MALL-resident."""
     e = 8 if dtype == "f64" else 4
     rows = ray_steps / stride if stride else 0.0
-    narr = 13 if method == 7 else 9
-    return rows * 7 * e + 2.0 * rays * (narr * e + 5)
+    return rows * (7 if n_ray else 6) * e + 2.0 * rays * (48 + (7 if method == 7 else 3) * e + 5)
 
 
 def fan(scen, R_total, rank, world):
@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--method", type=int, default=None)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--record", default="full", help="full (the reference's s_ray layout, default) | none | stride:N")
+    ap.add_argument("--n-ray", action="store_true",
+                    help="also keep n_ray rows (coef*n per row): internal to the reference's trazar (RT_bench.py:803), not among "
+                         "its return values (:948), so off by default")
     ap.add_argument("--mode", default="lane", choices=["lane", "refill"],
                     help="lane: one lane per ray; refill: persistent waves with ballot/prefix lane refill")
     ap.add_argument("--order", default="fan", choices=["fan", "shuffled"],
@@ -186,7 +189,8 @@ def main():
                         record_stride=stride_, rec_rows=rec_rows_, block_size=args.block,
                         launch_mode=1 if args.mode == "refill" else 0, refill_min=args.refill_min,
                         field_path={"auto": 0, "global": 1, "lds": 2}[args.field_path], sort_rays=args.sort,
-                        lazy_clear=True)    # every pass re-runs the same launch conditions: same rows rewritten
+                        lazy_clear=True,    # every pass re-runs the same launch conditions: same rows rewritten
+                        keep_n_ray=args.n_ray)
 
     try:
         batch = make_batch(stride, rec_rows)
@@ -258,7 +262,7 @@ def main():
     if rank == 0:
         balg = alg_bytes_per_step(args.dtype, stride)
         ksec = kern_ms * 1e-3
-        key = f"{args.scenario}:{R_local}:{args.record}:{args.dtype}:op{args.method}"
+        key = f"{args.scenario}:{R_local}:{args.record}{'+n_ray' if args.n_ray and stride else ''}:{args.dtype}:op{args.method}"
         prof = {}
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}) or {}
@@ -267,7 +271,7 @@ def main():
         if not isinstance(prof, dict):        # round-1 format: a bare byte count
             prof = {"hbm_bytes": prof, "source": "profiles/r01_f_head_pmc_summary.txt"}
         measured = prof.get("hbm_bytes") if args.chunk <= 0 and args.mode == "lane" else None
-        model = min_hbm_bytes(args.dtype, stride, steps_per_pass, R_local, args.method)
+        model = min_hbm_bytes(args.dtype, stride, steps_per_pass, R_local, args.method, args.n_ray)
         hbm_bytes = measured if measured else model
         hbm = {"achieved": hbm_bytes / ksec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": hbm_bytes / ksec / 1e9 / HBM_PEAK_GBS,
@@ -301,7 +305,7 @@ def main():
                                    f"rays, interleaved across ranks), op{args.method}, DELTA_S={step:.12g}, "
                                    f"box={tuple(float(v) for v in lim)}, record={args.record}",
                        "rays_total": R_total, "rays_rank0": R_local, "ray_steps_per_pass_rank0": int(steps_per_pass),
-                       "method": f"op{args.method}", "record": args.record, "launch_mode": args.mode,
+                       "method": f"op{args.method}", "record": args.record, "n_ray_rows": bool(args.n_ray and stride), "launch_mode": args.mode,
                        "ray_order": args.order, "sort_rays": bool(args.sort), "field_path": args.field_path,
                        "steps_per_launch": args.chunk or "all", "parallelism": f"ray-shard x{world}"},
             "roofline": roof,

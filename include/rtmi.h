@@ -100,7 +100,9 @@ typedef struct {
                                 rewrites exactly the rows the previous run wrote (same launch conditions and steps; set_state /
                                 set_per_ray force a clear); until the re-run has finished, rows beyond a ray's CURRENT row still
                                 hold the previous pass's (identical) values -- for timed re-runs of one batch (bench.py) */
-    int32_t reserved0;       /* must be 0 */
+    int32_t no_n_ray;        /* 1: keep no n_ray rows.  n_ray (coef*n per row, :803) is an internal array of trazar -- it feeds the
+                                traveltime recurrence (:874) and is not among trazar's return values (:948) -- so a caller of the
+                                reference's call surface never sees it; dropping it saves 1/7 of the recorded bytes */
 } rtmi_params;
 
 /* Upload R launch conditions (host pointers; x0/y0 per ray -- pos_x[k], -2 or the fisheye start, :809-813),
@@ -150,6 +152,19 @@ int rtmi_metric(rtmi_batch *b, int kind, double *out);
  * (RT_bench.py:987-1003).  out[ntimes][3][R], host, fp64; NaN where a ray never reaches that traveltime
  * (the reference skips such rays, :997).  Needs record_stride 1. */
 int rtmi_isochrones(rtmi_batch *b, int32_t ntimes, const double *times, double *out);
+
+/* Wavefronts: the across-ray stage of the reference's wavefront extraction (RT_bench.py:1005-1026, 1043-1044).  For each
+ * traveltime the isochrone points of the rays that reach it (as rtmi_isochrones) are sorted by y (np.argsort, :1016),
+ * scipy's PchipInterpolator x(y) is built through them (:1020) and evaluated: its derivative at the points (:1021-1022),
+ * the normal angle (:1025-1026), |ray angle - normal angle| (:1032) and the curve itself on nfine equally spaced y between the
+ * first and the last point (:1043-1044; the reference uses 100).  All on the device; host outputs, fp64:
+ *   count[ntimes]            points on each wavefront (rays that reach the traveltime)
+ *   nodes[ntimes][7][R]      per sorted position j < count: y, x, ray angle, dx/dy, normal angle, |ray angle - normal angle|,
+ *                            ray index (caller's order); NaN at j >= count, and in the derived columns when count < 2
+ *   fine[ntimes][2][nfine]   x, y of the interpolated wavefront (NaN when count < 2); nfine = 0 skips it (fine may be NULL)
+ * Needs record_stride 1.  Points with equal y make scipy raise; here they give NaN in the derived columns. */
+int rtmi_wavefronts(rtmi_batch *b, int32_t ntimes, const double *times, int32_t nfine, int64_t *count, double *nodes,
+                    double *fine);
 
 typedef struct {
     void *s_ray, *n_ray;                 /* device, dtype, layouts above */

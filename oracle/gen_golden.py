@@ -256,6 +256,39 @@ def main():
                             out[it, q, i] = PchipInterpolator(t_ray, s_ray[:n, col, i])(travel_time)
             save("isochrones_vert_op6", dict(times=times, points=out, theta=d["theta"], step=d["step"],
                                              max_size=d["max_size"], box=d["box"]))
+    if want("wavefronts"):
+        # across-ray stage of the wavefront extraction (RT_bench.py:1005-1026, 1043-1044), with the reference's own calls,
+        # on the reference's own trajectories (vert op6, 31 rays; anisotropy op11 takes 90 s of reference time for the same code)
+        from scipy.interpolate import PchipInterpolator
+        d, s_ray = run_traj(R, "vert_heterogeneous", 6, R.DELTA_S, 91)
+        times = np.arange(0.05, 0.6, 0.05)
+        RC = s_ray.shape[2]
+        res = dict(times=times, theta=d["theta"], step=d["step"], max_size=d["max_size"], box=d["box"])
+        for it, travel_time in enumerate(times):
+            valid_ray_coord, angle_vector, rays = [], [], []
+            for i in range(RC):
+                n = int(d["d_ray"][2, i]) + 1
+                t_ray = s_ray[:n, 4, i]
+                if np.max(t_ray) >= travel_time:
+                    x = PchipInterpolator(t_ray, s_ray[:n, 0, i])(travel_time)
+                    y = PchipInterpolator(t_ray, s_ray[:n, 1, i])(travel_time)
+                    angle_vector.append(PchipInterpolator(t_ray, s_ray[:n, 5, i])(travel_time))
+                    valid_ray_coord.append([x, y]); rays.append(i)
+            res[f"count{it}"] = len(valid_ray_coord)
+            if len(valid_ray_coord) > 1:
+                valid_ray_coord = np.array(valid_ray_coord); angle_vector = np.array(angle_vector)
+                indices = np.argsort(valid_ray_coord[:, 1])
+                ray_coord_sorted = valid_ray_coord[indices]
+                pchip_interpolator = PchipInterpolator(ray_coord_sorted[:, 1], ray_coord_sorted[:, 0])
+                dy_dx_original = pchip_interpolator.derivative()(ray_coord_sorted[:, 1])
+                tangent_angles = np.pi / 2 - np.arctan(dy_dx_original)
+                normal_angles = tangent_angles - np.pi / 2
+                y_fine = np.linspace(min(ray_coord_sorted[:, 1]), max(ray_coord_sorted[:, 1]), 100)
+                res.update({f"y{it}": ray_coord_sorted[:, 1], f"x{it}": ray_coord_sorted[:, 0], f"ray{it}": np.array(rays)[indices],
+                            f"angle_rayorder{it}": angle_vector, f"dxdy{it}": dy_dx_original, f"normal{it}": normal_angles,
+                            f"angle_diff_ref{it}": np.absolute(angle_vector - normal_angles),    # (:1032) as the reference zips it
+                            f"x_fine{it}": pchip_interpolator(y_fine), f"y_fine{it}": y_fine})
+        save("wavefronts_vert_op6", res)
     if want("consts"):
         save("constants", consts)
 

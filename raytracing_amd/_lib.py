@@ -23,7 +23,7 @@ class Params(C.Structure):
                 ("box", C.c_double * 4), ("launch_mode", C.c_int32), ("block_size", C.c_int32),
                 ("refill_min", C.c_int32), ("exact_basis", C.c_int32),
                 ("field_path", C.c_int32), ("sort_rays", C.c_int32),
-                ("ext_s_ray", C.c_void_p), ("ext_n_ray", C.c_void_p), ("lazy_clear", C.c_int32), ("reserved0", C.c_int32)]
+                ("ext_s_ray", C.c_void_p), ("ext_n_ray", C.c_void_p), ("lazy_clear", C.c_int32), ("no_n_ray", C.c_int32)]
 
 
 class DeviceView(C.Structure):
@@ -65,6 +65,7 @@ SYMBOLS = {
     "rtmi_read_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp, _dp]),
     "rtmi_metric": (C.c_int, [C.c_void_p, C.c_int, _dp]),
     "rtmi_isochrones": (C.c_int, [C.c_void_p, C.c_int32, _dp, _dp]),
+    "rtmi_wavefronts": (C.c_int, [C.c_void_p, C.c_int32, _dp, C.c_int32, C.POINTER(C.c_int64), _dp, _dp]),
     "rtmi_batch_view": (C.c_int, [C.c_void_p, C.POINTER(DeviceView)]),
     "rtmi_batch_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "rtmi_batch_destroy": (None, [C.c_void_p]),
@@ -83,6 +84,17 @@ def lib():
                 f"{LIB_PATH} is missing: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()' or make -C raytracing_amd/csrc). "
                 "raytracing_amd has no CPU fallback.")
+        # torch's ROCm wheels bundle their own HIP runtime.  Two HIP runtimes can share a process only if torch's is
+        # the first to touch the device (afterwards librtmi's, from /opt/rocm, works beside it; the other way round
+        # torch reports "No HIP GPUs are available").  So when torch is already imported, let it look first.
+        import sys
+        if "torch" in sys.modules:
+            try:
+                t = sys.modules["torch"]
+                if t.cuda.is_available():
+                    t.cuda.init()          # is_available() alone does not create torch's HIP context
+            except Exception:
+                pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/rtmi.h"
+#include "rtmi_internal.h"
 #include "rt_device.h"
 
 #define RTMI_EXPORT extern "C" __attribute__((visibility("default")))
@@ -528,35 +529,80 @@ template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::
 // has no dense row stores to queue the scratch reloads behind), the tile variant for two with no spills.
 // Every lane runs every iteration until no lane of its wave is active; a ray's state is stored the moment it
 // terminates (or when the launch's step budget ends), so idle lanes never write.
-template <typename T, int METHOD, bool ISO, bool LDS, bool VAR>
-__global__ __launch_bounds__(256, LDS ? 2 : 3) void k_advance(BatchDev<T> a, int nsteps) {
-    __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
-    typename GatherOf<T, LDS>::type gather;
-    gather_init<T, LDS>(gather, lds);
+// ---- trajectory rows through a wave-uniform buffer descriptor
+// In k_advance every live lane of a wave is at the same row (they start together and step together), so a row's
+// address splits into a wave-uniform part -- row base + block offset, kept in SGPRs as a buffer descriptor -- a
+// per-quantity scalar offset (q*R elements) and a per-lane constant (lane*sizeof(T)).  That removes the per-lane
+// 64-bit address arithmetic of write_row (seven v_mad_u64_u32 / v_lshl_add_u64 chains per step) and frees their
+// registers.  RTMI_ROW_STORE_AUX sets the stores' cache policy (0 plain, 2 nt, 16 sc1, 18 sc1 nt).
+#ifndef RTMI_ROW_STORE_AUX
+#define RTMI_ROW_STORE_AUX 2   // nt: rows are written once and never read by the kernel (measured 3-5 % over plain stores)
+#endif
+typedef unsigned rt_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void row_store(__amdgpu_buffer_rsrc_t rs, int voff, int soff, double v) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(rt_u32x2, v), rs, voff, soff, RTMI_ROW_STORE_AUX);
+}
+__device__ __forceinline__ void row_store(__amdgpu_buffer_rsrc_t rs, int voff, int soff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, RTMI_ROW_STORE_AUX);
+}
+// rowp / nrowp: this block's slice of the current row of s_ray / n_ray (wave-uniform pointers the loop advances)
+template <typename T>
+__device__ __forceinline__ void write_row_uniform(const BatchDev<T>& a, T* rowp, T* nrowp, int voff, const rt::Ray<T>& r) {
+    const int qR = (int)(a.R * (long)sizeof(T));                        // byte distance between quantities (< 2^31 / 6: pick_advance)
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rowp, 0, 0x7fffffff, 0x00020000);
+    row_store(rs, voff, 0, (T)r.x);
+    row_store(rs, voff, qR, (T)r.y);
+    row_store(rs, voff, 2 * qR, r.mx);
+    row_store(rs, voff, 3 * qR, r.my);
+    row_store(rs, voff, 4 * qR, (T)r.tt);
+    row_store(rs, voff, 5 * qR, (T)r.th);
+    if (nrowp) {
+        const __amdgpu_buffer_rsrc_t rn = __builtin_amdgcn_make_buffer_rsrc(nrowp, 0, 0x7fffffff, 0x00020000);
+        row_store(rn, voff, 0, r.nray);
+    }
+}
+
+// The step loop of k_advance.  UROW: rows are recorded and every live lane of the wave is at the same row, so the
+// row counter lives in scalar registers and rows go out through write_row_uniform; otherwise per-lane bookkeeping
+// (also when nothing is recorded).
+template <typename T, int METHOD, bool ISO, typename G, bool UROW>
+__device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Consts<T>& K, G& gather, rt::Ray<T>& r, long k, int& i,
+                                             bool& alive, int max_size, int nsteps) {
     const bool RECORD = a.stride != 0;
-    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    rt::Ray<T> r;
-    int i = 0, until = 0;
+    int until = 0;
     long row = 0;
-    bool alive = k < a.R && a.alive[k];
-    // VAR: every ray carries its own DELTA_S and max_size (the calibration sweep as one candidate x ray batch)
-    rt::Consts<T> K = a.K;
-    int max_size = a.max_size;
-    if (VAR && k < a.R) { K.step = a.vstep[k]; K.step2h = a.vstep2h[k]; K.step2 = K.step2h * T(2); max_size = a.vmax[k]; }
-    if (alive) {
-        load_ray<T, METHOD, ISO>(a, k, r, i);
-        until = RECORD ? a.stride - (i % a.stride) : 0;  // steps until the next recorded row
-        row = RECORD ? i / a.stride : 0;
-    } else {
-        idle_ray(a, r);
+    // UROW: scalar row bookkeeping common to the live lanes: steps until the next recorded row, rows that may still be
+    // written, and this block's slice of the current row (advanced by one row of 6*R / R values per recorded row)
+    int rows_left = 0;
+    T *rowp = nullptr, *nrowp = nullptr;
+    const long blk = (long)blockIdx.x * blockDim.x;
+    const int voff = (int)(threadIdx.x * sizeof(T));
+    if (UROW && RECORD) {
+        const int i0 = __builtin_amdgcn_readfirstlane(rt::wave_max_i(alive ? i : 0));
+        const int row0 = i0 / a.stride;
+        until = a.stride - (i0 % a.stride);
+        rows_left = (int)(a.rec_rows - 1 - row0 < 0x7fffffffL ? a.rec_rows - 1 - row0 : 0x7fffffffL);
+        rowp = a.s_ray + (size_t)row0 * 6 * a.R + blk;
+        nrowp = a.n_ray ? a.n_ray + (size_t)row0 * a.R + blk : nullptr;
+    } else if (RECORD && alive) {
+        until = a.stride - (i % a.stride);   // steps until the next recorded row
+        row = i / a.stride;
     }
     for (int it = 0; it < nsteps; ++it) {
         if (__ballot(alive) == 0ull) break;
         const bool active = alive;
         ++i;
         const bool inside = rt::ray_step<T, METHOD, ISO>(a.F, K, gather, active, r, i);
+        if (UROW && RECORD) {
+            if (--until == 0) {
+                until = a.stride;
+                rowp += 6 * a.R;
+                if (nrowp) nrowp += a.R;
+                if (--rows_left >= 0 && active) write_row_uniform(a, rowp, nrowp, voff, r);
+            }
+        }
         if (active) {
-            if (RECORD) {
+            if (!UROW && RECORD) {
                 if (--until == 0) {
                     until = a.stride;
                     ++row;
@@ -567,6 +613,35 @@ __global__ __launch_bounds__(256, LDS ? 2 : 3) void k_advance(BatchDev<T> a, int
             if (!alive) store_ray<T, METHOD>(a, k, r, i, false);
         }
     }
+}
+
+// The loop at :866-879: one lane per ray, state in registers for up to nsteps DELTA_S steps.
+// ISO (gamma == 1) drops the anisotropic factor's dead arithmetic; LDS selects the wave-private field tile
+// (rt::LdsGather) over per-lookup global gathers.  Results are bit-identical across all four variants.
+// The global-gather variant is built for three waves per SIMD (26 VGPRs spill; still 8 % faster when the loop
+// has no dense row stores to queue the scratch reloads behind), the tile variant for two with no spills.
+// Every lane runs every iteration until no lane of its wave is active; a ray's state is stored the moment it
+// terminates (or when the launch's step budget ends), so idle lanes never write.
+template <typename T, int METHOD, bool ISO, bool LDS, bool VAR>
+__global__ __launch_bounds__(256, LDS ? 2 : (sizeof(T) == 4 ? 4 : 3)) void k_advance(BatchDev<T> a, int nsteps) {
+    __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
+    typename GatherOf<T, LDS>::type gather;
+    gather_init<T, LDS>(gather, lds);
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    rt::Ray<T> r;
+    int i = 0;
+    bool alive = k < a.R && a.alive[k];
+    // VAR: every ray carries its own DELTA_S and max_size (the calibration sweep as one candidate x ray batch)
+    rt::Consts<T> K = a.K;
+    int max_size = a.max_size;
+    if (VAR && k < a.R) { K.step = a.vstep[k]; K.step2h = a.vstep2h[k]; K.step2 = K.step2h * T(2); max_size = a.vmax[k]; }
+    if (alive) load_ray<T, METHOD, ISO>(a, k, r, i);
+    else idle_ray(a, r);
+    // The tile variant records rows through the wave-uniform descriptor path: the host launches it only while every live
+    // ray of the batch is at the same row (always, unless rtmi_batch_set_state gave rays rows of their own) and a row's
+    // six quantities lie within 32-bit byte offsets of each other (pick_advance); the global-gather variant keeps the
+    // per-lane row bookkeeping.
+    advance_loop<T, METHOD, ISO, decltype(gather), LDS>(a, K, gather, r, k, i, alive, max_size, nsteps);
     if (alive) store_ray<T, METHOD>(a, k, r, i, true);
 }
 
@@ -751,6 +826,9 @@ template <typename T> static const void* refill_fn(int m, bool iso, bool lds) {
 // the vector-memory queue the stores occupy: 27.0 vs 29.0 ms at full record); without dense recording the plain
 // gather is ahead (18.9 vs 20.3 ms) because the kernel is VALU-bound and the tile costs ~25 integer instructions.
 static bool use_lds_tile(const rtmi_batch* b) {
+    // the tile kernel stores rows through a wave-uniform descriptor (write_row_uniform): rays must be in lockstep
+    // (no rtmi_batch_set_state since the last reset) and 6 quantities x R values must fit 31-bit byte offsets
+    if (b->p.record_stride != 0 && (b->dirty_state || (double)b->R * (double)b->esz * 6.0 >= 2147483647.0)) return false;
     if (b->p.field_path == 1) return false;
     if (b->p.field_path == 2) return true;
     return b->p.record_stride == 1 || b->p.record_stride == 2;
@@ -814,6 +892,8 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     ARG_TRY(p->field_path >= 0 && p->field_path <= 2, "rtmi_batch_create: field_path must be 0 (auto), 1 (global) or 2 (LDS tile)");
     ARG_TRY(p->sort_rays == 0 || p->sort_rays == 1, "rtmi_batch_create: sort_rays must be 0 or 1");
     ARG_TRY(p->lazy_clear == 0 || p->lazy_clear == 1, "rtmi_batch_create: lazy_clear must be 0 or 1");
+    ARG_TRY(p->no_n_ray == 0 || p->no_n_ray == 1, "rtmi_batch_create: no_n_ray must be 0 or 1");
+    ARG_TRY(!(p->no_n_ray && p->ext_n_ray), "rtmi_batch_create: no_n_ray set together with ext_n_ray");
     DEVICE_TRY(f, "rtmi_batch_create");
     rtmi_batch* b = new (std::nothrow) rtmi_batch();
     if (!b) return fail(RTMI_ERR_ALLOC, "rtmi_batch_create: host allocation failed");
@@ -834,7 +914,8 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
         if (b->p.record_stride > 0) {
             if (p->ext_s_ray) b->s_ray = p->ext_s_ray;
             else { HIP_TRY(hipMalloc(&b->s_ray, (size_t)b->p.rec_rows * 6 * Rz * b->esz)); b->own_s = true; }
-            if (p->ext_n_ray) b->n_ray = p->ext_n_ray;
+            if (p->no_n_ray) b->n_ray = nullptr;
+            else if (p->ext_n_ray) b->n_ray = p->ext_n_ray;
             else { HIP_TRY(hipMalloc(&b->n_ray, (size_t)b->p.rec_rows * Rz * b->esz)); b->own_n = true; }
         }
         std::vector<double> sorted;   // keeps the permuted launch conditions alive until the copies are done
@@ -1015,8 +1096,9 @@ static int fold_events(rtmi_batch* b) {
     return RTMI_OK;
 }
 
-template <typename T> static void launch_advance(const rtmi_batch* b, int nsteps) {
+template <typename T> static void launch_advance(rtmi_batch* b, int nsteps) {
     BatchDev<T> a = batch_dev<T>(b);
+    b->kfn = pick_advance(b);   // depends on state that changes after create (set_state, set_per_ray)
     void* args[] = {&a, &nsteps};
     const int bs = b->p.block_size > 0 ? b->p.block_size : 256;
     const dim3 g((unsigned)((b->R + bs - 1) / bs)), blk(bs);
@@ -1160,6 +1242,7 @@ RTMI_EXPORT int rtmi_read_rows(rtmi_batch* b, int64_t row0, int64_t nrows, doubl
     ARG_TRY(b, "rtmi_read_rows: null");
     ARG_TRY(b->p.record_stride > 0, "rtmi_read_rows: batch keeps no trajectory (record_stride = 0)");
     ARG_TRY(row0 >= 0 && nrows >= 0 && row0 + nrows <= b->p.rec_rows, "rtmi_read_rows: row range outside rec_rows");
+    ARG_TRY(!(n_ray && !b->n_ray), "rtmi_read_rows: n_ray requested but the batch keeps none (params.no_n_ray)");
     if (nrows == 0) return RTMI_OK;
     const size_t R = (size_t)b->R;
     for (int which = 0; which < 2; which++) {
@@ -1336,10 +1419,14 @@ template <typename T> __global__ void k_isochrone(BatchDev<T> a, int ntimes, con
     }
 }
 
-RTMI_EXPORT int rtmi_isochrones(rtmi_batch* b, int32_t ntimes, const double* times, double* out) {
-    ARG_TRY(b && times && out, "rtmi_isochrones: null");
+int rtmi_internal_fail(int code, const char* msg) { return fail(code, msg); }
+
+// the per-ray isochrone stage with its result left on the device (shared with wavefront.hip)
+int rtmi_internal_isochrones_device(rtmi_batch* b, int32_t ntimes, const double* times, double** d_out, long* R, void** stream) {
+    ARG_TRY(b && times && d_out, "rtmi_isochrones: null");
     ARG_TRY(ntimes > 0 && ntimes <= 4096, "rtmi_isochrones: ntimes must be in [1, 4096]");
     ARG_TRY(b->p.record_stride == 1, "rtmi_isochrones: needs the full trajectory (record_stride 1)");
+    DEVICE_TRY(b->field, "rtmi_isochrones");
     double *d = nullptr, *dt = nullptr;
     const size_t nb = (size_t)ntimes * 3 * (size_t)b->R * sizeof(double);
     HIP_TRY(hipMalloc(&d, nb));
@@ -1351,10 +1438,25 @@ RTMI_EXPORT int rtmi_isochrones(rtmi_batch* b, int32_t ntimes, const double* tim
         else hipLaunchKernelGGL(k_isochrone<float>, g, blk, 0, b->stream, batch_dev<float>(b), (int)ntimes, dt, d);
         e = hipGetLastError();
     }
-    if (e == hipSuccess) e = hipMemcpyAsync(out, d, nb, hipMemcpyDeviceToHost, b->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-    (void)hipFree(d);
     (void)hipFree(dt);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return fail(RTMI_ERR_HIP, std::string("rtmi_isochrones: ") + hipGetErrorString(e));
+    }
+    *d_out = d;
+    if (R) *R = (long)b->R;
+    if (stream) *stream = (void*)b->stream;
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_isochrones(rtmi_batch* b, int32_t ntimes, const double* times, double* out) {
+    ARG_TRY(out, "rtmi_isochrones: null");
+    double* d = nullptr;
+    const int rc = rtmi_internal_isochrones_device(b, ntimes, times, &d, nullptr, nullptr);
+    if (rc) return rc;
+    const hipError_t e = hipMemcpy(out, d, (size_t)ntimes * 3 * (size_t)b->R * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
     if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_isochrones: ") + hipGetErrorString(e));
     return RTMI_OK;
 }

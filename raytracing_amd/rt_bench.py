@@ -275,7 +275,7 @@ class Batch:
 
     def __init__(self, field, method, step, max_size, box, gamma, thetas, x0, y0, record_stride=1, rec_rows=0,
                  gamma_step=None, stream=None, ext_s_ray=None, ext_n_ray=None, block_size=0, launch_mode=0,
-                 refill_min=0, exact_basis=0, field_path=0, sort_rays=False, lazy_clear=False):
+                 refill_min=0, exact_basis=0, field_path=0, sort_rays=False, lazy_clear=False, keep_n_ray=True):
         self.field = field
         th = np.ascontiguousarray(thetas, dtype=np.float64)
         self.R = len(th)
@@ -297,6 +297,7 @@ class Batch:
         p.sort_rays = int(bool(sort_rays))
         p.ext_s_ray = ext_s_ray; p.ext_n_ray = ext_n_ray
         p.lazy_clear = int(bool(lazy_clear))
+        p.no_n_ray = int(not keep_n_ray)
         self.params = p
         self._h = C.c_void_p()
         check(lib().rtmi_batch_create(field._h, C.byref(p), self.R, dptr(x0), dptr(y0), dptr(th), stream,
@@ -361,6 +362,30 @@ class Batch:
         check(lib().rtmi_isochrones(self._h, len(t), dptr(t), dptr(out)))
         return out
 
+    def wavefronts(self, times, nfine=100):
+        """The reference's wavefront extraction (RT_bench.py:1005-1044) on the device: one dict per traveltime with the
+        points of the wavefront sorted by y -- 'y', 'x', 'angle' (ray angle), 'dxdy' (derivative of the PCHIP interpolant
+        x(y) at the points), 'normal' (normal angle), 'angle_diff' (|ray angle - normal angle|), 'ray' (ray indices) --
+        and 'x_fine', 'y_fine' (the interpolated wavefront on nfine points).  Wavefronts with < 2 points have empty
+        derived arrays, like the reference, which skips them (:1011)."""
+        t = np.ascontiguousarray(times, dtype=np.float64)
+        nt = len(t)
+        count = np.zeros(nt, dtype=np.int64)
+        nodes = np.empty((nt, 7, self.R))
+        fine = np.empty((nt, 2, nfine)) if nfine else None
+        check(lib().rtmi_wavefronts(self._h, nt, dptr(t), int(nfine), count.ctypes.data_as(C.POINTER(C.c_int64)), dptr(nodes),
+                                    dptr(fine)))
+        out = []
+        for i in range(nt):
+            n = int(count[i])
+            d = dict(time=float(t[i]), count=n, y=nodes[i, 0, :n].copy(), x=nodes[i, 1, :n].copy(), angle=nodes[i, 2, :n].copy(),
+                     ray=nodes[i, 6, :n].astype(np.int64))
+            m = n if n >= 2 else 0
+            d.update(dxdy=nodes[i, 3, :m].copy(), normal=nodes[i, 4, :m].copy(), angle_diff=nodes[i, 5, :m].copy(),
+                     x_fine=fine[i, 0].copy() if nfine and m else np.empty(0), y_fine=fine[i, 1].copy() if nfine and m else np.empty(0))
+            out.append(d)
+        return out
+
     def stats(self):
         s = Stats()
         check(lib().rtmi_batch_stats(self._h, C.byref(s)))
@@ -377,6 +402,10 @@ class Batch:
         For consumers that stay on the GPU or feed torch.distributed (RCCL) collectives; the tensors alias
         library memory and die with the batch."""
         import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("torch sees no HIP device: when torch and raytracing_amd share a process, import torch "
+                               "(and let it initialise, e.g. torch.cuda.is_available()) BEFORE the first rtmi call -- "
+                               "torch bundles its own HIP runtime and must be the first to open the device")
         v = self.view()
         ts = "<f8" if v.dtype == F64 else "<f4"
 
@@ -528,7 +557,7 @@ def trazar(selected_func, z, grd, show, step, divisor, user_choice, *, thetas=No
         max_size = N * divisor if op_fish else int(np.ceil(s / step) + 1)   # :796-799
     stride = 0 if record is None else (1 if record == "full" else int(record))
     b = Batch(fld, selected_func, step, max_size, box, gamma, theta_v[:ray_count], x0, y0, record_stride=stride,
-              sort_rays="auto")
+              sort_rays="auto", keep_n_ray=False)          # n_ray is internal to the reference's trazar (:803), never returned
     t1 = time.perf_counter()
     b.run()
     b.sync()

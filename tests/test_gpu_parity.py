@@ -933,3 +933,62 @@ def test_cfg4_fp32_full_8m_rays(rb, gpu_fields):
     assert same.mean() > 0.99 and err < 2e-5
     n0 = 0.07142864686293911
     assert np.max(np.abs(f32[6] - n0 * np.cos(th))) / n0 < 6e-4
+
+
+# ------------------------------------------------------------------ SURVEY 8f rank 4, second stage: wavefronts across rays
+def test_wavefronts_vs_scipy_on_reference_trajectories(rb, gpu_fields):
+    """rtmi_wavefronts (device: sort by y, PCHIP across rays, derivative, normal angles, 100-point curve) against the
+    reference's own code path (RT_bench.py:1005-1026, 1043-1044: np.argsort + scipy PchipInterpolator + .derivative())
+    applied to the reference's trajectories -- fixture wavefronts_vert_op6, 11 traveltimes x 31 rays."""
+    g = golden("wavefronts_vert_op6")
+    b = rb.Batch(gpu_fields("vert_heterogeneous"), 6, float(g["step"]), int(g["max_size"]), g["box"], 1, g["theta"], -2.0,
+                 -2.0, record_stride=1)
+    b.run()
+    wf = b.wavefronts(g["times"])
+    iso = b.isochrones(g["times"])
+    b.close()
+    assert len(wf) == 11
+    seen = 0
+    for it, w in enumerate(wf):
+        n = int(g[f"count{it}"])
+        assert w["count"] == n
+        if n <= 1:
+            assert len(w["dxdy"]) == 0 and len(w["x_fine"]) == 0      # the reference skips such wavefronts (:1011)
+            continue
+        seen += 1
+        assert np.array_equal(w["ray"], g[f"ray{it}"])                # same order as np.argsort gives
+        assert np.all(np.diff(w["y"]) > 0)
+        for key in ("y", "x", "dxdy", "normal", "x_fine", "y_fine"):
+            assert np.abs(w[key] - g[key + str(it)]).max() < 1e-10, (it, key)
+        # |ray angle - normal angle|: the reference zips the ray-ordered angles with the y-sorted normals (:1032); the two
+        # orders coincide on its fans, and the device pairs each point with its own angle
+        assert np.abs(w["angle"] - iso[it, 2, w["ray"]]).max() == 0
+        assert np.abs(w["angle_diff"] - np.abs(w["angle"] - w["normal"])).max() < 1e-15
+        assert np.abs(w["angle_diff"] - g[f"angle_diff_ref{it}"]).max() < 1e-10
+        assert w["angle_diff"].max() < 0.05                           # rays are normal to wavefronts (31 coarse points)
+    assert seen >= 8
+
+
+def test_wavefronts_large_fan_properties(rb, gpu_fields):
+    """The same stage on a 65 536-ray fan with the rays in shuffled order (the sort has real work to do): y strictly
+    increasing, ray indices a permutation of the rays that reach the traveltime, rays normal to the wavefront."""
+    R = 65536
+    rng = np.random.default_rng(3)
+    th = rng.permutation(np.linspace(0.05, np.pi / 2 - 0.05, R))
+    lim = LIMITS["vert_heterogeneous"]
+    b = rb.Batch(gpu_fields("vert_heterogeneous"), 6, rb.DELTA_S, 30228, lim, 1, th, -2.0, -2.0, record_stride=1, rec_rows=3072,
+                 sort_rays=True, keep_n_ray=False)
+    b.run()
+    times = [0.1, 0.2]
+    wf = b.wavefronts(times, nfine=1000)
+    iso = b.isochrones(times)
+    b.close()
+    for it, w in enumerate(wf):
+        reach = ~np.isnan(iso[it, 0])
+        assert w["count"] == reach.sum() and w["count"] > R // 2
+        assert np.array_equal(np.sort(w["ray"]), np.nonzero(reach)[0])
+        assert np.all(np.diff(w["y"]) > 0)
+        assert np.array_equal(w["x"], iso[it, 0, w["ray"]]) and np.array_equal(w["y"], iso[it, 1, w["ray"]])
+        assert np.median(w["angle_diff"]) < 1e-3 and w["angle_diff"][100:-100].max() < 2e-2
+        assert np.all(np.diff(w["y_fine"]) > 0) and w["y_fine"][0] == w["y"][0] and w["y_fine"][-1] == w["y"][-1]
+        assert np.abs(np.interp(w["y_fine"], w["y"], w["x"]) - w["x_fine"]).max() < 1e-6
