@@ -108,18 +108,25 @@ template <> struct M<float> {
 
 // sin/cos of (theta + k) given s = sin(theta), c = cos(theta): for |k| < 2^-6 the angle-addition formulas
 // with 4-term series of sin k and 1 - cos k (truncation < 1e-19 relative), else a full evaluation.
+template <typename T> __device__ __forceinline__ void sincos_add_small(T s, T c, T k, T* so, T* co) {
+    const T z = k * k;
+    T ps = fma_(z, T(-1.0 / 5040.0), T(1.0 / 120.0));
+    ps = fma_(z, ps, T(-1.0 / 6.0));
+    const T sk = fma_(z * k, ps, k);                 // sin k
+    T pc = fma_(z, T(-1.0 / 40320.0), T(1.0 / 720.0));
+    pc = fma_(z, pc, T(-1.0 / 24.0));
+    pc = fma_(z, pc, T(0.5));
+    const T ck1 = z * pc;                            // 1 - cos k
+    *so = fma_(c, sk, fma_(-s, ck1, s));
+    *co = fma_(-s, sk, fma_(-c, ck1, c));
+}
 template <typename T> __device__ __forceinline__ void sincos_add(double theta, T s, T c, T k, T* so, T* co) {
-    if (M<T>::abs_(k) < M<T>::small_angle) {
-        const T z = k * k;
-        T ps = fma_(z, T(-1.0 / 5040.0), T(1.0 / 120.0));
-        ps = fma_(z, ps, T(-1.0 / 6.0));
-        const T sk = fma_(z * k, ps, k);                 // sin k
-        T pc = fma_(z, T(-1.0 / 40320.0), T(1.0 / 720.0));
-        pc = fma_(z, pc, T(-1.0 / 24.0));
-        pc = fma_(z, pc, T(0.5));
-        const T ck1 = z * pc;                            // 1 - cos k
-        *so = fma_(c, sk, fma_(-s, ck1, s));
-        *co = fma_(-s, sk, fma_(-c, ck1, c));
+    const bool small = M<T>::abs_(k) < M<T>::small_angle;
+    // per-lane choice of formula; the vote only selects a layout without exec-mask bookkeeping for the common case
+    if (__ballot(!small) == 0ull) {
+        sincos_add_small(s, c, k, so, co);
+    } else if (small) {
+        sincos_add_small(s, c, k, so, co);
     } else {
         M<T>::sincos_(theta + (double)k, so, co);
     }
@@ -227,28 +234,41 @@ __device__ __forceinline__ int axis_basis(T v, int j, T t0, T t1, int q, T a, T 
 //
 // Fast path (per lane; unless F.exact): a cell at least five cells inside the grid has the six cubic knots
 // x[j-2..j+3] = consecutive linspace points, i.e. equally spaced up to the rounding of i*h + a (measured:
-// <= 3e-13 relative to h on the reference's grids).  There the cubic weights are the uniform B-spline
-// polynomials of u = (v - x[j])/(x[j+1] - x[j]) -- 10 flops instead of 61 -- and differ from fpbspl on the true
-// knots by <= 4e-14 absolute (tools/basis_error.py).  The linear weights keep fpbspl's form.  F.exact forces
-// the general form everywhere; rtmi_field_eval (the n_gradient call surface) always uses it.
+// <= 3e-13 relative to h on the reference's grids).  There the position in the cell is u = (v - a)/h - j straight
+// from the quotient that locates the cell (no knot is formed at all), the linear weights are (1 - u, u) and the cubic
+// weights are the uniform B-spline polynomials of u -- 16 flops instead of 61.  u differs from FITPACK's
+// (v - x[j])/(x[j+1] - x[j]) by the rounding of the quotient (<= 6e-14 of a cell for grids up to 1000 cells) plus the
+// knots' own departure from equal spacing; a lookup that lands within that distance of a grid line may take the
+// neighbouring cell with u = 1 - eps instead of eps, which the splines' continuity makes immaterial.  Weights differ
+// from fpbspl on the true knots by <= 1.5e-13 absolute (tools/basis_error.py).  F.exact forces the general form
+// everywhere; rtmi_field_eval (the n_gradient call surface) always uses it.
+template <typename T>
+__device__ __forceinline__ void axis_fast(T ur, T jf, int& j, int& l, T wl[2], T w[4]) {
+    const T u = ur - jf, om = T(1) - u;
+    j = (int)jf;
+    l = j + 2;
+    wl[0] = om; wl[1] = u;
+    const T u2 = u * u, om2 = om * om;
+    w[0] = om2 * om * T(1.0 / 6.0);
+    w[1] = fma_(u2, fma_(u, T(0.5), T(-1)), T(2.0 / 3.0));
+    w[2] = fma_(om2, fma_(om, T(0.5), T(-1)), T(2.0 / 3.0));
+    w[3] = u2 * u * T(1.0 / 6.0);
+}
+__device__ __forceinline__ double floor_(double x) { return __builtin_floor(x); }
+__device__ __forceinline__ float floor_(float x) { return __builtin_floorf(x); }
+
 template <typename T>
 __device__ __forceinline__ void axis_eval(T v, int q, T a, T h, T b, T ih, int exact, int& j, int& l, T wl[2], T w[4]) {
     v = M<T>::min_(M<T>::max_(v, a), b);
-    const int jg = (int)((v - a) * ih);
-    if (!exact && jg >= 5 && jg <= q - 8) {
-        T t0 = M<T>::lin(jg, h, a), t1 = M<T>::lin(jg + 1, h, a);
-        j = jg;
-        if (t0 > v) { j = jg - 1; t1 = t0; t0 = M<T>::lin(j, h, a); }                 // rare: v within rounding of a grid line
-        else if (t1 <= v) { j = jg + 1; t0 = t1; t1 = M<T>::lin(j + 1, h, a); }
-        const T f = rcp_near(t1 - t0, ih);
-        const T om = f * (t1 - v), u = f * (v - t0);
-        wl[0] = om; wl[1] = u;
-        const T u2 = u * u, om2 = om * om;
-        w[0] = om2 * om * T(1.0 / 6.0);
-        w[1] = fma_(u2, fma_(u, T(0.5), T(-1)), T(2.0 / 3.0));
-        w[2] = fma_(om2, fma_(om, T(0.5), T(-1)), T(2.0 / 3.0));
-        w[3] = u2 * u * T(1.0 / 6.0);
-        l = j + 2;
+    const T ur = (v - a) * ih, jf = floor_(ur);
+    const int jg = (int)jf;
+    const bool fast = !exact && jg >= 5 && jg <= q - 8;
+    // Which FORMULA a lane uses depends on its own values only; the wave vote merely picks a code layout without
+    // exec-mask bookkeeping for the (overwhelmingly common) case that every lane is in the interior.
+    if (__ballot(!fast) == 0ull) {
+        axis_fast(ur, jf, j, l, wl, w);
+    } else if (fast) {
+        axis_fast(ur, jf, j, l, wl, w);
     } else {
         T t0, t1;
         j = locate(v, q, a, h, b, ih, t0, t1);
@@ -469,13 +489,17 @@ template <typename T> struct Consts {
 
 // anisotropy(theta, gamma) (:118-119) from sin/cos.  ISO (gamma == 1): sqrt(s^2 + c^2), which is 1 +- ulp
 // and is kept (quirk Q5), the product gamma*s is exact.
+// ISO (gamma == 1): the reference's sqrt(sin^2 + cos^2) is 1 +- 1 ulp (quirk Q5) -- rounding noise of ITS sin/cos; with
+// this path's own sin/cos (within 1 ulp of libm's, not equal) the noise would be a different one, so the factor is taken
+// as exactly 1 here (momenta, n_ray and traveltime move by <= 1 ulp; the reference-order methods of rt_exact.h keep it).
 template <typename T, bool ISO> __device__ __forceinline__ T aniso(T s, T c, T gamma) {
-    const T gs = ISO ? s : gamma * s;
+    if (ISO) return T(1);
+    const T gs = gamma * s;
     return M<T>::sqrt_(fma_(gs, gs, c * c));
 }
 // moment() (:217-230) given coef = anisotropy(theta, gamma).  ISO: gamma**2-1 == 0 makes the bracket exactly 1.
 template <typename T, bool ISO> __device__ __forceinline__ T moment(T n, T coef, T g2m1, T o0, T o1) {
-    if (ISO) return n * coef * o0;
+    if (ISO) return n * o0;
     return n * coef * o0 * (T(1) + o1 * g2m1 / (coef * coef));
 }
 template <typename T> __device__ __forceinline__ T impulse(T a, T b, T step) { return step * (a + b) * T(0.5); }
@@ -626,7 +650,7 @@ __device__ __forceinline__ void store_update(const Consts<T>& k, Ray<T>& r, Acc 
     r.hx0 = r.hx1; r.hy0 = r.hy1; r.hx1 = (T)r.x; r.hy1 = (T)r.y;
     r.x = fx; r.y = fy; r.th = fth; r.n = fn; r.gx = fgx; r.gy = fgy; r.rn = frn;
     r.ux = c; r.uy = s; r.coef = coef;
-    const T nray = coef * fn;                               // (:873)
+    const T nray = ISO ? fn : coef * fn;                    // (:873)
     r.tt = r.tt + (Acc)(dist * (r.nray + nray) * T(0.5));   // (:874) quirk Q6
     r.nray = nray;
 }
@@ -635,7 +659,7 @@ __device__ __forceinline__ void store_update(const Consts<T>& k, Ray<T>& r, Acc 
 template <typename T, bool ISO> __device__ __forceinline__ void derive(const Consts<T>& k, Ray<T>& r) {
     M<T>::sincos_(r.th, &r.uy, &r.ux);
     r.coef = aniso<T, ISO>(r.uy, r.ux, k.gamma);
-    r.nray = r.coef * r.n;
+    r.nray = ISO ? r.n : r.coef * r.n;
     r.rn = rcp_full(r.n);
     r.mx = moment<T, ISO>(r.n, r.coef, k.g2m1, r.ux, -(r.uy * r.uy));
     r.my = moment<T, ISO>(r.n, r.coef, k.g2m1, r.uy, r.ux * r.ux);

@@ -417,6 +417,7 @@ template <typename T> struct BatchDev {
     double* st;
     int has_hist;     // op7 only: hx0, hy0, hx1, hy1 follow n, gx, gy
     int exact;        // fp64 op3/4/5/9/10/11: derived values and lookups in the reference's operation order (rt_exact.h)
+    int iso;          // the step kernels run their ISO build (gamma == 1, method < 10, not exact): coef taken as exactly 1
     __device__ __forceinline__ double* acc(int q) const { return st + (size_t)q * R; }                 // 0..5: x y th dsim dreal tt
     __device__ __forceinline__ T* aux(int q) const { return reinterpret_cast<T*>(st + (size_t)6 * R) + (size_t)q * R; }   // 0..2: n gx gy; 3..6: history
     int* istep;
@@ -436,9 +437,13 @@ template <typename T> __device__ __forceinline__ void write_row(const BatchDev<T
 }
 
 // derived values / lookups outside the step loop, where the method is a run-time property of the batch
-template <typename T> __device__ __forceinline__ void derive_rt(const BatchDev<T>& a, rt::Ray<T>& r) { rt::derive<T, false>(a.K, r); }
+template <typename T> __device__ __forceinline__ void derive_rt(const BatchDev<T>& a, rt::Ray<T>& r) {
+    if (a.iso) rt::derive<T, true>(a.K, r); else rt::derive<T, false>(a.K, r);
+}
 template <> __device__ __forceinline__ void derive_rt<double>(const BatchDev<double>& a, rt::Ray<double>& r) {
-    if (a.exact) rt::ex::derive(a.K, r); else rt::derive<double, false>(a.K, r);
+    if (a.exact) rt::ex::derive(a.K, r);
+    else if (a.iso) rt::derive<double, true>(a.K, r);
+    else rt::derive<double, false>(a.K, r);
 }
 template <typename T> __device__ __forceinline__ void n_gradient_rt(const BatchDev<T>& a, T x, T y, T& n, T& gx, T& gy) {
     rt::GlobalGather<T> gg;
@@ -782,6 +787,7 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     const size_t R = (size_t)b->R;
     a.st = (double*)b->state; a.has_hist = p.method == 7;
     a.exact = p.dtype == RTMI_F64 && rt::is_exact_method(p.method);
+    a.iso = p.gamma == 1.0 && p.method < 10 && !a.exact;
     a.istep = b->istep; a.alive = b->alive;
     a.s_ray = (T*)b->s_ray; a.n_ray = (T*)b->n_ray;
     a.counters = b->counters;
