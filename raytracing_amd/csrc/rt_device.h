@@ -242,6 +242,7 @@ __device__ __forceinline__ int axis_basis(T v, int j, T t0, T t1, int q, T a, T 
 // neighbouring cell with u = 1 - eps instead of eps, which the splines' continuity makes immaterial.  Weights differ
 // from fpbspl on the true knots by <= 1.5e-13 absolute (tools/basis_error.py).  F.exact forces the general form
 // everywhere; rtmi_field_eval (the n_gradient call surface) always uses it.
+// (the unclamped quotient is used: a point that far inside the grid is not affected by the clamp of quirk Q4)
 template <typename T>
 __device__ __forceinline__ void axis_fast(T ur, T jf, int& j, int& l, T wl[2], T w[4]) {
     const T u = ur - jf, om = T(1) - u;
@@ -257,23 +258,12 @@ __device__ __forceinline__ void axis_fast(T ur, T jf, int& j, int& l, T wl[2], T
 __device__ __forceinline__ double floor_(double x) { return __builtin_floor(x); }
 __device__ __forceinline__ float floor_(float x) { return __builtin_floorf(x); }
 
+// general form of one axis (any cell): clamp, interval search on the true knots, fpbspl
 template <typename T>
-__device__ __forceinline__ void axis_eval(T v, int q, T a, T h, T b, T ih, int exact, int& j, int& l, T wl[2], T w[4]) {
-    v = M<T>::min_(M<T>::max_(v, a), b);
-    const T ur = (v - a) * ih, jf = floor_(ur);
-    const int jg = (int)jf;
-    const bool fast = !exact && jg >= 5 && jg <= q - 8;
-    // Which FORMULA a lane uses depends on its own values only; the wave vote merely picks a code layout without
-    // exec-mask bookkeeping for the (overwhelmingly common) case that every lane is in the interior.
-    if (__ballot(!fast) == 0ull) {
-        axis_fast(ur, jf, j, l, wl, w);
-    } else if (fast) {
-        axis_fast(ur, jf, j, l, wl, w);
-    } else {
-        T t0, t1;
-        j = locate(v, q, a, h, b, ih, t0, t1);
-        l = axis_basis(v, j, t0, t1, q, a, h, b, wl, w);
-    }
+__device__ __forceinline__ void axis_general(T v, int q, T a, T h, T b, T ih, int& j, int& l, T wl[2], T w[4]) {
+    T t0, t1;
+    j = locate(v, q, a, h, b, ih, t0, t1);      // clamps v (quirk Q4)
+    l = axis_basis(v, j, t0, t1, q, a, h, b, wl, w);
 }
 
 // ---------------------------------------------------------------- n_gradient = locate + gather + combine
@@ -283,9 +273,27 @@ template <typename T> struct Cell {
     T lwx[2], lwy[2], wx[4], wy[4];
 };
 
+// Both axes.  A lane takes the fast form on an axis when the UNCLAMPED quotient (v - a)/h lies in [5, q - 7): the point
+// is then at least five cells inside the grid (no clamp can apply) and cell j = floor(quotient) has equally spaced
+// knots around it.  Which FORMULA a lane uses depends on its own values only; the wave vote below merely picks a code
+// layout without exec-mask bookkeeping for the overwhelmingly common case that every lane is interior on both axes.
+// Both axes.  A lane takes the fast form on an axis when the UNCLAMPED quotient (v - a)/h lies in [5, q - 7): the point
+// is then at least five cells inside the grid (no clamp can apply) and cell j = floor(quotient) has equally spaced
+// knots around it.  Which FORMULA a lane uses depends on its own values only; the wave vote below merely picks a code
+// layout without exec-mask bookkeeping for the overwhelmingly common case that every lane is interior on both axes.
 template <typename T> __device__ __forceinline__ void field_locate(const FieldDev<T>& F, T x, T y, Cell<T>& c) {
-    axis_eval(x, F.qx, F.ax, F.hx, F.bx, F.inv_hx, F.exact, c.jx, c.lx, c.lwx, c.wx);
-    axis_eval(y, F.qy, F.ay, F.hy, F.by, F.inv_hy, F.exact, c.jy, c.ly, c.lwy, c.wy);
+    const T urx = (x - F.ax) * F.inv_hx, ury = (y - F.ay) * F.inv_hy;
+    const bool fx = !F.exact && urx >= T(5) && urx < (T)(F.qx - 7);     // false for NaN
+    const bool fy = !F.exact && ury >= T(5) && ury < (T)(F.qy - 7);
+    if (__ballot(!(fx && fy)) == 0ull) {
+        axis_fast(urx, floor_(urx), c.jx, c.lx, c.lwx, c.wx);
+        axis_fast(ury, floor_(ury), c.jy, c.ly, c.lwy, c.wy);
+    } else {
+        if (fx) axis_fast(urx, floor_(urx), c.jx, c.lx, c.lwx, c.wx);
+        else axis_general(x, F.qx, F.ax, F.hx, F.bx, F.inv_hx, c.jx, c.lx, c.lwx, c.wx);
+        if (fy) axis_fast(ury, floor_(ury), c.jy, c.ly, c.lwy, c.wy);
+        else axis_general(y, F.qy, F.ay, F.hy, F.by, F.inv_hy, c.jy, c.ly, c.lwy, c.wy);
+    }
 }
 
 // one (d/dx-spline, d/dy-spline) coefficient pair: a single 16-byte (fp64) access in HBM and in LDS
@@ -295,6 +303,8 @@ template <typename T> using Pair = T __attribute__((ext_vector_type(2)));
 // 36 coefficients straight from HBM/L2: 2x2 of zn and the 4x4 window of interleaved pairs.
 template <typename T>
 __device__ __forceinline__ void gather_global(const FieldDev<T>& F, const Cell<T>& c, T z[4], Pair<T> g[4][4]) {
+    // grids hold < 2^31 values and < 2^24 per axis (field_alloc), so the element indices are 24-bit products in 32 bits
+    // (64-bit index arithmetic on purpose: 24-bit multiplies measured 8 % slower here -- two more spilled registers)
     const T* zp = F.zn + (size_t)c.jy * F.qx + c.jx;
     z[0] = zp[0]; z[1] = zp[1]; z[2] = zp[F.qx]; z[3] = zp[F.qx + 1];
     const Pair<T>* gp = reinterpret_cast<const Pair<T>*>(F.g) + ((size_t)(c.ly - 3) * F.qx + (c.lx - 3));

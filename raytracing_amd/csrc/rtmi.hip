@@ -295,7 +295,7 @@ static int field_alloc(int dtype, int qx, int qy, void* stream, rtmi_field** out
     ARG_TRY(out, "field: out is null");
     ARG_TRY(dtype == RTMI_F64 || dtype == RTMI_F32, "field: dtype must be RTMI_F64 or RTMI_F32");
     ARG_TRY(qx >= 8 && qy >= 8, "field: grid must be at least 8x8 (cubic not-a-knot fit)");
-    ARG_TRY((size_t)qx * qy < (1ull << 31), "field: grid too large");
+    ARG_TRY((size_t)qx * qy < (1ull << 31) && qx < (1 << 24) && qy < (1 << 24), "field: grid too large");
     rtmi_field* f = new (std::nothrow) rtmi_field();
     if (!f) return fail(RTMI_ERR_ALLOC, "field: host allocation failed");
     f->dtype = dtype; f->qx = qx; f->qy = qy; f->stream = (hipStream_t)stream;
@@ -540,6 +540,9 @@ template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::
 // per-quantity scalar offset (q*R elements) and a per-lane constant (lane*sizeof(T)).  That removes the per-lane
 // 64-bit address arithmetic of write_row (seven v_mad_u64_u32 / v_lshl_add_u64 chains per step) and frees their
 // registers.  RTMI_ROW_STORE_AUX sets the stores' cache policy (0 plain, 2 nt, 16 sc1, 18 sc1 nt).
+#ifndef RTMI_TILE_WAVES
+#define RTMI_TILE_WAVES 2      // waves per SIMD the LDS-tile variant of k_advance is built for
+#endif
 #ifndef RTMI_ROW_STORE_AUX
 #define RTMI_ROW_STORE_AUX 2   // nt: rows are written once and never read by the kernel (measured 3-5 % over plain stores)
 #endif
@@ -628,7 +631,7 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
 // Every lane runs every iteration until no lane of its wave is active; a ray's state is stored the moment it
 // terminates (or when the launch's step budget ends), so idle lanes never write.
 template <typename T, int METHOD, bool ISO, bool LDS, bool VAR>
-__global__ __launch_bounds__(256, LDS ? 2 : (sizeof(T) == 4 ? 4 : 3)) void k_advance(BatchDev<T> a, int nsteps) {
+__global__ __launch_bounds__(256, LDS ? RTMI_TILE_WAVES : (sizeof(T) == 4 ? 4 : 3)) void k_advance(BatchDev<T> a, int nsteps) {
     __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
     typename GatherOf<T, LDS>::type gather;
     gather_init<T, LDS>(gather, lds);
