@@ -179,11 +179,12 @@ __device__ __forceinline__ double ang_cost(const Ray<double>& r, double step, do
 // One new point per iteration: of the two points of the new bracket one is the previous iteration's better point
 // ("survivor"; equal up to a few ulps of t to the point the reference would evaluate again), the other is the
 // survivor moved by h_j = pi*GR^(j+4) towards the kept side.
-//   Phase A (first kGoldRotIters iterations, bracket >= 2e-5): sin/cos of the new point by rotating the survivor's
-//     sin/cos through h_j (table rt_golden_rot.h), no sincos evaluation at all.  The tracked angle drifts from the
-//     actual point by rounding (bounded by DPHI below), which only loosens the bound -- harmless while the bracket,
-//     and with it the gap between the two costs, is wide.
-//   Phase B (the rest): sincos_k at the actual point, tight bound, the survivor's value reused with its actual
+//   Phase A (the first kGoldRotIters iterations -- with the default, all 37 of a search that starts from width pi):
+//     sin/cos of the new point by rotating the survivor's sin/cos through h_j (table rt_golden_rot.h), no sincos
+//     evaluation at all.  The tracked angle drifts from the actual point by rounding (bounded by DPHI below), which
+//     only loosens the bound; measured on the BASELINE configurations the exact re-evaluation stays rare even in the
+//     last iterations (cfg5: 8.4e9 ray-steps/s with 24 rotation iterations, 9.5e9 with all of them).
+//   Phase B (whatever remains): sincos_k at the actual point, tight bound, the survivor's value reused with its actual
 //     distance |t - t_eval| priced in.
 //
 // FastSC(s, c, f, g): cost f and g = |e_x| + |e_y| of the residual vector from sin/cos of the evaluation angle.
@@ -192,13 +193,17 @@ __device__ __forceinline__ double ang_cost(const Ray<double>& r, double step, do
 //   LIP = 2 x (bound on |d e/dt|), K2 = relative error of squaring and adding, K3 = second-order terms.
 struct GoldBounds { double K1, LIP, K2, K3; };
 
-constexpr int kGoldRotIters = 24;
+#ifndef RTMI_GOLD_ROT_ITERS
+#define RTMI_GOLD_ROT_ITERS 48   // <= RT_GOLD_ROT_ENTRIES; from a bracket of width pi the search ends after 37 iterations
+#endif
+constexpr int kGoldRotIters = RTMI_GOLD_ROT_ITERS;
 __device__ const double kGoldRot[2 * RT_GOLD_ROT_ENTRIES] = {RT_GOLD_ROT_VALUES};
 constexpr double kU = 1.1102230246251565e-16;   // 2^-53
 
-template <typename FastSC, typename Exact>
-__device__ __forceinline__ double golden_filtered(FastSC fast_sc, Exact exact, const GoldBounds& B, double th, double s0,
-                                                  double c0) {
+// fast_a: the phase-A evaluation (may be cheaper and looser than fast_sc by at most EA in one residual component)
+template <typename FastA, typename FastSC, typename Exact>
+__device__ __forceinline__ double golden_filtered(FastA fast_a, double EA, FastSC fast_sc, Exact exact, const GoldBounds& B,
+                                                  double th, double s0, double c0) {
     const double GR = kGoldRatio, tol = M<double>::gold_tol;
     double a = th - kHalfPi, b = th + kHalfPi;
     double c = b - (b - a) * GR, d = a + (b - a) * GR;
@@ -208,13 +213,13 @@ __device__ __forceinline__ double golden_filtered(FastSC fast_sc, Exact exact, c
         // arithmetic's roundings (<= ulp(t) per update, t up to |theta| + pi/2)
         const double dphi = kU * (8.0 + kGoldRotIters * (6.0 + 2.0 * (__builtin_fabs(th) + 2.0)));
         const double lA = B.LIP * dphi;
-        const double K1A = B.K1 + lA, K3A = 4.0 * K1A * K1A;
+        const double K1A = B.K1 + lA + 2.0 * EA, K3A = 4.0 * K1A * K1A;
         const double sk = RT_GOLD_KAPPA_SIN, ck = RT_GOLD_KAPPA_COS;
         double sX = fma_(-c0, sk, s0 * ck), cX = fma_(s0, sk, c0 * ck);   // theta0 - kappa
         double sY = fma_(c0, sk, s0 * ck), cY = fma_(-s0, sk, c0 * ck);   // theta0 + kappa
         double fX, gX, fY, gY;
-        fast_sc(sX, cX, fX, gX);
-        fast_sc(sY, cY, fY, gY);
+        fast_a(sX, cX, fX, gX);
+        fast_a(sY, cY, fY, gY);
         bool x_is_c = true;
         for (; it < kGoldRotIters && __builtin_fabs(c - d) > tol; ++it) {
             const double bound = fma_(gX + gY, K1A, fma_(fX + fY, B.K2, K3A));
@@ -232,13 +237,13 @@ __device__ __forceinline__ double golden_filtered(FastSC fast_sc, Exact exact, c
             const double sh = lt ? -kGoldRot[2 * it] : kGoldRot[2 * it];
             sY = fma_(cX, sh, sX * ch);
             cY = fma_(-sX, sh, cX * ch);
-            fast_sc(sY, cY, fY, gY);
+            fast_a(sY, cY, fY, gY);
             x_is_c = !lt;
         }
     }
-    // ---- phase B
-    double fc, gc, fd, gd, tc = c, td = d;
-    {
+    // ---- phase B (only if the search is still running)
+    double fc = 0, gc = 0, fd = 0, gd = 0, tc = c, td = d;
+    if (it < kGoldMaxIter && __builtin_fabs(c - d) > tol) {
         double s, cs;
         sincos_k(c, &s, &cs); fast_sc(s, cs, fc, gc);
         sincos_k(d, &s, &cs); fast_sc(s, cs, fd, gd);
@@ -296,7 +301,7 @@ __device__ __forceinline__ double ang_golden_iso(const Ray<double>& r, double st
     const double e1 = 12.0 * kU * mag;
     GoldBounds B;
     B.K1 = 2.0 * e1; B.LIP = 2.0 * afn; B.K2 = 8.0 * kU; B.K3 = 16.0 * e1 * e1;
-    return golden_filtered(fast_sc, exact, B, r.th, r.uy, r.ux);
+    return golden_filtered(fast_sc, 0.0, fast_sc, exact, B, r.th, r.uy, r.ux);
 }
 
 // anisotropic cost (:725-728 / :758-761); the step functions read the module-global gamma (quirk Q12)
@@ -311,18 +316,21 @@ __device__ __forceinline__ double ang_golden_aniso(const Ray<double>& r, const C
     // Fast form: with a^2 = gamma^2 s^2 + c^2 the reference's brackets are 1 - s^2 (gamma^2-1)/a^2 = 1/a^2 and
     // 1 + c^2 (gamma^2-1)/a^2 = gamma^2/a^2, so m_x = n' c / a and m_y = n' gamma^2 s / a: no cancellation, one rsq.
     const double hstep = step * 0.5, gam2 = gam * gam, fng2 = fn * gam2;
-    auto fast_sc = [=](double s, double c, double& f, double& g) {
+    auto fast_n = [=](double s, double c, double& f, double& g, const int newton) {
         const double gs = gam * s;
         const double q2 = fma_(gs, gs, c * c);
-        double ra = __builtin_amdgcn_rsq(q2);                       // 1/a: hardware estimate + two Newton steps (< 2 ulp)
+        double ra = __builtin_amdgcn_rsq(q2);                       // 1/a: hardware estimate + Newton steps
         ra = fma_(ra * 0.5, fma_(-q2 * ra, ra, 1.0), ra);
-        ra = fma_(ra * 0.5, fma_(-q2 * ra, ra, 1.0), ra);
+        if (newton > 1) ra = fma_(ra * 0.5, fma_(-q2 * ra, ra, 1.0), ra);
         const double a = q2 * ra;
         const double e0 = fn * c * ra - mix - fma_(a, fgx, cgx) * hstep;
         const double e1 = fng2 * s * ra - miy - fma_(a, fgy, cgy) * hstep;
         f = fma_(e1, e1, e0 * e0);
         g = __builtin_fabs(e0) + __builtin_fabs(e1);
     };
+    auto fast_sc = [=](double s, double c, double& f, double& g) { fast_n(s, c, f, g, 2); };   // < 2 ulp in 1/a
+    // phase A: one Newton step on the >= 20-bit hardware estimate leaves 1/a within 2^-38 (3.7e-12) relative
+    auto fast_a = [=](double s, double c, double& f, double& g) { fast_n(s, c, f, g, 1); };
     // Error of one residual component (u = 2^-53, relative errors unless stated).  Reference arithmetic: s, c <= 1.1u
     // (libm); a <= 4.1u; n'*a*o0 <= 7.2u; w = o1*(gamma^2-1)/a^2 <= 14.4u with |w| <= wmax = |gamma^2-1| / min(1, gamma^2);
     // the bracket F = 1 + w cancels, |dF| <= 14.4u*wmax + u*|F|, |F| <= 1 + wmax; so |dm| <= |n'|*gmax*(14.4u*wmax +
@@ -343,7 +351,8 @@ __device__ __forceinline__ double ang_golden_aniso(const Ray<double>& r, const C
     // varies with a(t) only
     B.LIP = 3.0 * (afn * g2max * (1.0 / amin + g2a / (2.0 * amin * amin * amin)) + step * g2a / amin * gsum);
     B.K2 = 8.0 * kU; B.K3 = 16.0 * e1 * e1;
-    return golden_filtered(fast_sc, exact, B, r.th, r.uy, r.ux);
+    const double EA = 4.0e-12 * (afn * g2max / amin + step * gmax * gsum);     // |m| * 3.7e-12, and the impulse's a(t)
+    return golden_filtered(fast_a, EA, fast_sc, exact, B, r.th, r.uy, r.ux);
 }
 
 // ---------------------------------------------------------------- opN around the field lookup
