@@ -19,8 +19,8 @@ Rank 0 prints ONE JSON line.
   roofline      what bounds the advance kernel, as a fraction <= 1 of a hardware peak: HBM bytes per launch (rocprofv3
                 counters, profiles/traffic.json; or, without a profile of this configuration, the bytes the launch must
                 write and read: recorded rows + state) over the kernel time measured here with HIP events, against
-                8 TB/s -- and the vector ALU's busy time from the profiled SQ_ACTIVE_INST_VALU counter against 1024 SIMDs
-                at 2.4 GHz.  `bound` names the larger.  SURVEY.md 8d's ALGORITHMIC byte model (state in/out + coefficient gather per ray-step) is kept
+                8 TB/s -- and the vector ALU's issue time from the profiled instruction counts (4 cycles per fp64
+                wave-instruction, 2 per other) against 1024 SIMDs at 2.4 GHz.  `bound` names the larger.  SURVEY.md 8d's ALGORITHMIC byte model (state in/out + coefficient gather per ray-step) is kept
                 under `alg_model`; it is not a bound for this kernel (state lives in registers across all steps of a
                 ray, the gather is served from LDS/L2), which is why it exceeds the HBM peak.
   cpu_baseline  the CPU oracle (oracle/, a port of the reference's algorithm) on this host's cores over a bounded
@@ -278,15 +278,16 @@ def main():
                "bytes_per_pass": hbm_bytes,
                "bytes_source": prof.get("source") if measured else "model: recorded rows x 7 values + ray state in and out"}
         roof = dict(hbm, bound="hbm", traffic=measured, traffic_source=prof.get("source") if measured else None)
-        # vector-ALU busy time from the profiled SQ_ACTIVE_INST_VALU (quad-cycles in which a SIMD executes a vector
-        # instruction, summed over the chip) against 1024 SIMDs at the 2.4 GHz peak clock
-        if measured and prof.get("valu_active_quadcycles"):
-            cyc = 4.0 * prof["valu_active_quadcycles"]
+        # vector-ALU issue time from the profiled instruction counts: a 64-lane fp64 instruction holds a SIMD for 4 cycles
+        # (16 lanes/clk), any other VALU instruction for 2 (SIMD-32); against 1024 SIMDs at the 2.4 GHz peak clock
+        if measured and prof.get("valu_insts"):
+            f64 = prof.get("valu_f64_insts", 0.0)
+            cyc = 4.0 * f64 + 2.0 * (prof["valu_insts"] - f64)
             frac = cyc / SIMDS / PEAK_CLOCK_HZ / ksec
             valu = {"achieved": cyc / ksec / 1e9, "peak": SIMDS * PEAK_CLOCK_HZ / 1e9, "unit": "G SIMD-cycles/s", "frac": frac,
-                    "valu_wave_insts_per_pass": prof.get("valu_insts"), "fp64_wave_insts_per_pass": prof.get("valu_f64_insts"),
+                    "valu_wave_insts_per_pass": prof.get("valu_insts"), "fp64_wave_insts_per_pass": f64,
                     "salu_wave_insts_per_pass": prof.get("salu_insts")}
-            roof["valu_busy"] = valu
+            roof["valu_issue"] = valu
             if frac > roof["frac"]:
                 roof.update(bound="valu", achieved=valu["achieved"], peak=valu["peak"], unit=valu["unit"], frac=frac)
         roof.update(kernel="k_trace_refill" if args.mode == "refill" else "k_advance", kernel_ms=kern_ms / launches,

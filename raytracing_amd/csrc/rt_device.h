@@ -90,7 +90,7 @@ template <> struct M<double> {
     // x[i] of numpy.linspace: i*step + a with separate roundings (contraction is off), so knots equal the host's bit for bit
     static __device__ __forceinline__ double lin(int i, double h, double a) { return (double)i * h + a; }
     static constexpr double gold_tol = 1.4901161193847656e-08;  // sqrt(DBL_EPSILON), RT_bench.py:66
-    static constexpr double small_angle = 0.015625;             // 2^-6: sincos_add's series bound
+    static constexpr double small_angle = 0.03125;              // 2^-5: sincos_add's series bound
 };
 template <> struct M<float> {
     // fp32 is the reduced-precision path (no reference to match bit for bit): hardware sqrt/rcp (1 ulp)
@@ -103,11 +103,13 @@ template <> struct M<float> {
     static __device__ __forceinline__ float min_(float x, float y) { return __builtin_fminf(x, y); }
     static __device__ __forceinline__ float lin(int i, float h, float a) { return (float)i * h + a; }
     static constexpr float gold_tol = 3.4526698300124393e-04f;  // sqrt(FLT_EPSILON): the fp32 analogue
-    static constexpr float small_angle = 0.015625f;
+    static constexpr float small_angle = 0.03125f;
 };
 
-// sin/cos of (theta + k) given s = sin(theta), c = cos(theta): for |k| < 2^-6 the angle-addition formulas
-// with 4-term series of sin k and 1 - cos k (truncation < 1e-19 relative), else a full evaluation.
+// sin/cos of (theta + k) given s = sin(theta), c = cos(theta): for |k| < 2^-5 the angle-addition formulas
+// with 4-term series of sin k and 1 - cos k (truncation < 3e-18 relative), else a full evaluation.  (2^-5 so that the
+// fisheye's RK2 half-step, k1 ~ 0.02 at the calibrated DELTA_S, stays on the series; a fifth term for 2^-4 cost the
+// global-gather kernel two more spilled registers and 11 % of its speed.)
 template <typename T> __device__ __forceinline__ void sincos_add_small(T s, T c, T k, T* so, T* co) {
     const T z = k * k;
     T ps = fma_(z, T(-1.0 / 5040.0), T(1.0 / 120.0));

@@ -543,6 +543,9 @@ template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::
 #ifndef RTMI_TILE_WAVES
 #define RTMI_TILE_WAVES 2      // waves per SIMD the LDS-tile variant of k_advance is built for
 #endif
+#ifndef RTMI_GOLD_WAVES
+#define RTMI_GOLD_WAVES 3      // waves per SIMD the golden-section builds (op5/9/10/11, global gather) are compiled for
+#endif
 #ifndef RTMI_ROW_STORE_AUX
 #define RTMI_ROW_STORE_AUX 2   // nt: rows are written once and never read by the kernel (measured 3-5 % over plain stores)
 #endif
@@ -631,7 +634,8 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
 // Every lane runs every iteration until no lane of its wave is active; a ray's state is stored the moment it
 // terminates (or when the launch's step budget ends), so idle lanes never write.
 template <typename T, int METHOD, bool ISO, bool LDS, bool VAR>
-__global__ __launch_bounds__(256, LDS ? RTMI_TILE_WAVES : (sizeof(T) == 4 ? 4 : 3)) void k_advance(BatchDev<T> a, int nsteps) {
+__global__ __launch_bounds__(256, LDS ? RTMI_TILE_WAVES : (sizeof(T) == 4 ? 4 : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : 3)))
+void k_advance(BatchDev<T> a, int nsteps) {
     __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
     typename GatherOf<T, LDS>::type gather;
     gather_init<T, LDS>(gather, lds);

@@ -75,10 +75,13 @@ def main():
             entry.update(valu_insts=vals["SQ_INSTS_VALU"], valu_f64_insts=f64, salu_insts=vals.get("SQ_INSTS_SALU"),
                          valu_active_quadcycles=vals.get("SQ_ACTIVE_INST_VALU"))
             ms = roof["kernel_ms_per_pass"]
-            if vals.get("SQ_ACTIVE_INST_VALU"):
-                cyc = 4 * vals["SQ_ACTIVE_INST_VALU"]      # the counter ticks in quad-cycles (MI355X_MICROARCH.md, cycle constants)
-                lines.append(f"vector ALU busy: SQ_ACTIVE_INST_VALU x 4 = {cyc:.4g} SIMD-cycles = {cyc / 1024 / 2.4e9 * 1e3:.2f} ms on 1024 SIMDs "
-                             f"at the 2.4 GHz peak clock = {cyc / 1024 / 2.4e9 * 1e3 / ms:.3f} of the un-profiled kernel time")
+            # SIMD issue time: a 64-lane fp64 instruction holds a SIMD for 4 cycles (16 lanes/clk), any other VALU
+            # instruction for 2 (SIMD-32).  SQ_ACTIVE_INST_VALU is per-WAVE activity (about one quad-cycle per instruction
+            # whatever its type) and exceeds the SIMD's time when waves overlap, so it is listed but not used as a bound.
+            cyc = 4.0 * f64 + 2.0 * (vals["SQ_INSTS_VALU"] - f64)
+            lines.append(f"vector ALU issue time: 4 x {f64:.4g} fp64 + 2 x {vals['SQ_INSTS_VALU'] - f64:.4g} other wave-instructions = {cyc:.4g} "
+                         f"SIMD-cycles = {cyc / 1024 / 2.4e9 * 1e3:.2f} ms on 1024 SIMDs at the 2.4 GHz peak clock = "
+                         f"{cyc / 1024 / 2.4e9 * 1e3 / ms:.3f} of the un-profiled kernel time")
         if "GRBM_GUI_ACTIVE" in vals and adv:
             try:
                 avg_ns = float(adv[0][stats_rows[0].index("AverageNs")])
