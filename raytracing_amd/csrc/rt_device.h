@@ -275,10 +275,17 @@ template <typename T> struct Cell {
     T lwx[2], lwy[2], wx[4], wy[4];
 };
 
-// Both axes.  A lane takes the fast form on an axis when the UNCLAMPED quotient (v - a)/h lies in [5, q - 7): the point
-// is then at least five cells inside the grid (no clamp can apply) and cell j = floor(quotient) has equally spaced
-// knots around it.  Which FORMULA a lane uses depends on its own values only; the wave vote below merely picks a code
-// layout without exec-mask bookkeeping for the overwhelmingly common case that every lane is interior on both axes.
+// The rare layout of field_locate: some lane of the wave is near the grid's rim (or F.exact is set).  (Keeping it out
+// of line was tried: the Cell then lives in scratch memory and the step loop runs at half speed.)
+template <typename T>
+__device__ __forceinline__ void field_locate_mixed(const FieldDev<T>& F, T x, T y, bool fx, bool fy, Cell<T>& c) {
+    const T urx = (x - F.ax) * F.inv_hx, ury = (y - F.ay) * F.inv_hy;
+    if (fx) axis_fast(urx, floor_(urx), c.jx, c.lx, c.lwx, c.wx);
+    else axis_general(x, F.qx, F.ax, F.hx, F.bx, F.inv_hx, c.jx, c.lx, c.lwx, c.wx);
+    if (fy) axis_fast(ury, floor_(ury), c.jy, c.ly, c.lwy, c.wy);
+    else axis_general(y, F.qy, F.ay, F.hy, F.by, F.inv_hy, c.jy, c.ly, c.lwy, c.wy);
+}
+
 // Both axes.  A lane takes the fast form on an axis when the UNCLAMPED quotient (v - a)/h lies in [5, q - 7): the point
 // is then at least five cells inside the grid (no clamp can apply) and cell j = floor(quotient) has equally spaced
 // knots around it.  Which FORMULA a lane uses depends on its own values only; the wave vote below merely picks a code
@@ -291,10 +298,7 @@ template <typename T> __device__ __forceinline__ void field_locate(const FieldDe
         axis_fast(urx, floor_(urx), c.jx, c.lx, c.lwx, c.wx);
         axis_fast(ury, floor_(ury), c.jy, c.ly, c.lwy, c.wy);
     } else {
-        if (fx) axis_fast(urx, floor_(urx), c.jx, c.lx, c.lwx, c.wx);
-        else axis_general(x, F.qx, F.ax, F.hx, F.bx, F.inv_hx, c.jx, c.lx, c.lwx, c.wx);
-        if (fy) axis_fast(ury, floor_(ury), c.jy, c.ly, c.lwy, c.wy);
-        else axis_general(y, F.qy, F.ay, F.hy, F.by, F.inv_hy, c.jy, c.ly, c.lwy, c.wy);
+        field_locate_mixed(F, x, y, fx, fy, c);
     }
 }
 
@@ -356,6 +360,7 @@ template <typename T> struct GlobalGather {
         cc.jx = active ? c.jx : 0; cc.jy = active ? c.jy : 0; cc.lx = active ? c.lx : 3; cc.ly = active ? c.ly : 3;
         gather_global(F, cc, z, g);
     }
+    __device__ __forceinline__ void lookup(const FieldDev<T>& F, const Cell<T>& c, bool active, T& n, T& gx, T& gy);
 };
 
 __device__ __forceinline__ int wave_min_i(int v) {
@@ -419,8 +424,10 @@ template <typename T> struct LdsGather {
         }
     }
 
-    __device__ __forceinline__ void fetch(const FieldDev<T>& F, const Cell<T>& c, bool active, T z[4], Pair<T> g[4][4]) {
-        int cx = c.lx - 3 - ox, cy = c.ly - 3 - oy;
+    // Where this lane's window sits in the tile (cx, cy) and whether it does; re-stages the tile when a live lane's
+    // window has left it.  Must be reached in wave-uniform control flow (it votes and shuffles).
+    __device__ __forceinline__ bool place(const FieldDev<T>& F, const Cell<T>& c, bool active, int& cx, int& cy) {
+        cx = c.lx - 3 - ox; cy = c.ly - 3 - oy;
         // the bilinear 2x2 sits at window offset (+1,+1) when the cell is not at a not-a-knot end
         const bool regular = c.jx == c.lx - 2 && c.jy == c.ly - 2;
         // an idle lane counts as served (it reads tile corner (0,0); nobody uses what it computes)
@@ -448,6 +455,12 @@ template <typename T> struct LdsGather {
         }
         cx = (fits && active) ? cx : 0;
         cy = (fits && active) ? cy : 0;
+        return fits;
+    }
+
+    __device__ __forceinline__ void fetch(const FieldDev<T>& F, const Cell<T>& c, bool active, T z[4], Pair<T> g[4][4]) {
+        int cx, cy;
+        const bool fits = place(F, c, active, cx, cy);
         if (__ballot(!fits) == 0ull) {
             read_tile(cx, cy, z, g);              // the common case, wave-uniform: straight-line LDS reads
         } else if (fits) {
@@ -460,6 +473,24 @@ template <typename T> struct LdsGather {
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
         }
     }
+
+    // fetch + field_combine (consuming the window in two halves of two rows to shorten its register lifetime was tried:
+    // 200 instead of 208 VGPRs, same time).
+    __device__ __forceinline__ void lookup(const FieldDev<T>& F, const Cell<T>& c, bool active, T& n, T& gx, T& gy) {
+        int cx, cy;
+        const bool fits = place(F, c, active, cx, cy);
+        T z[4];
+        Pair<T> g[4][4];
+        if (__ballot(!fits) == 0ull) {
+            read_tile(cx, cy, z, g);
+        } else if (fits) {
+            read_tile(cx, cy, z, g);
+        } else {
+            gather_global(F, c, z, g);
+            __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), see fetch()
+        }
+        field_combine(c, z, g, n, gx, gy);
+    }
 };
 
 // n_gradient(vector, grd, z) (:141-156): bilinear n, bicubic dn/dx and dn/dy at (x, y) -> (n, [gx, gy]).
@@ -468,9 +499,13 @@ template <typename T, typename G>
 __device__ __forceinline__ void n_gradient(const FieldDev<T>& F, G& gather, bool active, T x, T y, T& n, T& gx, T& gy) {
     Cell<T> c;
     field_locate(F, x, y, c);
+    gather.lookup(F, c, active, n, gx, gy);
+}
+template <typename T>
+__device__ __forceinline__ void GlobalGather<T>::lookup(const FieldDev<T>& F, const Cell<T>& c, bool active, T& n, T& gx, T& gy) {
     T z[4];
     Pair<T> g[4][4];
-    gather.fetch(F, c, active, z, g);
+    fetch(F, c, active, z, g);
     field_combine(c, z, g, n, gx, gy);
 }
 
