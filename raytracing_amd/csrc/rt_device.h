@@ -152,6 +152,25 @@ template <typename T> struct FieldDev {
     int exact;   // 1: FITPACK's arithmetic with true knots in every cell (see axis_eval)
 };
 
+// Rare branches of the step loop (a lookup near the grid's rim, re-staging the LDS tile, a lane falling back to a global
+// gather) need field members the common path never touches (h, b, the array pointers).  Kept in scalar registers for the
+// whole loop they cost ~16 SGPRs, and the step loop is short of exactly those (it spills SGPRs to VGPR lanes and
+// rematerialises constants every iteration).  Every kernel that looks the field up has its FieldDev at offset 0 of the
+// kernel-argument segment (k_advance / k_trace_refill / k_init: BatchDev::F is the first member; k_field_eval: first
+// argument), so a rare branch can re-read it from there; the empty asm keeps the loads inside the branch.
+#ifndef RTMI_NO_KERNARG_FIELD
+template <typename T> __device__ __forceinline__ FieldDev<T> rare_field(const FieldDev<T>&) {
+    typedef const FieldDev<T> __attribute__((address_space(4))) * KP;
+    KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    FieldDev<T> out;
+    __builtin_memcpy(&out, p, sizeof(out));      // scalar loads from the constant address space
+    return out;                                   // scalar loads, live only inside the branch
+}
+#else
+template <typename T> __device__ __forceinline__ const FieldDev<T>& rare_field(const FieldDev<T>& F) { return F; }
+#endif
+
 template <typename T> __device__ __forceinline__ T axis_at(int i, int q, T a, T h, T b) {
     return i >= q - 1 ? b : M<T>::lin(i, h, a);
 }
@@ -298,7 +317,7 @@ template <typename T> __device__ __forceinline__ void field_locate(const FieldDe
         axis_fast(urx, floor_(urx), c.jx, c.lx, c.lwx, c.wx);
         axis_fast(ury, floor_(ury), c.jy, c.ly, c.lwy, c.wy);
     } else {
-        field_locate_mixed(F, x, y, fx, fy, c);
+        field_locate_mixed(rare_field(F), x, y, fx, fy, c);
     }
 }
 
@@ -426,13 +445,14 @@ template <typename T> struct LdsGather {
 
     // Where this lane's window sits in the tile (cx, cy) and whether it does; re-stages the tile when a live lane's
     // window has left it.  Must be reached in wave-uniform control flow (it votes and shuffles).
-    __device__ __forceinline__ bool place(const FieldDev<T>& F, const Cell<T>& c, bool active, int& cx, int& cy) {
+    __device__ __forceinline__ bool place(const FieldDev<T>& F_, const Cell<T>& c, bool active, int& cx, int& cy) {
         cx = c.lx - 3 - ox; cy = c.ly - 3 - oy;
         // the bilinear 2x2 sits at window offset (+1,+1) when the cell is not at a not-a-knot end
         const bool regular = c.jx == c.lx - 2 && c.jy == c.ly - 2;
         // an idle lane counts as served (it reads tile corner (0,0); nobody uses what it computes)
         bool fits = !active || (valid && regular && (unsigned)cx <= (unsigned)(TILE - 4) && (unsigned)cy <= (unsigned)(TILE - 4));
         if (__ballot(!fits) != 0ull) {
+            const FieldDev<T> F = rare_field(F_);
             if (cooldown == 0 && F.qx >= TILE && F.qy >= TILE) {
                 const int mnx = wave_min_i(active && regular ? c.lx - 3 : 0x7fffffff);
                 const int mxx = wave_max_i(active && regular ? c.lx : -0x7fffffff);
@@ -466,7 +486,7 @@ template <typename T> struct LdsGather {
         } else if (fits) {
             read_tile(cx, cy, z, g);
         } else {
-            gather_global(F, c, z, g);            // this lane's window is outside the tile (or at a grid end)
+            gather_global(rare_field(F), c, z, g);   // this lane's window is outside the tile (or at a grid end)
             // Retire these loads here.  Otherwise the compiler, which shares the ds_read block between this
             // mixed case and the all-lanes-fit case, guards the LDS reads with vmcnt waits -- and vmcnt also
             // counts the trajectory stores of the previous step, so every step would wait for HBM writes.
@@ -486,7 +506,7 @@ template <typename T> struct LdsGather {
         } else if (fits) {
             read_tile(cx, cy, z, g);
         } else {
-            gather_global(F, c, z, g);
+            gather_global(rare_field(F), c, z, g);
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), see fetch()
         }
         field_combine(c, z, g, n, gx, gy);

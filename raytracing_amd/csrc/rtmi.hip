@@ -534,6 +534,22 @@ template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::
 // has no dense row stores to queue the scratch reloads behind), the tile variant for two with no spills.
 // Every lane runs every iteration until no lane of its wave is active; a ray's state is stored the moment it
 // terminates (or when the launch's step budget ends), so idle lanes never write.
+// A ray's state is stored once, when it terminates: the batch members that needs (state slab, istep, alive) are re-read
+// from the kernel-argument segment there instead of occupying scalar registers for the whole loop (see rt::rare_field).
+#ifndef RTMI_NO_KERNARG_FIELD
+template <typename T> __device__ __forceinline__ BatchDev<T> rare_batch(const BatchDev<T>&) {
+    static_assert(__builtin_offsetof(BatchDev<T>, F) == 0, "rt::rare_field reads the FieldDev at offset 0 of the kernel arguments");
+    typedef const BatchDev<T> __attribute__((address_space(4))) * KP;
+    KP p = (KP)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    BatchDev<T> out;
+    __builtin_memcpy(&out, p, sizeof(out));      // scalar loads from the constant address space
+    return out;
+}
+#else
+template <typename T> __device__ __forceinline__ const BatchDev<T>& rare_batch(const BatchDev<T>& a) { return a; }
+#endif
+
 // ---- trajectory rows through a wave-uniform buffer descriptor
 // In k_advance every live lane of a wave is at the same row (they start together and step together), so a row's
 // address splits into a wave-uniform part -- row base + block offset, kept in SGPRs as a buffer descriptor -- a
@@ -621,7 +637,7 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
                 }
             }
             alive = inside && (i + 1 < max_size);
-            if (!alive) store_ray<T, METHOD>(a, k, r, i, false);
+            if (!alive) store_ray<T, METHOD>(rare_batch(a), k, r, i, false);
         }
     }
 }
