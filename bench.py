@@ -276,7 +276,7 @@ def main():
         hbm = {"achieved": hbm_bytes / ksec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                "frac": hbm_bytes / ksec / 1e9 / HBM_PEAK_GBS,
                "bytes_per_pass": hbm_bytes,
-               "bytes_source": prof.get("source") if measured else "model: recorded rows x 7 values + ray state in and out"}
+               "bytes_source": prof.get("source") if measured else "model: recorded rows x 6 values (7 with n_ray) + ray state in and out"}
         roof = dict(hbm, bound="hbm", traffic=measured, traffic_source=prof.get("source") if measured else None)
         # vector-ALU issue time from the profiled instruction counts: a 64-lane fp64 instruction holds a SIMD for 4 cycles
         # (16 lanes/clk), any other VALU instruction for 2 (SIMD-32); against 1024 SIMDs at the 2.4 GHz peak clock

@@ -370,6 +370,45 @@ __device__ __forceinline__ void field_combine(const Cell<T>& c, const T z[4], co
     gy = sy;
 }
 
+// gather_global + field_combine with the window consumed row by row (PHASES of 4/PHASES rows each): the same sums in the
+// same order as field_combine, hence the same bits, with 1/PHASES of the window in registers at a time.  PHASES = 4 is
+// the register-frugal form for the rare per-lane fallback of the tile kernel.
+template <typename T, int PHASES>
+__device__ __forceinline__ void lookup_global_rows(const FieldDev<T>& F, const Cell<T>& c, T& n, T& gx, T& gy) {
+    const T* zp = F.zn + (size_t)c.jy * F.qx + c.jx;
+    const T z0 = zp[0], z1 = zp[1], z2 = zp[F.qx], z3 = zp[F.qx + 1];
+    const Pair<T>* gp = reinterpret_cast<const Pair<T>*>(F.g) + ((size_t)(c.ly - 3) * F.qx + (c.lx - 3));
+    constexpr int ROWS = 4 / PHASES;
+    T sx = 0, sy = 0;
+#pragma unroll
+    for (int ph = 0; ph < PHASES; ph++) {
+        Pair<T> a[ROWS][4];
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) a[r][q] = gp[(size_t)(ph * ROWS + r) * F.qx + q];
+        }
+#pragma unroll
+        for (int r = 0; r < ROWS; r++) {
+            T rx = a[r][0].x * c.wx[0], ry = a[r][0].y * c.wx[0];
+#pragma unroll
+            for (int q = 1; q < 4; q++) {
+                rx = fma_(a[r][q].x, c.wx[q], rx);
+                ry = fma_(a[r][q].y, c.wx[q], ry);
+            }
+            const int rr = ph * ROWS + r;
+            sx = rr == 0 ? rx * c.wy[0] : fma_(rx, c.wy[rr], sx);
+            sy = rr == 0 ? ry * c.wy[0] : fma_(ry, c.wy[rr], sy);
+        }
+        if (PHASES > 1) asm volatile("" : "+v"(sx), "+v"(sy) : : "memory");   // the next rows' loads stay behind these sums
+    }
+    n = fma_(z3 * c.lwy[1], c.lwx[1], fma_(z2 * c.lwy[1], c.lwx[0], fma_(z1 * c.lwy[0], c.lwx[1], (z0 * c.lwy[0]) * c.lwx[0])));
+    gx = sx; gy = sy;
+}
+
+#ifndef RTMI_GLOBAL_PHASES
+#define RTMI_GLOBAL_PHASES 2
+#endif
 // Gather policy 1: every lookup reads its 36 coefficients from global memory (L1/L2-resident in practice).
 template <typename T> struct GlobalGather {
     __device__ __forceinline__ void fetch(const FieldDev<T>& F, const Cell<T>& c, bool active, T z[4], Pair<T> g[4][4]) {
@@ -499,17 +538,17 @@ template <typename T> struct LdsGather {
     __device__ __forceinline__ void lookup(const FieldDev<T>& F, const Cell<T>& c, bool active, T& n, T& gx, T& gy) {
         int cx, cy;
         const bool fits = place(F, c, active, cx, cy);
-        T z[4];
-        Pair<T> g[4][4];
-        if (__ballot(!fits) == 0ull) {
+        if (__ballot(!fits) == 0ull || fits) {   // every lane in the tile (the common, wave-uniform case), or this one is
+            T z[4];
+            Pair<T> g[4][4];
             read_tile(cx, cy, z, g);
-        } else if (fits) {
-            read_tile(cx, cy, z, g);
+            field_combine(c, z, g, n, gx, gy);
         } else {
-            gather_global(rare_field(F), c, z, g);
+            // this lane's window is outside the tile (or at a grid end): row by row from global memory, so that this rare
+            // branch does not set the kernel's register count (36 coefficients + 18 addresses in flight did)
+            lookup_global_rows<T, 4>(rare_field(F), c, n, gx, gy);
             __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), see fetch()
         }
-        field_combine(c, z, g, n, gx, gy);
     }
 };
 
@@ -523,10 +562,12 @@ __device__ __forceinline__ void n_gradient(const FieldDev<T>& F, G& gather, bool
 }
 template <typename T>
 __device__ __forceinline__ void GlobalGather<T>::lookup(const FieldDev<T>& F, const Cell<T>& c, bool active, T& n, T& gx, T& gy) {
-    T z[4];
-    Pair<T> g[4][4];
-    fetch(F, c, active, z, g);
-    field_combine(c, z, g, n, gx, gy);
+    // The window in two halves of two rows: 9 loads in flight instead of 18, and the kernel fits three waves per SIMD
+    // without spilling (143 instead of 168 VGPRs + 35 spilled).  A/B in one session: 15.0 vs 18.1 ms without recording,
+    // 24.0 vs 30.2 ms with the full record (four phases / four waves per SIMD: 15.2 / 24.1 ms).
+    Cell<T> cc = c;   // an idle lane reads the grid's first window instead of its stale cell (one shared cache line)
+    cc.jx = active ? c.jx : 0; cc.jy = active ? c.jy : 0; cc.lx = active ? c.lx : 3; cc.ly = active ? c.ly : 3;
+    lookup_global_rows<T, RTMI_GLOBAL_PHASES>(F, cc, n, gx, gy);
 }
 
 // ---------------------------------------------------------------- per-ray state

@@ -559,6 +559,9 @@ template <typename T> __device__ __forceinline__ const BatchDev<T>& rare_batch(c
 #ifndef RTMI_TILE_WAVES
 #define RTMI_TILE_WAVES 2      // waves per SIMD the LDS-tile variant of k_advance is built for
 #endif
+#ifndef RTMI_GLOBAL_WAVES
+#define RTMI_GLOBAL_WAVES 3    // waves per SIMD the fp64 global-gather builds are compiled for
+#endif
 #ifndef RTMI_GOLD_WAVES
 #define RTMI_GOLD_WAVES 3      // waves per SIMD the golden-section builds (op5/9/10/11, global gather) are compiled for
 #endif
@@ -650,7 +653,7 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
 // Every lane runs every iteration until no lane of its wave is active; a ray's state is stored the moment it
 // terminates (or when the launch's step budget ends), so idle lanes never write.
 template <typename T, int METHOD, bool ISO, bool LDS, bool VAR>
-__global__ __launch_bounds__(256, LDS ? RTMI_TILE_WAVES : (sizeof(T) == 4 ? 4 : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : 3)))
+__global__ __launch_bounds__(256, LDS ? RTMI_TILE_WAVES : (sizeof(T) == 4 ? 4 : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES)))
 void k_advance(BatchDev<T> a, int nsteps) {
     __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
     typename GatherOf<T, LDS>::type gather;
@@ -662,14 +665,14 @@ void k_advance(BatchDev<T> a, int nsteps) {
     // VAR: every ray carries its own DELTA_S and max_size (the calibration sweep as one candidate x ray batch)
     rt::Consts<T> K = a.K;
     int max_size = a.max_size;
-    if (VAR && k < a.R) { K.step = a.vstep[k]; K.step2h = a.vstep2h[k]; K.step2 = K.step2h * T(2); max_size = a.vmax[k]; }
+    if (VAR && a.vstep && k < a.R) { K.step = a.vstep[k]; K.step2h = a.vstep2h[k]; K.step2 = K.step2h * T(2); max_size = a.vmax[k]; }
     if (alive) load_ray<T, METHOD, ISO>(a, k, r, i);
     else idle_ray(a, r);
-    // The tile variant records rows through the wave-uniform descriptor path: the host launches it only while every live
-    // ray of the batch is at the same row (always, unless rtmi_batch_set_state gave rays rows of their own) and a row's
-    // six quantities lie within 32-bit byte offsets of each other (pick_advance); the global-gather variant keeps the
-    // per-lane row bookkeeping.
-    advance_loop<T, METHOD, ISO, decltype(gather), LDS>(a, K, gather, r, k, i, alive, max_size, nsteps);
+    // Rows are recorded through the wave-uniform descriptor path (UROW) by every build except the VAR one: the host
+    // launches a non-VAR build only while every live ray of the batch is at the same row (always, unless
+    // rtmi_batch_set_state gave rays rows of their own) and a row's six quantities lie within 31-bit byte offsets of each
+    // other (pick_advance); the VAR build keeps the per-lane row bookkeeping.
+    advance_loop<T, METHOD, ISO, decltype(gather), !VAR>(a, K, gather, r, k, i, alive, max_size, nsteps);
     if (alive) store_ray<T, METHOD>(a, k, r, i, true);
 }
 
@@ -855,16 +858,20 @@ template <typename T> static const void* refill_fn(int m, bool iso, bool lds) {
 // the vector-memory queue the stores occupy: 27.0 vs 29.0 ms at full record); without dense recording the plain
 // gather is ahead (18.9 vs 20.3 ms) because the kernel is VALU-bound and the tile costs ~25 integer instructions.
 static bool use_lds_tile(const rtmi_batch* b) {
-    // the tile kernel stores rows through a wave-uniform descriptor (write_row_uniform): rays must be in lockstep
-    // (no rtmi_batch_set_state since the last reset) and 6 quantities x R values must fit 31-bit byte offsets
-    if (b->p.record_stride != 0 && (b->dirty_state || (double)b->R * (double)b->esz * 6.0 >= 2147483647.0)) return false;
     if (b->p.field_path == 1) return false;
     if (b->p.field_path == 2) return true;
     return b->p.record_stride == 1 || b->p.record_stride == 2;
 }
+// rows can go out through the wave-uniform descriptor path: rays in lockstep (no rtmi_batch_set_state since the last
+// reset) and 6 quantities x R values within 31-bit byte offsets
+static bool uniform_rows_ok(const rtmi_batch* b) {
+    return b->p.record_stride == 0 || (!b->dirty_state && (double)b->R * (double)b->esz * 6.0 < 2147483647.0);
+}
 static const void* pick_advance(const rtmi_batch* b) {
     const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
-    if (b->vstep) return b->p.dtype == RTMI_F64 ? advance_var_fn<double>(b->p.method, iso) : advance_var_fn<float>(b->p.method, iso);
+    // the VAR build: per-ray DELTA_S / max_size when set, and per-lane row bookkeeping always
+    if (b->vstep || !uniform_rows_ok(b))
+        return b->p.dtype == RTMI_F64 ? advance_var_fn<double>(b->p.method, iso) : advance_var_fn<float>(b->p.method, iso);
     return b->p.dtype == RTMI_F64 ? advance_fn<double>(b->p.method, iso, lds) : advance_fn<float>(b->p.method, iso, lds);
 }
 static const void* pick_refill(const rtmi_batch* b) {
