@@ -406,6 +406,9 @@ __device__ __forceinline__ void lookup_global_rows(const FieldDev<T>& F, const C
     gx = sx; gy = sy;
 }
 
+#ifndef RTMI_TILE_PHASES
+#define RTMI_TILE_PHASES 2     // the 4x4 window is read from the LDS tile and summed in this many groups of rows
+#endif
 #ifndef RTMI_GLOBAL_PHASES
 #define RTMI_GLOBAL_PHASES 2
 #endif
@@ -533,16 +536,49 @@ template <typename T> struct LdsGather {
         }
     }
 
-    // fetch + field_combine (consuming the window in two halves of two rows to shorten its register lifetime was tried:
-    // 200 instead of 208 VGPRs, same time).
+    // fetch + field_combine.  With every lane in the tile the window is read and summed in RTMI_TILE_PHASES groups of rows
+    // (same sums in the same order as field_combine, so the same bits): 8 LDS reads in flight instead of 16, 146 instead of
+    // 182 VGPRs, i.e. three waves per SIMD without spilling (A/B in one session: 22.9 vs 24.8 ms with the full record).
     __device__ __forceinline__ void lookup(const FieldDev<T>& F, const Cell<T>& c, bool active, T& n, T& gx, T& gy) {
         int cx, cy;
         const bool fits = place(F, c, active, cx, cy);
         if (__ballot(!fits) == 0ull || fits) {   // every lane in the tile (the common, wave-uniform case), or this one is
+#if RTMI_TILE_PHASES > 1
+            const RT_LDS Pair<T>* gw = gt + cy * GPITCH + cx;
+            const RT_LDS T* zw = zt + (cy + 1) * ZPITCH + (cx + 1);
+            const T z0 = zw[0], z1 = zw[1], z2 = zw[ZPITCH], z3 = zw[ZPITCH + 1];
+            constexpr int ROWS = 4 / RTMI_TILE_PHASES;
+            T sx = 0, sy = 0;
+#pragma unroll
+            for (int ph = 0; ph < RTMI_TILE_PHASES; ph++) {
+                Pair<T> a[ROWS][4];
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) a[r][q] = gw[(ph * ROWS + r) * GPITCH + q];
+                }
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) {
+                    T rx = a[r][0].x * c.wx[0], ry = a[r][0].y * c.wx[0];
+#pragma unroll
+                    for (int q = 1; q < 4; q++) {
+                        rx = fma_(a[r][q].x, c.wx[q], rx);
+                        ry = fma_(a[r][q].y, c.wx[q], ry);
+                    }
+                    const int rr = ph * ROWS + r;
+                    sx = rr == 0 ? rx * c.wy[0] : fma_(rx, c.wy[rr], sx);
+                    sy = rr == 0 ? ry * c.wy[0] : fma_(ry, c.wy[rr], sy);
+                }
+                asm volatile("" : "+v"(sx), "+v"(sy) : : "memory");   // the next rows' reads stay behind these sums
+            }
+            n = fma_(z3 * c.lwy[1], c.lwx[1], fma_(z2 * c.lwy[1], c.lwx[0], fma_(z1 * c.lwy[0], c.lwx[1], (z0 * c.lwy[0]) * c.lwx[0])));
+            gx = sx; gy = sy;
+#else
             T z[4];
             Pair<T> g[4][4];
             read_tile(cx, cy, z, g);
             field_combine(c, z, g, n, gx, gy);
+#endif
         } else {
             // this lane's window is outside the tile (or at a grid end): row by row from global memory, so that this rare
             // branch does not set the kernel's register count (36 coefficients + 18 addresses in flight did)

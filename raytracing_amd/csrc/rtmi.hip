@@ -557,7 +557,7 @@ template <typename T> __device__ __forceinline__ const BatchDev<T>& rare_batch(c
 // 64-bit address arithmetic of write_row (seven v_mad_u64_u32 / v_lshl_add_u64 chains per step) and frees their
 // registers.  RTMI_ROW_STORE_AUX sets the stores' cache policy (0 plain, 2 nt, 16 sc1, 18 sc1 nt).
 #ifndef RTMI_TILE_WAVES
-#define RTMI_TILE_WAVES 2      // waves per SIMD the LDS-tile variant of k_advance is built for
+#define RTMI_TILE_WAVES 3      // waves per SIMD the LDS-tile variant of k_advance is built for
 #endif
 #ifndef RTMI_GLOBAL_WAVES
 #define RTMI_GLOBAL_WAVES 3    // waves per SIMD the fp64 global-gather builds are compiled for
