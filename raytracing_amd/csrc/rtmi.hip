@@ -575,10 +575,21 @@ __device__ __forceinline__ void row_store(__amdgpu_buffer_rsrc_t rs, int voff, i
 __device__ __forceinline__ void row_store(__amdgpu_buffer_rsrc_t rs, int voff, int soff, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, voff, soff, RTMI_ROW_STORE_AUX);
 }
+// A pointer every lane of the wave holds the same value of, pinned to scalar registers.  The compiler keeps the row
+// pointers of advance_loop in VGPRs (their loop-carried updates get moved to the VALU) and would otherwise wrap every
+// buffer store in a readfirstlane/compare waterfall loop: 6 VALU + 5 SALU instructions per store for one iteration.
+template <typename T>
+__device__ __forceinline__ T* wave_uniform_ptr(T* p) {
+    const unsigned long v = (unsigned long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (T*)(((unsigned long)hi << 32) | lo);
+}
 // rowp / nrowp: this block's slice of the current row of s_ray / n_ray (wave-uniform pointers the loop advances)
 template <typename T>
 __device__ __forceinline__ void write_row_uniform(const BatchDev<T>& a, T* rowp, T* nrowp, int voff, const rt::Ray<T>& r) {
     const int qR = (int)(a.R * (long)sizeof(T));                        // byte distance between quantities (< 2^31 / 6: pick_advance)
+    rowp = wave_uniform_ptr(rowp);
+    nrowp = wave_uniform_ptr(nrowp);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rowp, 0, 0x7fffffff, 0x00020000);
     row_store(rs, voff, 0, (T)r.x);
     row_store(rs, voff, qR, (T)r.y);
