@@ -407,7 +407,7 @@ __device__ __forceinline__ void lookup_global_rows(const FieldDev<T>& F, const C
 }
 
 #ifndef RTMI_TILE_PHASES
-#define RTMI_TILE_PHASES 2     // the 4x4 window is read from the LDS tile and summed in this many groups of rows
+#define RTMI_TILE_PHASES 4     // the 4x4 window is read from the LDS tile and summed in this many groups of rows
 #endif
 #ifndef RTMI_GLOBAL_PHASES
 #define RTMI_GLOBAL_PHASES 2

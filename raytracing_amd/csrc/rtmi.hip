@@ -530,8 +530,6 @@ template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::
 // The loop at :866-879: one lane per ray, state in registers for up to nsteps DELTA_S steps.
 // ISO (gamma == 1) drops the anisotropic factor's dead arithmetic; LDS selects the wave-private field tile
 // (rt::LdsGather) over per-lookup global gathers.  Results are bit-identical across all four variants.
-// The global-gather variant is built for three waves per SIMD (26 VGPRs spill; still 8 % faster when the loop
-// has no dense row stores to queue the scratch reloads behind), the tile variant for two with no spills.
 // Every lane runs every iteration until no lane of its wave is active; a ray's state is stored the moment it
 // terminates (or when the launch's step budget ends), so idle lanes never write.
 // A ray's state is stored once, when it terminates: the batch members that needs (state slab, istep, alive) are re-read
@@ -557,8 +555,12 @@ template <typename T> __device__ __forceinline__ const BatchDev<T>& rare_batch(c
 // 64-bit address arithmetic of write_row (seven v_mad_u64_u32 / v_lshl_add_u64 chains per step) and frees their
 // registers.  RTMI_ROW_STORE_AUX sets the stores' cache policy (0 plain, 2 nt, 16 sc1, 18 sc1 nt).
 #ifndef RTMI_TILE_WAVES
-#define RTMI_TILE_WAVES 3      // waves per SIMD the LDS-tile variant of k_advance is built for
+#define RTMI_TILE_WAVES 4      // waves per SIMD the LDS-tile variant of k_advance is built for (the light methods)
 #endif
+// op2 and op6 (one field lookup per step, no golden section, no curvature terms) fit one more wave per SIMD than the rest
+constexpr bool light_method(int m) { return m == 2 || m == 6; }
+// op4 and the golden-section methods carry the most state: their tile builds keep two waves per SIMD
+constexpr bool heavy_method(int m) { return m == 4 || m == 5 || m >= 9; }
 #ifndef RTMI_GLOBAL_WAVES
 #define RTMI_GLOBAL_WAVES 3    // waves per SIMD the fp64 global-gather builds are compiled for
 #endif
@@ -659,12 +661,12 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
 // The loop at :866-879: one lane per ray, state in registers for up to nsteps DELTA_S steps.
 // ISO (gamma == 1) drops the anisotropic factor's dead arithmetic; LDS selects the wave-private field tile
 // (rt::LdsGather) over per-lookup global gathers.  Results are bit-identical across all four variants.
-// The global-gather variant is built for three waves per SIMD (26 VGPRs spill; still 8 % faster when the loop
-// has no dense row stores to queue the scratch reloads behind), the tile variant for two with no spills.
+// Register budgets (RTMI_*_WAVES): the fp64 tile variant fits four waves per SIMD (128 VGPRs, the window read and summed
+// row by row), the fp64 global-gather variants three (137-168 VGPRs, gathers in two halves); none of them spills.
 // Every lane runs every iteration until no lane of its wave is active; a ray's state is stored the moment it
 // terminates (or when the launch's step budget ends), so idle lanes never write.
 template <typename T, int METHOD, bool ISO, bool LDS, bool VAR>
-__global__ __launch_bounds__(256, LDS ? RTMI_TILE_WAVES : (sizeof(T) == 4 ? 4 : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES)))
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : LDS ? (light_method(METHOD) ? RTMI_TILE_WAVES : heavy_method(METHOD) ? 2 : 3) : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES))
 void k_advance(BatchDev<T> a, int nsteps) {
     __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
     typename GatherOf<T, LDS>::type gather;
@@ -683,6 +685,10 @@ void k_advance(BatchDev<T> a, int nsteps) {
     // launches a non-VAR build only while every live ray of the batch is at the same row (always, unless
     // rtmi_batch_set_state gave rays rows of their own) and a row's six quantities lie within 31-bit byte offsets of each
     // other (pick_advance); the VAR build keeps the per-lane row bookkeeping.
+    // Drain the state loads here: a load still pending at the loop header stays "pending" in the compiler's wait-count
+    // model around the back edge, and every first use in the loop then waits for vmcnt(0), i.e. for the previous
+    // step's row stores to be acknowledged.
+    __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), expcnt and lgkmcnt untouched
     advance_loop<T, METHOD, ISO, decltype(gather), !VAR>(a, K, gather, r, k, i, alive, max_size, nsteps);
     if (alive) store_ray<T, METHOD>(a, k, r, i, true);
 }
@@ -694,8 +700,11 @@ void k_advance(BatchDev<T> a, int nsteps) {
 // never depends on its lane or wave mates, so results are bit-identical to k_advance.
 // Exit: the queue is exhausted and no lane is live -- reached by every wave because each ray takes at most
 // max_size steps and the queue only advances.
+#ifndef RTMI_REFILL_WAVES
+#define RTMI_REFILL_WAVES 3
+#endif
 template <typename T, int METHOD, bool ISO, bool LDS>
-__global__ __launch_bounds__(256, 2) void k_trace_refill(BatchDev<T> a, int refill_min, int chunk) {
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : light_method(METHOD) ? RTMI_REFILL_WAVES : 2) void k_trace_refill(BatchDev<T> a, int refill_min, int chunk) {
     __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
     typename GatherOf<T, LDS>::type gather;
     gather_init<T, LDS>(gather, lds);
@@ -729,6 +738,7 @@ __global__ __launch_bounds__(256, 2) void k_trace_refill(BatchDev<T> a, int refi
             }
             exhausted = base + (unsigned long long)n_dead >= (unsigned long long)a.R;
             live_mask = __ballot(alive);
+            __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): no state load pending into the step loop (see k_advance)
         }
         if (live_mask == 0) {
             if (exhausted) break;
