@@ -133,6 +133,17 @@ template <typename T> __device__ __forceinline__ void sincos_add(double theta, T
         M<T>::sincos_(theta + (double)k, so, co);
     }
 }
+// sin/cos of `target` == (angle of (s, c)) + k: by rotation when k is small and no refresh is due, else from scratch
+template <typename T> __device__ __forceinline__ void sincos_add(double target, T s, T c, T k, T* so, T* co, bool refresh) {
+    const bool small = M<T>::abs_(k) < M<T>::small_angle && !refresh;
+    if (__ballot(!small) == 0ull) {
+        sincos_add_small(s, c, k, so, co);
+    } else if (small) {
+        sincos_add_small(s, c, k, so, co);
+    } else {
+        M<T>::sincos_(target, so, co);
+    }
+}
 
 constexpr double kGoldRatio = 0.6180339887498949;   // (sqrt(5)-1)/2, RT_bench.py:65
 constexpr double kHalfPi = 1.5707963267948966;      // DELTA_G, RT_bench.py:64
@@ -779,15 +790,16 @@ __device__ __forceinline__ Acc op_angle(const Consts<T>& k, const Ray<T>& r, boo
 }
 
 // store_update_results (:783-790) + the row bookkeeping of the loop body (:871-875)
-template <typename T, bool ISO>
+template <typename T, bool ISO, bool ROT = false>
 __device__ __forceinline__ void store_update(const Consts<T>& k, Ray<T>& r, Acc fx, Acc fy, Acc fth, T fn, T fgx, T fgy,
-                                             T frn) {
+                                             T frn, bool refresh = false) {
     const T dx = (T)(r.x - fx), dy = (T)(r.y - fy);
     const T dist = M<T>::sqrt_(fma_(dy, dy, dx * dx));  // np.linalg.norm on 2 elements
     r.dsim += (Acc)dist;
     r.dreal += (Acc)k.step;  // quirk Q16: accumulated, not i*step
     T s, c;
-    M<T>::sincos_(fth, &s, &c);
+    if constexpr (ROT) sincos_add<T>(fth, r.uy, r.ux, (T)(fth - r.th), &s, &c, refresh);
+    else M<T>::sincos_(fth, &s, &c);
     const T coef = aniso<T, ISO>(s, c, k.gamma);
     r.mx = moment<T, ISO>(fn, coef, k.g2m1, c, -(s * s));
     r.my = moment<T, ISO>(fn, coef, k.g2m1, s, c * c);
@@ -800,8 +812,8 @@ __device__ __forceinline__ void store_update(const Consts<T>& k, Ray<T>& r, Acc 
 }
 
 // derived quantities from the stored state (used when a launch (re)loads a ray from HBM)
-template <typename T, bool ISO> __device__ __forceinline__ void derive(const Consts<T>& k, Ray<T>& r) {
-    M<T>::sincos_(r.th, &r.uy, &r.ux);
+template <typename T, bool ISO, bool HAVE_UNIT = false> __device__ __forceinline__ void derive(const Consts<T>& k, Ray<T>& r) {
+    if constexpr (!HAVE_UNIT) M<T>::sincos_(r.th, &r.uy, &r.ux);      // HAVE_UNIT: (ux, uy) came with the state (RotatesUnit)
     r.coef = aniso<T, ISO>(r.uy, r.ux, k.gamma);
     r.nray = ISO ? r.n : r.coef * r.n;
     r.rn = rcp_full(r.n);
@@ -824,6 +836,21 @@ template <int METHOD> struct IsExact<double, METHOD> {
     static constexpr bool value = METHOD == 3 || METHOD == 4 || METHOD == 5 || METHOD == 9 || METHOD == 10 || METHOD == 11;
 };
 inline bool is_exact_method(int method) { return method == 3 || method == 4 || method == 5 || method >= 9; }
+
+// op2/op6 in fp64 turn by less than 2^-5 rad per step almost everywhere, so the unit vector (cos, sin) of the new angle is
+// the old one rotated by the angle's increment (a 7th-order series, 14 fp64 instructions) instead of a from-scratch
+// sincos with range reduction and quadrant selection (37); every kUnitRefresh-th row of a ray (by its own row index, so
+// the result does not depend on lanes, waves or launch boundaries) and every larger turn recompute it from the angle.
+// The unit vector is then part of a ray's state: it is stored with it (BatchDev::unit) and reloaded, never re-derived,
+// so a trajectory is the same whether it runs in one launch or row by row.  Measured against the from-scratch build over
+// 65 536-ray fans: 7e-14 (vert_heterogeneous), 1.4e-12 (fisheye), 4e-11 (interface, where a ray's position error is
+// amplified ~1e5 times by the sharp index change) in the final state -- the size of either build's distance from the
+// reference.  1024 rather than a shorter period: with lane refill the lanes of a wave are at rows of their own, and a
+// wave takes the slow two-formula layout whenever any of its 64 lanes refreshes (6 % of its steps at 1024, 22 % at 256).
+constexpr int kUnitRefresh = 1024;
+template <typename T, int METHOD> struct RotatesUnit { static constexpr bool value = false; };
+template <int METHOD> struct RotatesUnit<double, METHOD> { static constexpr bool value = METHOD == 2 || METHOD == 6; };
+inline bool rotates_unit(int method) { return method == 2 || method == 6; }
 
 // One iteration of trazar's loop for row index i (the row being produced); returns "still inside the box".
 // For op7 rows 1 and 2 are the bootstrap steps (:833-864): first- and second-order backward differences and
@@ -849,7 +876,10 @@ __device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& 
     } else {
         fth = op_angle<T, METHOD>(k, r, flag, fx, fy, fn, fgx, fgy, frn);
     }
-    store_update<T, ISO>(k, r, fx, fy, fth, fn, fgx, fgy, frn);
+    if constexpr (RotatesUnit<T, METHOD>::value)
+        store_update<T, ISO, true>(k, r, fx, fy, fth, fn, fgx, fgy, frn, (i & (kUnitRefresh - 1)) == 0);
+    else
+        store_update<T, ISO>(k, r, fx, fy, fth, fn, fgx, fgy, frn);
     return boot || !outside(k, r);
     }
 }

@@ -418,8 +418,10 @@ template <typename T> struct BatchDev {
     int has_hist;     // op7 only: hx0, hy0, hx1, hy1 follow n, gx, gy
     int exact;        // fp64 op3/4/5/9/10/11: derived values and lookups in the reference's operation order (rt_exact.h)
     int iso;          // the step kernels run their ISO build (gamma == 1, method < 10, not exact): coef taken as exactly 1
+    int rot;          // fp64 op2/op6 (rt::RotatesUnit): the unit vector (cos, sin) is state, kept in unit(0), unit(1)
     __device__ __forceinline__ double* acc(int q) const { return st + (size_t)q * R; }                 // 0..5: x y th dsim dreal tt
     __device__ __forceinline__ T* aux(int q) const { return reinterpret_cast<T*>(st + (size_t)6 * R) + (size_t)q * R; }   // 0..2: n gx gy; 3..6: history
+    __device__ __forceinline__ T* unit(int q) const { return aux(3 + q); }     // rot batches have no history arrays
     int* istep;
     unsigned char* alive;
     T *s_ray, *n_ray;
@@ -466,6 +468,7 @@ template <typename T> __global__ void k_init(BatchDev<T> a) {
     a.acc(0)[k] = r.x; a.acc(1)[k] = r.y; a.acc(2)[k] = r.th; a.aux(0)[k] = r.n; a.aux(1)[k] = r.gx; a.aux(2)[k] = r.gy;
     a.acc(3)[k] = 0; a.acc(4)[k] = 0; a.acc(5)[k] = 0;
     if (a.has_hist) { a.aux(3)[k] = 0; a.aux(4)[k] = 0; a.aux(5)[k] = 0; a.aux(6)[k] = 0; }
+    if (a.rot) { a.unit(0)[k] = r.ux; a.unit(1)[k] = r.uy; }
     a.istep[k] = 0;
     a.alive[k] = max_size_of(a, k) > 1;
     if (a.stride && a.rec_rows > 0) write_row(a, 0, k, r);
@@ -500,7 +503,9 @@ __device__ __forceinline__ void load_ray(const BatchDev<T>& a, long k, rt::Ray<T
     r.dsim = a.acc(3)[k]; r.dreal = a.acc(4)[k]; r.tt = a.acc(5)[k];
     if (METHOD == 7) { r.hx0 = a.aux(3)[k]; r.hy0 = a.aux(4)[k]; r.hx1 = a.aux(5)[k]; r.hy1 = a.aux(6)[k]; }
     else { r.hx0 = r.hy0 = r.hx1 = r.hy1 = 0; }
-    if constexpr (rt::IsExact<T, METHOD>::value) rt::ex::derive(a.K, r); else rt::derive<T, ISO>(a.K, r);
+    if constexpr (rt::IsExact<T, METHOD>::value) rt::ex::derive(a.K, r);
+    else if constexpr (rt::RotatesUnit<T, METHOD>::value) { r.ux = a.unit(0)[k]; r.uy = a.unit(1)[k]; rt::derive<T, ISO, true>(a.K, r); }
+    else rt::derive<T, ISO>(a.K, r);
     i = a.istep[k];
 }
 template <typename T, int METHOD>
@@ -508,6 +513,7 @@ __device__ __forceinline__ void store_ray(const BatchDev<T>& a, long k, const rt
     a.acc(0)[k] = r.x; a.acc(1)[k] = r.y; a.acc(2)[k] = r.th; a.aux(0)[k] = r.n; a.aux(1)[k] = r.gx; a.aux(2)[k] = r.gy;
     a.acc(3)[k] = r.dsim; a.acc(4)[k] = r.dreal; a.acc(5)[k] = r.tt;
     if (METHOD == 7) { a.aux(3)[k] = r.hx0; a.aux(4)[k] = r.hy0; a.aux(5)[k] = r.hx1; a.aux(6)[k] = r.hy1; }
+    if constexpr (rt::RotatesUnit<T, METHOD>::value) { a.unit(0)[k] = r.ux; a.unit(1)[k] = r.uy; }
     a.istep[k] = i;
     a.alive[k] = alive;
 }
@@ -835,6 +841,7 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     a.st = (double*)b->state; a.has_hist = p.method == 7;
     a.exact = p.dtype == RTMI_F64 && rt::is_exact_method(p.method);
     a.iso = p.gamma == 1.0 && p.method < 10 && !a.exact;
+    a.rot = p.dtype == RTMI_F64 && rt::rotates_unit(p.method);
     a.istep = b->istep; a.alive = b->alive;
     a.s_ray = (T*)b->s_ray; a.n_ray = (T*)b->n_ray;
     a.counters = b->counters;
@@ -881,6 +888,9 @@ template <typename T> static const void* refill_fn(int m, bool iso, bool lds) {
 static bool use_lds_tile(const rtmi_batch* b) {
     if (b->p.field_path == 1) return false;
     if (b->p.field_path == 2) return true;
+    // the tile pays where row stores would queue ahead of the gathers of a light step; the reference-order fp64 methods
+    // (op3/4/5/9/10/11: 2-74 cost evaluations per step, more live state) measure 2-15 % faster on global gathers
+    if (b->p.dtype == RTMI_F64 && rt::is_exact_method(b->p.method)) return false;
     return b->p.record_stride == 1 || b->p.record_stride == 2;
 }
 // rows can go out through the wave-uniform descriptor path: rays in lockstep (no rtmi_batch_set_state since the last
@@ -961,7 +971,7 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     int rc = RTMI_OK;
     auto body = [&]() -> int {
         const size_t Rz = (size_t)R;
-        const int naux = p->method == 7 ? 7 : 3;
+        const int naux = p->method == 7 ? 7 : (p->dtype == RTMI_F64 && rt::rotates_unit(p->method)) ? 5 : 3;   // n gx gy + history | unit vector
         HIP_TRY(hipMalloc(&b->state, 6 * Rz * sizeof(double) + naux * Rz * b->esz));
         HIP_TRY(hipMalloc(&b->istep, Rz * sizeof(int)));
         HIP_TRY(hipMalloc(&b->alive, Rz));
@@ -1111,6 +1121,11 @@ template <typename T> __global__ void k_set_state(BatchDev<T> a, const double* s
     for (int q = 0; q < 3; q++) a.acc(3 + q)[k] = st[(size_t)(6 + q) * a.R + o];
     if (a.has_hist && hist)
         for (int q = 0; q < 4; q++) a.aux(3 + q)[k] = (T)hist[(size_t)q * a.R + o];
+    if (a.rot) {                                  // a state given from outside starts from its angle's own sin/cos
+        T sn, cs;
+        rt::M<T>::sincos_(a.acc(2)[k], &sn, &cs);
+        a.unit(0)[k] = cs; a.unit(1)[k] = sn;
+    }
     if (istep) a.istep[k] = istep[o];
     a.alive[k] = a.istep[k] + 1 < max_size_of(a, k);
 }
