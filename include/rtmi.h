@@ -88,8 +88,8 @@ typedef struct {
     int32_t refill_min;      /* launch_mode 1: compact when this many lanes of a wave are idle (0 -> 32) */
     int32_t exact_basis;     /* 0: uniform-knot cubic basis in interior cells (<= 4e-14 from FITPACK's weights);
                                 1: FITPACK's fpbspl arithmetic on the true knots in every cell (slower) */
-    int32_t field_path;      /* where lookups read the field: 0 auto (LDS tile when rows are recorded every step or two,
-                                else global), 1 global memory (L1/L2), 2 wave-private LDS tile; identical results */
+    int32_t field_path;      /* where lookups read the field: 0 auto (wave-private LDS tile, except global memory for fp64
+                                op3/4/5/9/10/11), 1 global memory (L1/L2), 2 wave-private LDS tile; identical results */
     int32_t sort_rays;       /* 1: reorder rays inside the batch by launch cell block and angle so that lanes of a wave stay
                                 coherent; every read call still answers in the caller's ray order (see rtmi_device_view.perm) */
     /* optional caller-owned DEVICE buffers (e.g. torch tensors); NULL -> the library allocates */

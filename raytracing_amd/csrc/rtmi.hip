@@ -888,10 +888,11 @@ template <typename T> static const void* refill_fn(int m, bool iso, bool lds) {
 static bool use_lds_tile(const rtmi_batch* b) {
     if (b->p.field_path == 1) return false;
     if (b->p.field_path == 2) return true;
-    // the tile pays where row stores would queue ahead of the gathers of a light step; the reference-order fp64 methods
-    // (op3/4/5/9/10/11: 2-74 cost evaluations per step, more live state) measure 2-15 % faster on global gathers
-    if (b->p.dtype == RTMI_F64 && rt::is_exact_method(b->p.method)) return false;
-    return b->p.record_stride == 1 || b->p.record_stride == 2;
+    // Measured: the tile build wins for the fast-form methods in every record mode -- op2/op6 at four waves
+    // per SIMD 12.5 vs 15.0 ms without recording and 19 vs 24 ms with the full record, op1/7/8 and fp32 by 0-2 %, a
+    // shuffled fan 44 vs 50 ms; the reference-order fp64 methods (op3/4/5/9/10/11: 2-74 cost evaluations per step, more
+    // live state) are 2-15 % faster on global gathers.
+    return !(b->p.dtype == RTMI_F64 && rt::is_exact_method(b->p.method));
 }
 // rows can go out through the wave-uniform descriptor path: rays in lockstep (no rtmi_batch_set_state since the last
 // reset) and 6 quantities x R values within 31-bit byte offsets

@@ -53,7 +53,7 @@ def main():
                  f"# workload: {cfg['workload']}",
                  f"# bench (same box, un-profiled): value {bench['value']:.4e} ray-steps/s, {bench['ms_per_step']:.3f} ms per pass, "
                  f"advance kernel {roof['kernel_ms_per_pass']:.3f} ms per pass by HIP events ({roof['launches_per_pass']} launch(es))",
-                 f"# kernel: {meta.get('kernel')}  VGPR {meta.get('vgpr')}  SGPR {meta.get('sgpr')}  LDS {meta.get('lds')} B/block  "
+                 f"# kernel: {meta.get('kernel')}  VGPR {roof.get('vgprs')} (code object; rocprofv3 VGPR_Count column: {meta.get('vgpr')})  SGPR {meta.get('sgpr')}  LDS {meta.get('lds')} B/block  "
                  f"scratch {meta.get('scratch')} B/lane  grid {meta.get('grid')} x wg {meta.get('wg')}"]
         if adv:
             hdr = stats_rows[0]
