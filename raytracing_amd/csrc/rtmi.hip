@@ -573,6 +573,9 @@ constexpr bool heavy_method(int m) { return m == 4 || m == 5 || m >= 9; }
 #ifndef RTMI_GOLD_WAVES
 #define RTMI_GOLD_WAVES 3      // waves per SIMD the golden-section builds (op5/9/10/11, global gather) are compiled for
 #endif
+#ifndef RTMI_STEP_PAIRS
+#define RTMI_STEP_PAIRS 2      // 1: op2/op6 fp64, 2: every fast-form build -- two steps per loop iteration (see advance_loop)
+#endif
 #ifndef RTMI_ROW_STORE_AUX
 #define RTMI_ROW_STORE_AUX 2   // nt: rows are written once and never read by the kernel (measured 3-5 % over plain stores)
 #endif
@@ -637,8 +640,9 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
         until = a.stride - (i % a.stride);   // steps until the next recorded row
         row = i / a.stride;
     }
-    for (int it = 0; it < nsteps; ++it) {
-        if (__ballot(alive) == 0ull) break;
+    // one DELTA_S step of every lane; false once no lane of the wave is live
+    auto one_step = [&]() -> bool {
+        if (__ballot(alive) == 0ull) return false;
         const bool active = alive;
         ++i;
         const bool inside = rt::ray_step<T, METHOD, ISO>(a.F, K, gather, active, r, i);
@@ -661,6 +665,19 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
             alive = inside && (i + 1 < max_size);
             if (!alive) store_ray<T, METHOD>(rare_batch(a), k, r, i, false);
         }
+        return true;
+    };
+    if constexpr (RTMI_STEP_PAIRS == 2 ? !rt::IsExact<T, METHOD>::value : (RTMI_STEP_PAIRS && light_method(METHOD) && sizeof(T) == 8)) {
+        // Two steps per loop iteration: the second step's results land in the registers the first step's inputs left, so
+        // the ~15 register copies that rotate the new state into the loop-carried registers every step disappear.
+        for (int it = 0; it < nsteps; it += 2) {
+            if (!one_step()) break;
+            if (it + 1 >= nsteps) break;
+            if (!one_step()) break;
+        }
+    } else {
+        for (int it = 0; it < nsteps; ++it)
+            if (!one_step()) break;
     }
 }
 
