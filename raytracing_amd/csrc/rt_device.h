@@ -848,9 +848,20 @@ inline bool is_exact_method(int method) { return method == 3 || method == 4 || m
 // reference.  1024 rather than a shorter period: with lane refill the lanes of a wave are at rows of their own, and a
 // wave takes the slow two-formula layout whenever any of its 64 lanes refreshes (6 % of its steps at 1024, 22 % at 256).
 constexpr int kUnitRefresh = 1024;
-template <typename T, int METHOD> struct RotatesUnit { static constexpr bool value = false; };
-template <int METHOD> struct RotatesUnit<double, METHOD> { static constexpr bool value = METHOD == 2 || METHOD == 6; };
-inline bool rotates_unit(int method) { return method == 2 || method == 6; }
+#ifndef RTMI_UNIT_REFRESH_F32
+// fp32 batches keep the from-scratch sincos: rotating in fp32 with a refresh every 16 rows gains 6 % on cfg4 but moves end
+// points from 3.9e-7 to 1.5e-6 of the fp64 path (every 64 rows: 6e-6) -- measured on 65 536-ray fans, not adopted.
+#define RTMI_UNIT_REFRESH_F32 0     // > 0: fp32 op2/op6 rotate the unit vector too, recomputing it every this many rows
+#endif
+template <typename T, int METHOD> struct RotatesUnit {
+    static constexpr bool value = (RTMI_UNIT_REFRESH_F32 > 0) && (METHOD == 2 || METHOD == 6);
+    static constexpr int refresh = RTMI_UNIT_REFRESH_F32 > 0 ? RTMI_UNIT_REFRESH_F32 : 1;
+};
+template <int METHOD> struct RotatesUnit<double, METHOD> {
+    static constexpr bool value = METHOD == 2 || METHOD == 6;
+    static constexpr int refresh = kUnitRefresh;
+};
+inline bool rotates_unit(int method, bool f64) { return (f64 || RTMI_UNIT_REFRESH_F32 > 0) && (method == 2 || method == 6); }
 
 // One iteration of trazar's loop for row index i (the row being produced); returns "still inside the box".
 // For op7 rows 1 and 2 are the bootstrap steps (:833-864): first- and second-order backward differences and
@@ -877,7 +888,7 @@ __device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& 
         fth = op_angle<T, METHOD>(k, r, flag, fx, fy, fn, fgx, fgy, frn);
     }
     if constexpr (RotatesUnit<T, METHOD>::value)
-        store_update<T, ISO, true>(k, r, fx, fy, fth, fn, fgx, fgy, frn, (i & (kUnitRefresh - 1)) == 0);
+        store_update<T, ISO, true>(k, r, fx, fy, fth, fn, fgx, fgy, frn, (i & (RotatesUnit<T, METHOD>::refresh - 1)) == 0);
     else
         store_update<T, ISO>(k, r, fx, fy, fth, fn, fgx, fgy, frn);
     return boot || !outside(k, r);

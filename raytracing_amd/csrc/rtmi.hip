@@ -858,7 +858,7 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     a.st = (double*)b->state; a.has_hist = p.method == 7;
     a.exact = p.dtype == RTMI_F64 && rt::is_exact_method(p.method);
     a.iso = p.gamma == 1.0 && p.method < 10 && !a.exact;
-    a.rot = p.dtype == RTMI_F64 && rt::rotates_unit(p.method);
+    a.rot = rt::rotates_unit(p.method, p.dtype == RTMI_F64);
     a.istep = b->istep; a.alive = b->alive;
     a.s_ray = (T*)b->s_ray; a.n_ray = (T*)b->n_ray;
     a.counters = b->counters;
@@ -989,7 +989,7 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     int rc = RTMI_OK;
     auto body = [&]() -> int {
         const size_t Rz = (size_t)R;
-        const int naux = p->method == 7 ? 7 : (p->dtype == RTMI_F64 && rt::rotates_unit(p->method)) ? 5 : 3;   // n gx gy + history | unit vector
+        const int naux = p->method == 7 ? 7 : rt::rotates_unit(p->method, p->dtype == RTMI_F64) ? 5 : 3;   // n gx gy + history | unit vector
         HIP_TRY(hipMalloc(&b->state, 6 * Rz * sizeof(double) + naux * Rz * b->esz));
         HIP_TRY(hipMalloc(&b->istep, Rz * sizeof(int)));
         HIP_TRY(hipMalloc(&b->alive, Rz));

@@ -240,6 +240,24 @@ def test_one_step_launches_equal_single_launch(rb, gpu_fields):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_launch_cuts_across_unit_vector_refresh(dtype, rb, gpu_fields):
+    """op2/op6 carry the unit tangent as state and rotate it (recomputed from the angle every 1024th row of a ray, fp64):
+    a trajectory must not depend on where launches cut it, including right at and around the refresh rows."""
+    F = gpu_fields("vert_heterogeneous", rb.F64 if dtype == "f64" else rb.F32)
+    th = np.linspace(np.pi / 4 - 0.02, np.pi / 4 + 0.02, 192)           # rays that stay inside past the second refresh row
+    kw = dict(record_stride=1)
+    a = rb.Batch(F, 6, rb.DELTA_S, 2200, LIMITS["vert_heterogeneous"], 1, th, -2.0, -2.0, **kw)
+    a.run()
+    b = rb.Batch(F, 6, rb.DELTA_S, 2200, LIMITS["vert_heterogeneous"], 1, th, -2.0, -2.0, **kw)
+    for n in (1000, 23, 1, 1, 3, 1019, 1, 2, 5000):                     # cuts at rows 1000, 1023, 1024, 1025, 1028, 2047, 2048, 2050
+        b.step(n)
+    assert a.d_ray()[2].min() > 2060
+    assert np.array_equal(a.d_ray(), b.d_ray()) and np.array_equal(a.final(), b.final())
+    assert np.array_equal(a.rows(), b.rows())
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("m", [6, 7])
 def test_sharding_is_bit_identical(m, rb, gpu_fields):
     """rays are independent, so any partition gives the same bits."""
