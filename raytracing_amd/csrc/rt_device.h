@@ -13,6 +13,18 @@ namespace rt {
 // values, never from a wave vote.
 __device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+// a*b + c where c is a loop-invariant constant held in a VGPR pair: written as the three-address v_fma_f64.  Left to the
+// compiler this becomes v_mov_b64 (copy the constant) + v_fmac_f64 (accumulate into the copy), two instructions for one.
+#ifndef RTMI_NO_FMA3
+__device__ __forceinline__ double fma_const(double a, double b, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+    return d;
+}
+#else
+__device__ __forceinline__ double fma_const(double a, double b, double c) { return __builtin_fma(a, b, c); }
+#endif
+__device__ __forceinline__ float fma_const(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
 // ---------------------------------------------------------------- sin/cos
 // fp64 sincos: 3-constant Cody-Waite reduction by pi/2 (the first step is exact under fma, so the reduction
@@ -112,11 +124,11 @@ template <> struct M<float> {
 // global-gather kernel two more spilled registers and 11 % of its speed.)
 template <typename T> __device__ __forceinline__ void sincos_add_small(T s, T c, T k, T* so, T* co) {
     const T z = k * k;
-    T ps = fma_(z, T(-1.0 / 5040.0), T(1.0 / 120.0));
-    ps = fma_(z, ps, T(-1.0 / 6.0));
+    T ps = fma_const(z, T(-1.0 / 5040.0), T(1.0 / 120.0));
+    ps = fma_const(z, ps, T(-1.0 / 6.0));
     const T sk = fma_(z * k, ps, k);                 // sin k
-    T pc = fma_(z, T(-1.0 / 40320.0), T(1.0 / 720.0));
-    pc = fma_(z, pc, T(-1.0 / 24.0));
+    T pc = fma_const(z, T(-1.0 / 40320.0), T(1.0 / 720.0));
+    pc = fma_const(z, pc, T(-1.0 / 24.0));
     pc = fma_(z, pc, T(0.5));
     const T ck1 = z * pc;                            // 1 - cos k
     *so = fma_(c, sk, fma_(-s, ck1, s));
