@@ -598,7 +598,12 @@ __device__ __forceinline__ T* wave_uniform_ptr(T* p) {
 // rowp / nrowp: this block's slice of the current row of s_ray / n_ray (wave-uniform pointers the loop advances)
 template <typename T>
 __device__ __forceinline__ void write_row_uniform(const BatchDev<T>& a, T* rowp, T* nrowp, int voff, const rt::Ray<T>& r) {
-    const int qR = (int)(a.R * (long)sizeof(T));                        // byte distance between quantities (< 2^31 / 6: pick_advance)
+    int qR = (int)(a.R * (long)sizeof(T));                              // byte distance between quantities (< 2^31 / 6: pick_advance)
+#ifndef RTMI_NO_QR_LAUNDER
+    // the multiples of qR are formed here, per row, with one scalar instruction each: hoisted out of the step loop they
+    // do not fit the scalar registers and come back through v_readlane + 5 wait states apiece
+    asm volatile("" : "+s"(qR));
+#endif
     rowp = wave_uniform_ptr(rowp);
     nrowp = wave_uniform_ptr(nrowp);
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(rowp, 0, 0x7fffffff, 0x00020000);
