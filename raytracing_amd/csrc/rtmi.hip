@@ -573,6 +573,9 @@ constexpr bool heavy_method(int m) { return m == 4 || m == 5 || m >= 9; }
 #ifndef RTMI_GOLD_WAVES
 #define RTMI_GOLD_WAVES 3      // waves per SIMD the golden-section builds (op5/9/10/11, global gather) are compiled for
 #endif
+#ifndef RTMI_F32_WAVES
+#define RTMI_F32_WAVES 4       // waves per SIMD the fp32 builds of k_advance are compiled for
+#endif
 #ifndef RTMI_STEP_PAIRS
 #define RTMI_STEP_PAIRS 2      // 1: op2/op6 fp64, 2: every fast-form build -- two steps per loop iteration (see advance_loop)
 #endif
@@ -694,7 +697,7 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
 // Every lane runs every iteration until no lane of its wave is active; a ray's state is stored the moment it
 // terminates (or when the launch's step budget ends), so idle lanes never write.
 template <typename T, int METHOD, bool ISO, bool LDS, bool VAR>
-__global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : LDS ? (light_method(METHOD) ? RTMI_TILE_WAVES : heavy_method(METHOD) ? 2 : 3) : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES))
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? RTMI_F32_WAVES : LDS ? (light_method(METHOD) ? RTMI_TILE_WAVES : heavy_method(METHOD) ? 2 : 3) : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES))
 void k_advance(BatchDev<T> a, int nsteps) {
     __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
     typename GatherOf<T, LDS>::type gather;
