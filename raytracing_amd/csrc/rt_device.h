@@ -90,8 +90,7 @@ template <> struct M<double> {
         const double r = fma_(-h, g, 0.5);
         g = fma_(g, r, g);
         h = fma_(h, r, h);
-        g = fma_(fma_(-g, g, x), h, g);
-        return fma_(fma_(-g, g, x), h, g);
+        return fma_(fma_(-g, g, x), h, g);      // one residual correction: <= 1 ulp (a second one would round correctly)
     }
     static __device__ __forceinline__ double sqrt_full(double x) { return __dsqrt_rn(x); }
     static __device__ __forceinline__ void sincos_(double x, double* s, double* c) { sincos_k(x, s, c); }
@@ -372,11 +371,15 @@ template <typename T> __device__ __forceinline__ void gather_none(T z[4], Pair<T
     }
 }
 
-// bilinear n (fpbisp order: c * w_y * w_x) and the bicubic gradient: one basis for both components (same
-// knots); row sums, then the column sum.
+// bilinear n: the two x-interpolations, then the y-interpolation (6 instructions; fpbisp's four triple products take 8)
+template <typename T> __device__ __forceinline__ T bilinear(const Cell<T>& c, T z0, T z1, T z2, T z3) {
+    const T r0 = fma_(z1, c.lwx[1], z0 * c.lwx[0]), r1 = fma_(z3, c.lwx[1], z2 * c.lwx[0]);
+    return fma_(r1, c.lwy[1], r0 * c.lwy[0]);
+}
+// the bicubic gradient: one basis for both components (same knots); row sums, then the column sum.
 template <typename T>
 __device__ __forceinline__ void field_combine(const Cell<T>& c, const T z[4], const Pair<T> g[4][4], T& n, T& gx, T& gy) {
-    n = fma_(z[3] * c.lwy[1], c.lwx[1], fma_(z[2] * c.lwy[1], c.lwx[0], fma_(z[1] * c.lwy[0], c.lwx[1], (z[0] * c.lwy[0]) * c.lwx[0])));
+    n = bilinear(c, z[0], z[1], z[2], z[3]);
     T sx = 0, sy = 0;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -425,7 +428,7 @@ __device__ __forceinline__ void lookup_global_rows(const FieldDev<T>& F, const C
         }
         if (PHASES > 1) asm volatile("" : "+v"(sx), "+v"(sy) : : "memory");   // the next rows' loads stay behind these sums
     }
-    n = fma_(z3 * c.lwy[1], c.lwx[1], fma_(z2 * c.lwy[1], c.lwx[0], fma_(z1 * c.lwy[0], c.lwx[1], (z0 * c.lwy[0]) * c.lwx[0])));
+    n = bilinear(c, z0, z1, z2, z3);
     gx = sx; gy = sy;
 }
 
@@ -594,7 +597,7 @@ template <typename T> struct LdsGather {
                 }
                 asm volatile("" : "+v"(sx), "+v"(sy) : : "memory");   // the next rows' reads stay behind these sums
             }
-            n = fma_(z3 * c.lwy[1], c.lwx[1], fma_(z2 * c.lwy[1], c.lwx[0], fma_(z1 * c.lwy[0], c.lwx[1], (z0 * c.lwy[0]) * c.lwx[0])));
+            n = bilinear(c, z0, z1, z2, z3);
             gx = sx; gy = sy;
 #else
             T z[4];
