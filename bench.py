@@ -120,8 +120,10 @@ def main():
     ap.add_argument("--n-ray", action="store_true",
                     help="also keep n_ray rows (coef*n per row): internal to the reference's trazar (RT_bench.py:803), not among "
                          "its return values (:948), so off by default")
-    ap.add_argument("--mode", default="lane", choices=["lane", "refill"],
-                    help="lane: one lane per ray; refill: persistent waves with ballot/prefix lane refill")
+    ap.add_argument("--mode", default="lane", choices=["lane", "refill", "sliced"],
+                    help="lane: one lane per ray; refill: persistent waves with ballot/prefix lane refill; "
+                         "sliced: persistent blocks advancing 256-ray bundles in time slices (launch_mode 2)")
+    ap.add_argument("--slice-steps", type=int, default=0, help="--mode sliced: DELTA_S steps per slice (0 = 256)")
     ap.add_argument("--order", default="fan", choices=["fan", "shuffled"],
                     help="ray order inside the batch: the sorted fan, or a seeded random permutation of it")
     ap.add_argument("--refill-min", type=int, default=0)
@@ -188,7 +190,7 @@ def main():
     def make_batch(stride_, rec_rows_):
         return rb.Batch(fld, args.method, step, max_size, lim, sc["gamma"], th, sc["start"][0], sc["start"][1],
                         record_stride=stride_, rec_rows=rec_rows_, block_size=args.block,
-                        launch_mode=1 if args.mode == "refill" else 0, refill_min=args.refill_min,
+                        launch_mode={"lane": 0, "refill": 1, "sliced": 2}[args.mode], refill_min=args.refill_min, slice_steps=args.slice_steps,
                         field_path={"auto": 0, "global": 1, "lds": 2}[args.field_path], sort_rays=args.sort,
                         lazy_clear=True,    # every pass re-runs the same launch conditions: same rows rewritten
                         keep_n_ray=args.n_ray)
@@ -295,7 +297,7 @@ def main():
             roof["valu_issue"] = valu
             if frac > roof["frac"]:
                 roof.update(bound="valu", achieved=valu["achieved"], peak=valu["peak"], unit=valu["unit"], frac=frac)
-        roof.update(kernel="k_trace_refill" if args.mode == "refill" else "k_advance", kernel_ms=kern_ms / launches,
+        roof.update(kernel={"refill": "k_trace_refill", "sliced": "k_advance_sliced"}.get(args.mode, "k_advance"), kernel_ms=kern_ms / launches,
                     kernel_ms_per_pass=kern_ms, launches_per_pass=launches, ray_steps_per_pass=int(steps_per_pass),
                     vgprs=st["vgprs"], hbm=hbm,
                     alg_model={"bytes_per_ray_step": balg, "GB_per_s": balg * steps_per_pass / ksec / 1e9,

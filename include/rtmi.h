@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 2
+#define RTMI_ABI_VERSION 3
 
 typedef enum {
     RTMI_OK = 0,
@@ -83,7 +83,9 @@ typedef struct {
     int32_t record_stride;   /* 0: keep no trajectory; s>=1: store rows i with i % s == 0 (1 = reference layout) */
     int64_t rec_rows;        /* rows allocated for s_ray/n_ray (row r holds step r*stride); 0 -> derived from max_size */
     double box[4];           /* limx_i, limx_s, limy_i, limy_s (:878) */
-    int32_t launch_mode;     /* 0: one lane per ray to completion; 1: persistent waves with lane refill */
+    int32_t launch_mode;     /* 0: one lane per ray to completion; 1: persistent waves with lane refill; 2: persistent blocks
+                                that advance 256-ray bundles in time slices of slice_steps rows (rtmi_run only; balances fans
+                                whose rays differ much in length); results are bit-identical in all three */
     int32_t block_size;      /* 0 -> default */
     int32_t refill_min;      /* launch_mode 1: compact when this many lanes of a wave are idle (0 -> 32) */
     int32_t exact_basis;     /* 0: uniform-knot cubic basis in interior cells (<= 4e-14 from FITPACK's weights);
@@ -103,6 +105,7 @@ typedef struct {
     int32_t no_n_ray;        /* 1: keep no n_ray rows.  n_ray (coef*n per row, :803) is an internal array of trazar -- it feeds the
                                 traveltime recurrence (:874) and is not among trazar's return values (:948) -- so a caller of the
                                 reference's call surface never sees it; dropping it saves 1/7 of the recorded bytes */
+    int32_t slice_steps;     /* launch_mode 2: DELTA_S steps per time slice of a bundle (0 -> 256) */
 } rtmi_params;
 
 /* Upload R launch conditions (host pointers; x0/y0 per ray -- pos_x[k], -2 or the fisheye start, :809-813),

@@ -23,7 +23,7 @@ class Params(C.Structure):
                 ("box", C.c_double * 4), ("launch_mode", C.c_int32), ("block_size", C.c_int32),
                 ("refill_min", C.c_int32), ("exact_basis", C.c_int32),
                 ("field_path", C.c_int32), ("sort_rays", C.c_int32),
-                ("ext_s_ray", C.c_void_p), ("ext_n_ray", C.c_void_p), ("lazy_clear", C.c_int32), ("no_n_ray", C.c_int32)]
+                ("ext_s_ray", C.c_void_p), ("ext_n_ray", C.c_void_p), ("lazy_clear", C.c_int32), ("no_n_ray", C.c_int32), ("slice_steps", C.c_int32)]
 
 
 class DeviceView(C.Structure):
@@ -100,7 +100,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.rtmi_abi_version() != 2:
+        if L.rtmi_abi_version() != 3:
             raise ImportError("librtmi.so ABI version mismatch")
         _lib = L
     return _lib

@@ -497,25 +497,46 @@ __global__ void k_stats(const int* istep, const unsigned char* alive, long R, un
     }
 }
 
-template <typename T, int METHOD, bool ISO>
-__device__ __forceinline__ void load_ray(const BatchDev<T>& a, long k, rt::Ray<T>& r, int& i) {
-    r.x = a.acc(0)[k]; r.y = a.acc(1)[k]; r.th = a.acc(2)[k]; r.n = a.aux(0)[k]; r.gx = a.aux(1)[k]; r.gy = a.aux(2)[k];
-    r.dsim = a.acc(3)[k]; r.dreal = a.acc(4)[k]; r.tt = a.acc(5)[k];
-    if (METHOD == 7) { r.hx0 = a.aux(3)[k]; r.hy0 = a.aux(4)[k]; r.hx1 = a.aux(5)[k]; r.hy1 = a.aux(6)[k]; }
-    else { r.hx0 = r.hy0 = r.hx1 = r.hy1 = 0; }
-    if constexpr (rt::IsExact<T, METHOD>::value) rt::ex::derive(a.K, r);
-    else if constexpr (rt::RotatesUnit<T, METHOD>::value) { r.ux = a.unit(0)[k]; r.uy = a.unit(1)[k]; rt::derive<T, ISO, true>(a.K, r); }
-    else rt::derive<T, ISO>(a.K, r);
-    i = a.istep[k];
+// State accesses.  COH: the time-sliced kernel hands a bundle's state from one block to another, possibly on another XCD
+// whose L2 is not coherent with this one's; its state loads and stores are device-scope (relaxed) atomics, which go to the
+// coherence point, so that no whole-cache write-back / invalidate is needed around a slice (the rows need none: only the
+// host reads them).  Plain accesses otherwise.
+template <bool COH, typename V> __device__ __forceinline__ V ld_state(const V* p) {
+    if constexpr (COH) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else return *p;
 }
-template <typename T, int METHOD>
+template <bool COH, typename V> __device__ __forceinline__ void st_state(V* p, V v) {
+    if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+template <typename T, int METHOD, bool ISO, bool COH = false>
+__device__ __forceinline__ void load_ray(const BatchDev<T>& a, long k, rt::Ray<T>& r, int& i) {
+    r.x = ld_state<COH>(a.acc(0) + k); r.y = ld_state<COH>(a.acc(1) + k); r.th = ld_state<COH>(a.acc(2) + k);
+    r.n = ld_state<COH>(a.aux(0) + k); r.gx = ld_state<COH>(a.aux(1) + k); r.gy = ld_state<COH>(a.aux(2) + k);
+    r.dsim = ld_state<COH>(a.acc(3) + k); r.dreal = ld_state<COH>(a.acc(4) + k); r.tt = ld_state<COH>(a.acc(5) + k);
+    if (METHOD == 7) {
+        r.hx0 = ld_state<COH>(a.aux(3) + k); r.hy0 = ld_state<COH>(a.aux(4) + k);
+        r.hx1 = ld_state<COH>(a.aux(5) + k); r.hy1 = ld_state<COH>(a.aux(6) + k);
+    } else { r.hx0 = r.hy0 = r.hx1 = r.hy1 = 0; }
+    if constexpr (rt::IsExact<T, METHOD>::value) rt::ex::derive(a.K, r);
+    else if constexpr (rt::RotatesUnit<T, METHOD>::value) {
+        r.ux = ld_state<COH>(a.unit(0) + k); r.uy = ld_state<COH>(a.unit(1) + k);
+        rt::derive<T, ISO, true>(a.K, r);
+    } else rt::derive<T, ISO>(a.K, r);
+    i = ld_state<COH>(a.istep + k);
+}
+template <typename T, int METHOD, bool COH = false>
 __device__ __forceinline__ void store_ray(const BatchDev<T>& a, long k, const rt::Ray<T>& r, int i, bool alive) {
-    a.acc(0)[k] = r.x; a.acc(1)[k] = r.y; a.acc(2)[k] = r.th; a.aux(0)[k] = r.n; a.aux(1)[k] = r.gx; a.aux(2)[k] = r.gy;
-    a.acc(3)[k] = r.dsim; a.acc(4)[k] = r.dreal; a.acc(5)[k] = r.tt;
-    if (METHOD == 7) { a.aux(3)[k] = r.hx0; a.aux(4)[k] = r.hy0; a.aux(5)[k] = r.hx1; a.aux(6)[k] = r.hy1; }
-    if constexpr (rt::RotatesUnit<T, METHOD>::value) { a.unit(0)[k] = r.ux; a.unit(1)[k] = r.uy; }
-    a.istep[k] = i;
-    a.alive[k] = alive;
+    st_state<COH>(a.acc(0) + k, r.x); st_state<COH>(a.acc(1) + k, r.y); st_state<COH>(a.acc(2) + k, r.th);
+    st_state<COH>(a.aux(0) + k, r.n); st_state<COH>(a.aux(1) + k, r.gx); st_state<COH>(a.aux(2) + k, r.gy);
+    st_state<COH>(a.acc(3) + k, r.dsim); st_state<COH>(a.acc(4) + k, r.dreal); st_state<COH>(a.acc(5) + k, r.tt);
+    if (METHOD == 7) {
+        st_state<COH>(a.aux(3) + k, r.hx0); st_state<COH>(a.aux(4) + k, r.hy0);
+        st_state<COH>(a.aux(5) + k, r.hx1); st_state<COH>(a.aux(6) + k, r.hy1);
+    }
+    if constexpr (rt::RotatesUnit<T, METHOD>::value) { st_state<COH>(a.unit(0) + k, r.ux); st_state<COH>(a.unit(1) + k, r.uy); }
+    st_state<COH>(a.istep + k, i);
+    st_state<COH>(a.alive + k, (unsigned char)alive);
 }
 
 // A finite, in-grid dummy state for lanes that hold no ray (they still execute every step, see rt::ray_step).
@@ -533,11 +554,6 @@ template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::
     g.init(lds + (threadIdx.x >> 6) * rt::LdsGather<T>::ELEMS);
 }
 
-// The loop at :866-879: one lane per ray, state in registers for up to nsteps DELTA_S steps.
-// ISO (gamma == 1) drops the anisotropic factor's dead arithmetic; LDS selects the wave-private field tile
-// (rt::LdsGather) over per-lookup global gathers.  Results are bit-identical across all four variants.
-// Every lane runs every iteration until no lane of its wave is active; a ray's state is stored the moment it
-// terminates (or when the launch's step budget ends), so idle lanes never write.
 // A ray's state is stored once, when it terminates: the batch members that needs (state slab, istep, alive) are re-read
 // from the kernel-argument segment there instead of occupying scalar registers for the whole loop (see rt::rare_field).
 #ifndef RTMI_NO_KERNARG_FIELD
@@ -625,9 +641,9 @@ __device__ __forceinline__ void write_row_uniform(const BatchDev<T>& a, T* rowp,
 // The step loop of k_advance.  UROW: rows are recorded and every live lane of the wave is at the same row, so the
 // row counter lives in scalar registers and rows go out through write_row_uniform; otherwise per-lane bookkeeping
 // (also when nothing is recorded).
-template <typename T, int METHOD, bool ISO, typename G, bool UROW>
+template <typename T, int METHOD, bool ISO, typename G, bool UROW, bool COH = false>
 __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Consts<T>& K, G& gather, rt::Ray<T>& r, long k, int& i,
-                                             bool& alive, int max_size, int nsteps) {
+                                             bool& alive, int max_size, int nsteps, long blk) {
     const bool RECORD = a.stride != 0;
     int until = 0;
     long row = 0;
@@ -635,7 +651,6 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
     // written, and this block's slice of the current row (advanced by one row of 6*R / R values per recorded row)
     int rows_left = 0;
     T *rowp = nullptr, *nrowp = nullptr;
-    const long blk = (long)blockIdx.x * blockDim.x;
     const int voff = (int)(threadIdx.x * sizeof(T));
     if (UROW && RECORD) {
         const int i0 = __builtin_amdgcn_readfirstlane(rt::wave_max_i(alive ? i : 0));
@@ -671,7 +686,7 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
                 }
             }
             alive = inside && (i + 1 < max_size);
-            if (!alive) store_ray<T, METHOD>(rare_batch(a), k, r, i, false);
+            if (!alive) store_ray<T, METHOD, COH>(rare_batch(a), k, r, i, false);
         }
         return true;
     };
@@ -689,6 +704,9 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
     }
 }
 
+template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool COH = false>
+__device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, long blk, int nsteps);
+
 // The loop at :866-879: one lane per ray, state in registers for up to nsteps DELTA_S steps.
 // ISO (gamma == 1) drops the anisotropic factor's dead arithmetic; LDS selects the wave-private field tile
 // (rt::LdsGather) over per-lookup global gathers.  Results are bit-identical across all four variants.
@@ -700,17 +718,21 @@ template <typename T, int METHOD, bool ISO, bool LDS, bool VAR>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? RTMI_F32_WAVES : LDS ? (light_method(METHOD) ? RTMI_TILE_WAVES : heavy_method(METHOD) ? 2 : 3) : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES))
 void k_advance(BatchDev<T> a, int nsteps) {
     __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
+    advance_bundle<T, METHOD, ISO, LDS, VAR>(a, lds, (long)blockIdx.x * blockDim.x, nsteps);
+}
+template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool COH>
+__device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, long blk, int nsteps) {
     typename GatherOf<T, LDS>::type gather;
     gather_init<T, LDS>(gather, lds);
-    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long k = blk + threadIdx.x;
     rt::Ray<T> r;
     int i = 0;
-    bool alive = k < a.R && a.alive[k];
+    bool alive = k < a.R && ld_state<COH>(a.alive + (k < a.R ? k : 0));
     // VAR: every ray carries its own DELTA_S and max_size (the calibration sweep as one candidate x ray batch)
     rt::Consts<T> K = a.K;
     int max_size = a.max_size;
     if (VAR && a.vstep && k < a.R) { K.step = a.vstep[k]; K.step2h = a.vstep2h[k]; K.step2 = K.step2h * T(2); max_size = a.vmax[k]; }
-    if (alive) load_ray<T, METHOD, ISO>(a, k, r, i);
+    if (alive) load_ray<T, METHOD, ISO, COH>(a, k, r, i);
     else idle_ray(a, r);
     // Rows are recorded through the wave-uniform descriptor path (UROW) by every build except the VAR one: the host
     // launches a non-VAR build only while every live ray of the batch is at the same row (always, unless
@@ -720,8 +742,91 @@ void k_advance(BatchDev<T> a, int nsteps) {
     // model around the back edge, and every first use in the loop then waits for vmcnt(0), i.e. for the previous
     // step's row stores to be acknowledged.
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), expcnt and lgkmcnt untouched
-    advance_loop<T, METHOD, ISO, decltype(gather), !VAR>(a, K, gather, r, k, i, alive, max_size, nsteps);
-    if (alive) store_ray<T, METHOD>(a, k, r, i, true);
+    advance_loop<T, METHOD, ISO, decltype(gather), !VAR, COH>(a, K, gather, r, k, i, alive, max_size, nsteps, blk);
+    if (alive) store_ray<T, METHOD, COH>(a, k, r, i, true);
+    return alive;
+}
+
+// Time-sliced bundles on persistent blocks (launch_mode 2).  A launch of k_advance gives every 256-ray bundle a block
+// slot for its whole life; when the long bundles of a fan are a little more than a whole multiple of the slots (cfg3:
+// 2 060 bundles of 3 039 rows for 1 024 slots) the last round runs on a nearly empty chip.  Here as many blocks as fit
+// the device draw tickets from one counter: ticket t means slice t / NB of bundle t % NB, i.e. `slice` DELTA_S steps of
+// that bundle from the state its previous slice stored -- the same arithmetic as rtmi_step(b, slice) repeated, so the
+// results are the bits of every other mode.  Slices of one bundle are ordered through done[bundle]: the state goes
+// through device-scope accesses (ld_state / st_state), a block waits for its own stores (vmcnt(0) + barrier) before it
+// raises the flag, and reads the flag before it loads -- no whole-L2 write-back or invalidate, which the agent-scope
+// release/acquire fences of the first version cost at every slice (31.6 vs 18.4 ms with the full record).  A waiting
+// block waits for a block that is running, never for one that has not started.  A bundle whose rays have all terminated is marked once and costs later tickets one atomic read.
+// Exit, reached by every block: all bundles dead, or the ticket past the last possible slice (max_size / slice passes).
+__device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <typename T, int METHOD, bool ISO, bool LDS>
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? RTMI_F32_WAVES : LDS ? (light_method(METHOD) ? RTMI_TILE_WAVES : heavy_method(METHOD) ? 2 : 3) : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES))
+void k_advance_sliced(BatchDev<T> a, int slice, int passes, unsigned* ctl) {
+    __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
+    __shared__ unsigned long long s_ticket;
+    __shared__ unsigned s_word[2];
+    const unsigned long long NB = (unsigned long long)((a.R + 255) / 256);
+    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(ctl);      // ctl[0..1]
+    unsigned* dead = ctl + 2;                                                     // bundles that have no live ray left
+    unsigned* stalled = ctl + 3;                                                  // set if a wait ran out (never expected)
+    unsigned* done = ctl + 4;                                                     // [NB] slices finished per bundle
+    const unsigned kDead = 0xffffffffu;
+    // The block's bookkeeping is done by wave 0 with all of its lanes (every lane the same address and value; the ticket
+    // add is 1 from lane 0 and 0 from the others): a branch on the wave index is scalar, whereas `if (threadIdx.x == 0)`
+    // in front of a barrier had the compiler split this loop into a lane-0 loop around an other-lanes loop, with the
+    // barriers in the inner one -- lane 0 never came back for a second ticket.
+    const bool wave0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;
+    const unsigned one = (threadIdx.x & 63) == 0 ? 1u : 0u;
+    bool running = true;
+    while (running) {
+        if (wave0) {
+            const unsigned long long old = atomicAdd(ticket, (unsigned long long)one);
+            s_ticket = uniform_u64(old);                     // lane 0's return value is the ticket
+            s_word[0] = __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_word[1] = __hip_atomic_load(stalled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        // block-uniform values read from LDS are pinned to scalar registers: the loop and its barriers must be uniform
+        // control flow for the compiler too
+        const unsigned long long t = uniform_u64(s_ticket);
+        const unsigned ndead = __builtin_amdgcn_readfirstlane(s_word[0]), nstall = __builtin_amdgcn_readfirstlane(s_word[1]);
+        const bool stop = ndead >= (unsigned)NB || nstall != 0u || t >= NB * (unsigned long long)passes;
+        __syncthreads();                                     // the shared words are rewritten below / next round
+        if (stop) {
+            running = false;
+        } else {
+            const long bundle = (long)(t % NB);
+            const unsigned pass = (unsigned)(t / NB);
+            if (wave0) {
+                unsigned d = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&done[bundle], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                // the block that holds this bundle's previous slice is running; the bound only turns a logic error into
+                // a reported failure (RTMI_ERR_STATE) instead of a hung device
+                for (unsigned spins = 0; d < pass && spins < (1u << 20); ++spins) {   // ~2 s
+                    __builtin_amdgcn_s_sleep(16);
+                    d = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&done[bundle], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                }
+                if (d < pass) { __hip_atomic_store(stalled, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); d = kDead; }
+                s_word[0] = d;
+            }
+            __syncthreads();
+            const bool finished = __builtin_amdgcn_readfirstlane(s_word[0]) == kDead;   // no live ray left (or the wait was abandoned)
+            __syncthreads();
+            if (!finished) {
+                // state through device-scope accesses (ld_state / st_state); every lane's stores are acknowledged before
+                // the barrier, the flag is written after it
+                const bool alive = advance_bundle<T, METHOD, ISO, LDS, false, true>(a, lds, bundle * 256, slice);
+                __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
+                const int any = __builtin_amdgcn_readfirstlane(__syncthreads_or(alive));
+                if (wave0) {
+                    atomicAdd(dead, any ? 0u : one);
+                    __hip_atomic_store(&done[bundle], any ? pass + 1 : kDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
 }
 
 // Persistent waves with lane refill (launch_mode 1): every wave draws rays from a device-side queue
@@ -847,6 +952,9 @@ struct rtmi_batch {
     const void* kfn = nullptr;
     const void* kfn_refill = nullptr;
     int persistent_blocks = 0;   // resident 256-thread blocks of the refill kernel on this device
+    const void* kfn_sliced = nullptr;
+    int sliced_blocks = 0;       // resident 256-thread blocks of the sliced kernel on this device
+    unsigned* sliced_ctl = nullptr;   // launch_mode 2: ticket counter [2 words], dead bundles [2 words], done[bundles]
     bool dirty = false;          // rows may hold data a re-run will not overwrite (set_state / set_per_ray since the last clear)
     bool dirty_state = false;    // rtmi_batch_set_state ran since create / reset
 };
@@ -885,6 +993,16 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
 #define RTMI_REFILL_(T, M) \
     {{(const void*)k_trace_refill<T, M, false, false>, (const void*)k_trace_refill<T, M, false, true>}, \
      {(const void*)k_trace_refill<T, (M < 10 ? M : 1), (M < 10), false>, (const void*)k_trace_refill<T, (M < 10 ? M : 1), (M < 10), true>}}
+#define RTMI_SLICED_(T, M) \
+    {{(const void*)k_advance_sliced<T, M, false, false>, (const void*)k_advance_sliced<T, M, false, true>}, \
+     {(const void*)k_advance_sliced<T, (M < 10 ? M : 1), (M < 10), false>, (const void*)k_advance_sliced<T, (M < 10 ? M : 1), (M < 10), true>}}
+template <typename T> static const void* sliced_fn(int m, bool iso, bool lds) {
+    static const void* const tab[11][2][2] = {RTMI_SLICED_(T, 1), RTMI_SLICED_(T, 2), RTMI_SLICED_(T, 3), RTMI_SLICED_(T, 4),
+                                              RTMI_SLICED_(T, 5), RTMI_SLICED_(T, 6), RTMI_SLICED_(T, 7), RTMI_SLICED_(T, 8),
+                                              RTMI_SLICED_(T, 9), RTMI_SLICED_(T, 10), RTMI_SLICED_(T, 11)};
+    return tab[m - 1][iso ? 1 : 0][lds ? 1 : 0];
+}
+#undef RTMI_SLICED_
 template <typename T> static const void* advance_fn(int m, bool iso, bool lds) {
     static const void* const tab[11][2][2] = {RTMI_ADV_(T, 1), RTMI_ADV_(T, 2), RTMI_ADV_(T, 3), RTMI_ADV_(T, 4),
                                               RTMI_ADV_(T, 5), RTMI_ADV_(T, 6), RTMI_ADV_(T, 7), RTMI_ADV_(T, 8),
@@ -931,6 +1049,10 @@ static const void* pick_advance(const rtmi_batch* b) {
         return b->p.dtype == RTMI_F64 ? advance_var_fn<double>(b->p.method, iso) : advance_var_fn<float>(b->p.method, iso);
     return b->p.dtype == RTMI_F64 ? advance_fn<double>(b->p.method, iso, lds) : advance_fn<float>(b->p.method, iso, lds);
 }
+static const void* pick_sliced(const rtmi_batch* b) {
+    const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
+    return b->p.dtype == RTMI_F64 ? sliced_fn<double>(b->p.method, iso, lds) : sliced_fn<float>(b->p.method, iso, lds);
+}
 static const void* pick_refill(const rtmi_batch* b) {
     const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
     return b->p.dtype == RTMI_F64 ? refill_fn<double>(b->p.method, iso, lds) : refill_fn<float>(b->p.method, iso, lds);
@@ -959,7 +1081,7 @@ RTMI_EXPORT void rtmi_batch_destroy(rtmi_batch* b) {
     (void)hipFree(b->state); (void)hipFree(b->istep); (void)hipFree(b->alive); (void)hipFree(b->launch);
     (void)hipFree(b->perm);
     (void)hipFree(b->vstep); (void)hipFree(b->vstep2h); (void)hipFree(b->vmax);
-    (void)hipFree(b->counters);
+    (void)hipFree(b->counters); (void)hipFree(b->sliced_ctl);
     if (b->h_counters) (void)hipHostFree(b->h_counters);
     if (b->own_s) (void)hipFree(b->s_ray);
     if (b->own_n) (void)hipFree(b->n_ray);
@@ -979,7 +1101,8 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     ARG_TRY(p->method != 7 || p->max_size >= 4, "rtmi_batch_create: op7 needs max_size >= 4 (two bootstrap rows)");
     ARG_TRY(p->record_stride >= 0, "rtmi_batch_create: record_stride < 0");
     ARG_TRY(p->box[1] > p->box[0] && p->box[3] > p->box[2], "rtmi_batch_create: empty box");
-    ARG_TRY(p->launch_mode == 0 || p->launch_mode == 1, "rtmi_batch_create: launch_mode must be 0 or 1");
+    ARG_TRY(p->launch_mode >= 0 && p->launch_mode <= 2, "rtmi_batch_create: launch_mode must be 0, 1 or 2");
+    ARG_TRY(p->slice_steps >= 0, "rtmi_batch_create: slice_steps must be >= 0");
     ARG_TRY(p->refill_min >= 0 && p->refill_min <= 64, "rtmi_batch_create: refill_min must be in [0, 64]");
     ARG_TRY(p->exact_basis == 0 || p->exact_basis == 1, "rtmi_batch_create: exact_basis must be 0 or 1");
     ARG_TRY(p->field_path >= 0 && p->field_path <= 2, "rtmi_batch_create: field_path must be 0 (auto), 1 (global) or 2 (LDS tile)");
@@ -1053,6 +1176,12 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, b->kfn_refill, 256, 0));
         b->persistent_blocks = cus * (per_cu > 0 ? per_cu : 1);
+        if (b->p.launch_mode == 2) {
+            b->kfn_sliced = pick_sliced(b);
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, b->kfn_sliced, 256, 0));
+            b->sliced_blocks = cus * (per_cu > 0 ? per_cu : 1);
+            HIP_TRY(hipMalloc(&b->sliced_ctl, (4 + (Rz + 255) / 256) * sizeof(unsigned)));
+        }
         return batch_init_state(b, true);
     };
     try {
@@ -1264,9 +1393,42 @@ template <typename T> static void launch_refill(const rtmi_batch* b) {
     (void)hipLaunchKernel(b->kfn_refill, g, blk, args, 0, b->stream);
 }
 
+template <typename T> static void launch_sliced(const rtmi_batch* b, int slice, int passes) {
+    BatchDev<T> a = batch_dev<T>(b);
+    unsigned* ctl = b->sliced_ctl;
+    void* args[] = {&a, &slice, &passes, &ctl};
+    const long need = (b->R + 255) / 256;
+    const dim3 g((unsigned)(need < b->sliced_blocks ? need : b->sliced_blocks)), blk(256);
+    (void)hipLaunchKernel(b->kfn_sliced, g, blk, args, 0, b->stream);
+}
+
 RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
     ARG_TRY(b, "rtmi_run: null");
     int rc;
+    if (b->p.launch_mode == 2 && !b->vstep && uniform_rows_ok(b)) {
+        // persistent blocks, bundles advanced in time slices (k_advance_sliced); per-ray DELTA_S or rays at rows of their
+        // own (the VAR build's cases) run as launch_mode 0 below
+        DEVICE_TRY(b->field, "rtmi_run");
+        std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+        rc = next_event_pair(b, &ev);
+        if (rc) return rc;
+        const int slice = b->p.slice_steps > 0 ? b->p.slice_steps : 256;
+        const int passes = (b->p.max_size + slice - 1) / slice;
+        HIP_TRY(hipMemsetAsync(b->sliced_ctl, 0, (4 + ((size_t)b->R + 255) / 256) * sizeof(unsigned), b->stream));
+        HIP_TRY(hipEventRecord(ev->first, b->stream));
+        if (b->p.dtype == RTMI_F64) launch_sliced<double>(b, slice, passes);
+        else launch_sliced<float>(b, slice, passes);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(ev->second, b->stream));
+        b->launches++;
+        rc = read_counters(b);
+        if (rc) return rc;
+        unsigned ctl4[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpy(ctl4, b->sliced_ctl, sizeof(ctl4), hipMemcpyDeviceToHost));
+        if (ctl4[3] != 0) return fail(RTMI_ERR_STATE, "rtmi_run: the sliced launch abandoned a wait for a bundle's previous slice");
+        if (b->h_counters[1] != 0) return fail(RTMI_ERR_STATE, "rtmi_run: rays still live after the sliced launch");
+        return RTMI_OK;
+    }
     if (b->p.launch_mode == 1) {
         // persistent waves with lane refill: one launch drains the ray queue
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
@@ -1584,7 +1746,7 @@ RTMI_EXPORT int rtmi_batch_stats(rtmi_batch* b, rtmi_stats* s) {
     s->launches = b->launches;
     hipFuncAttributes fa;
     s->vgprs = s->sgprs = s->lds_bytes = 0;
-    if (hipFuncGetAttributes(&fa, b->p.launch_mode == 1 ? b->kfn_refill : b->kfn) == hipSuccess) { s->vgprs = fa.numRegs; s->lds_bytes = (uint32_t)fa.sharedSizeBytes; }
+    if (hipFuncGetAttributes(&fa, b->p.launch_mode == 1 ? b->kfn_refill : (b->p.launch_mode == 2 && b->kfn_sliced) ? b->kfn_sliced : b->kfn) == hipSuccess) { s->vgprs = fa.numRegs; s->lds_bytes = (uint32_t)fa.sharedSizeBytes; }
     return RTMI_OK;
 }
 

@@ -275,7 +275,7 @@ class Batch:
 
     def __init__(self, field, method, step, max_size, box, gamma, thetas, x0, y0, record_stride=1, rec_rows=0,
                  gamma_step=None, stream=None, ext_s_ray=None, ext_n_ray=None, block_size=0, launch_mode=0,
-                 refill_min=0, exact_basis=0, field_path=0, sort_rays=False, lazy_clear=False, keep_n_ray=True):
+                 refill_min=0, exact_basis=0, field_path=0, sort_rays=False, lazy_clear=False, keep_n_ray=True, slice_steps=0):
         self.field = field
         th = np.ascontiguousarray(thetas, dtype=np.float64)
         self.R = len(th)
@@ -298,6 +298,7 @@ class Batch:
         p.ext_s_ray = ext_s_ray; p.ext_n_ray = ext_n_ray
         p.lazy_clear = int(bool(lazy_clear))
         p.no_n_ray = int(not keep_n_ray)
+        p.slice_steps = int(slice_steps)
         self.params = p
         self._h = C.c_void_p()
         check(lib().rtmi_batch_create(field._h, C.byref(p), self.R, dptr(x0), dptr(y0), dptr(th), stream,

@@ -277,6 +277,42 @@ def test_sharding_is_bit_identical(m, rb, gpu_fields):
         p.close()
 
 
+@pytest.mark.parametrize("scen,m,dtype,slice_steps,stride", [("vert_heterogeneous", 6, "f64", 0, 1), ("fisheye", 6, "f64", 100, 1),
+                                                         ("vert_heterogeneous", 7, "f64", 37, 16), ("vert_heterogeneous", 9, "f64", 64, 1),
+                                                         ("vert_heterogeneous", 6, "f32", 300, 1), ("interface", 2, "f64", 1000, 0)])
+def test_sliced_bundles_are_bit_identical(scen, m, dtype, slice_steps, stride, rb, gpu_fields, oracle_fields):
+    """launch_mode 2 (persistent blocks, 256-ray bundles advanced in time slices through a ticket counter) vs one lane
+    per ray to completion: same rows, same final state, same step counts; more bundles than resident blocks would need
+    a large batch, so the ordering of a bundle's slices is exercised with short slices instead."""
+    R = 5000 if m != 9 else 600
+    lim = LIMITS[scen]
+    if scen == "fisheye":
+        th = np.linspace(np.pi / 4, 3 * np.pi / 4, R); x0, y0 = 1.0, 0.0
+        step, ms = 2 * np.pi / 303, 3040
+    else:
+        th = np.linspace(0.06, np.pi / 2, R); x0, y0 = -2.0, -2.0
+        step, ms = rb.DELTA_S, int(np.ceil(80 / rb.DELTA_S) + 1)
+    F = gpu_fields(scen, rb.F64 if dtype == "f64" else rb.F32)
+    a = rb.Batch(F, m, step, ms, lim, 1, th, x0, y0, record_stride=stride)
+    a.run()
+    b = rb.Batch(F, m, step, ms, lim, 1, th, x0, y0, record_stride=stride, launch_mode=2, slice_steps=slice_steps)
+    b.run()
+    sa, sb = a.stats(), b.stats()
+    assert sa["ray_steps"] == sb["ray_steps"] == int(a.d_ray()[2].sum()) and sb["live_rays"] == 0 and sb["launches"] == 1
+    assert np.array_equal(a.d_ray(), b.d_ray()) and np.array_equal(a.final(), b.final())
+    if stride:
+        assert np.array_equal(a.rows(), b.rows())
+    b.reset(); b.step(123); b.run()            # part of the way with the plain kernel, then the sliced launch
+    assert np.array_equal(a.d_ray(), b.d_ray()) and np.array_equal(a.final(), b.final())
+    if stride:
+        assert np.array_equal(a.rows(), b.rows())
+    if m == 9:                                  # and against the oracle directly: the reference-order method's bits
+        from oracle import rt_oracle as O
+        o = O.trazar(oracle_fields(scen), m, 1, step, ms, lim, x0, y0, th, record_stride=stride, nthreads=8)
+        assert np.array_equal(b.final(), o["final"]) and np.array_equal(b.rows(), o["s_ray"])
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("scen,m,refill_min", [("vert_heterogeneous", 6, 0), ("vert_heterogeneous", 7, 1),
                                                ("interface", 6, 48), ("vert_heterogeneous", 9, 16)])
 def test_lane_refill_is_bit_identical(scen, m, refill_min, rb, gpu_fields, oracle_fields):
