@@ -21,7 +21,7 @@ def counters(d):
     meta = {}
     for fn in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(fn)):
-            if "k_advance" in r["Kernel_Name"] or "k_trace_refill" in r["Kernel_Name"]:
+            if "k_advance" in r["Kernel_Name"] or "k_trace_refill" in r["Kernel_Name"]:   # k_advance_sliced included
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
                 meta = {"kernel": r["Kernel_Name"].split("(")[0], "vgpr": r["VGPR_Count"], "sgpr": r["SGPR_Count"],
                         "lds": r["LDS_Block_Size"], "scratch": r["Scratch_Size"], "grid": r["Grid_Size"], "wg": r["Workgroup_Size"]}
@@ -92,6 +92,8 @@ def main():
         with open(os.path.join(ROOT, "profiles", f"{tag}_bench.json"), "w") as f:
             f.write(json.dumps(bench) + "\n")
         key = f"{cfg['workload'].split(',')[0]}:{cfg['rays_rank0']}:{cfg['record']}{'+n_ray' if cfg.get('n_ray_rows') else ''}:{bench['dtype']}:{cfg['method']}"
+        if cfg.get("launch_mode", "lane") != "lane":          # bench.py looks up lane-mode entries only; keep the others apart
+            key += ":" + cfg["launch_mode"]
         tj[key] = entry
         print("\n".join(lines))
     tj["_note"] = ("HBM bytes and instruction counts per advance-kernel launch from rocprofv3 --pmc (separate passes; FETCH_SIZE/WRITE_SIZE "
