@@ -313,6 +313,23 @@ def test_sliced_bundles_are_bit_identical(scen, m, dtype, slice_steps, stride, r
     a.close(); b.close()
 
 
+def test_sliced_bundles_more_bundles_than_resident_blocks(rb, gpu_fields):
+    """launch_mode 2 with 1 954 bundles for at most 1 024 resident blocks and short slices: tickets of one bundle are drawn
+    by different blocks while its previous slice may still be running elsewhere (the per-bundle ordering), bundles die at
+    very different rows (the fisheye fan); the final state must still be the lane kernel's bits."""
+    R = 500_000
+    lim = LIMITS["fisheye"]
+    th = np.linspace(np.pi / 4, 3 * np.pi / 4, R)
+    F = gpu_fields("fisheye")
+    a = rb.Batch(F, 6, 2 * np.pi / 303, 3040, lim, 1, th, 1.0, 0.0, record_stride=0)
+    a.run()
+    b = rb.Batch(F, 6, 2 * np.pi / 303, 3040, lim, 1, th, 1.0, 0.0, record_stride=0, launch_mode=2, slice_steps=96)
+    b.run()
+    assert b.stats()["live_rays"] == 0 and a.stats()["ray_steps"] == b.stats()["ray_steps"]
+    assert np.array_equal(a.d_ray(), b.d_ray()) and np.array_equal(a.final(), b.final())
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("scen,m,refill_min", [("vert_heterogeneous", 6, 0), ("vert_heterogeneous", 7, 1),
                                                ("interface", 6, 48), ("vert_heterogeneous", 9, 16)])
 def test_lane_refill_is_bit_identical(scen, m, refill_min, rb, gpu_fields, oracle_fields):
