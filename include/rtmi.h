@@ -105,7 +105,8 @@ typedef struct {
     int32_t no_n_ray;        /* 1: keep no n_ray rows.  n_ray (coef*n per row, :803) is an internal array of trazar -- it feeds the
                                 traveltime recurrence (:874) and is not among trazar's return values (:948) -- so a caller of the
                                 reference's call surface never sees it; dropping it saves 1/7 of the recorded bytes */
-    int32_t slice_steps;     /* launch_mode 2: DELTA_S steps per time slice of a bundle (0 -> 256) */
+    int32_t slice_steps;     /* launch_mode 2: DELTA_S steps per time slice of a bundle (0 -> 256); a bundle's first two
+                                slices are 4 and 2 times as long */
 } rtmi_params;
 
 /* Upload R launch conditions (host pointers; x0/y0 per ray -- pos_x[k], -2 or the fisheye start, :809-813),

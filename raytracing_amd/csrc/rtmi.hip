@@ -589,6 +589,9 @@ constexpr bool heavy_method(int m) { return m == 4 || m == 5 || m >= 9; }
 #ifndef RTMI_GOLD_WAVES
 #define RTMI_GOLD_WAVES 3      // waves per SIMD the golden-section builds (op5/9/10/11, global gather) are compiled for
 #endif
+#ifndef RTMI_SLICED_SLEEP
+#define RTMI_SLICED_SLEEP 32   // s_sleep argument (x64 clocks) between two polls of a bundle's slice counter
+#endif
 #ifndef RTMI_F32_WAVES
 #define RTMI_F32_WAVES 4       // waves per SIMD the fp32 builds of k_advance are compiled for
 #endif
@@ -804,8 +807,8 @@ void k_advance_sliced(BatchDev<T> a, int slice, int passes, unsigned* ctl) {
                 unsigned d = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&done[bundle], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 // the block that holds this bundle's previous slice is running; the bound only turns a logic error into
                 // a reported failure (RTMI_ERR_STATE) instead of a hung device
-                for (unsigned spins = 0; d < pass && spins < (1u << 20); ++spins) {   // ~2 s
-                    __builtin_amdgcn_s_sleep(16);
+                for (unsigned spins = 0; d < pass && spins < (1u << 19); ++spins) {   // ~2 s
+                    __builtin_amdgcn_s_sleep(RTMI_SLICED_SLEEP);
                     d = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&done[bundle], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 }
                 if (d < pass) { __hip_atomic_store(stalled, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); d = kDead; }
@@ -817,7 +820,10 @@ void k_advance_sliced(BatchDev<T> a, int slice, int passes, unsigned* ctl) {
             if (!finished) {
                 // state through device-scope accesses (ld_state / st_state); every lane's stores are acknowledged before
                 // the barrier, the flag is written after it
-                const bool alive = advance_bundle<T, METHOD, ISO, LDS, false, true>(a, lds, bundle * 256, slice);
+                // long slices first (4x, 2x, then 1x `slice` steps): balance is decided at the end of a fan's life, and
+                // every slice costs an inter-slice latency
+                const int nsteps = pass == 0u ? 4 * slice : pass == 1u ? 2 * slice : slice;
+                const bool alive = advance_bundle<T, METHOD, ISO, LDS, false, true>(a, lds, bundle * 256, nsteps);
                 __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
                 const int any = __builtin_amdgcn_readfirstlane(__syncthreads_or(alive));
                 if (wave0) {
@@ -1180,6 +1186,7 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
             b->kfn_sliced = pick_sliced(b);
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, b->kfn_sliced, 256, 0));
             b->sliced_blocks = cus * (per_cu > 0 ? per_cu : 1);
+            if (getenv("RTMI_DEBUG")) fprintf(stderr, "rtmi: sliced kernel: %d CUs x %d resident blocks\n", cus, per_cu);
             HIP_TRY(hipMalloc(&b->sliced_ctl, (4 + (Rz + 255) / 256) * sizeof(unsigned)));
         }
         return batch_init_state(b, true);
@@ -1412,8 +1419,10 @@ RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
         rc = next_event_pair(b, &ev);
         if (rc) return rc;
-        const int slice = b->p.slice_steps > 0 ? b->p.slice_steps : 256;
-        const int passes = (b->p.max_size + slice - 1) / slice;
+        const int slice = b->p.slice_steps > 0 ? (b->p.slice_steps < (1 << 20) ? b->p.slice_steps : (1 << 20)) : 256;
+        // the first two slices of a bundle are 4 and 2 slices long (k_advance_sliced)
+        const long rest = (long)b->p.max_size - 6L * slice;
+        const int passes = 2 + (int)(rest > 0 ? (rest + slice - 1) / slice : 0);
         HIP_TRY(hipMemsetAsync(b->sliced_ctl, 0, (4 + ((size_t)b->R + 255) / 256) * sizeof(unsigned), b->stream));
         HIP_TRY(hipEventRecord(ev->first, b->stream));
         if (b->p.dtype == RTMI_F64) launch_sliced<double>(b, slice, passes);
