@@ -753,83 +753,91 @@ __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, lon
 // Time-sliced bundles on persistent blocks (launch_mode 2).  A launch of k_advance gives every 256-ray bundle a block
 // slot for its whole life; when the long bundles of a fan are a little more than a whole multiple of the slots (cfg3:
 // 2 060 bundles of 3 039 rows for 1 024 slots) the last round runs on a nearly empty chip.  Here as many blocks as fit
-// the device draw tickets from one counter: ticket t means slice t / NB of bundle t % NB, i.e. `slice` DELTA_S steps of
-// that bundle from the state its previous slice stored -- the same arithmetic as rtmi_step(b, slice) repeated, so the
-// results are the bits of every other mode.  Slices of one bundle are ordered through done[bundle]: the state goes
-// through device-scope accesses (ld_state / st_state), a block waits for its own stores (vmcnt(0) + barrier) before it
-// raises the flag, and reads the flag before it loads -- no whole-L2 write-back or invalidate, which the agent-scope
-// release/acquire fences of the first version cost at every slice (31.6 vs 18.4 ms with the full record).  A waiting
-// block waits for a block that is running, never for one that has not started.  A bundle whose rays have all terminated is marked once and costs later tickets one atomic read.
-// Exit, reached by every block: all bundles dead, or the ticket past the last possible slice (max_size / slice passes).
+// the device serve one FIFO of bundles: entry i < NB is bundle i (implicit), later entries are bundles pushed back by the
+// block that ran a slice of them and found rays still alive.  A slice is `slice` DELTA_S steps (the first two of a bundle
+// are 4 and 2 slices long: balance is decided at the end of a fan's life and every slice costs an inter-slice latency)
+// from the state the previous slice stored -- the arithmetic of rtmi_step repeated, so the results are the bits of every
+// other mode.  A bundle is in the queue at most once, so no two blocks ever hold it; its state goes through device-scope
+// accesses (ld_state / st_state) and a block drains its own stores (vmcnt(0) + barrier) before it pushes the bundle --
+// no whole-L2 write-back or invalidate (the agent-scope release/acquire fences of a first version cost 31.6 vs 18.4 ms
+// with the full record).  ctl: [0..1] head, [2..3] pushed, [4..5] finished (64-bit counters), [6] stalled, [8..] entries
+// (64-bit: slices done so far << 32 | bundle + 1; 0 = not written yet).
+// Exit, reached by every block: its entry index is past everything that was or will be pushed (finished == NB + pushed,
+// read in that order: then nothing is in flight that could push), or past the queue's capacity, or a wait ran out.
+// (An earlier version handed out tickets for every (bundle, pass) pair: blocks racing through the tickets of dead
+// bundles cost 0.5 ms on a balanced fan.)
 __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
 }
+__device__ __forceinline__ unsigned long long ld_u64(const unsigned long long* p) {
+    return uniform_u64(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
 template <typename T, int METHOD, bool ISO, bool LDS>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? RTMI_F32_WAVES : LDS ? (light_method(METHOD) ? RTMI_TILE_WAVES : heavy_method(METHOD) ? 2 : 3) : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES))
-void k_advance_sliced(BatchDev<T> a, int slice, int passes, unsigned* ctl) {
+void k_advance_sliced(BatchDev<T> a, int slice, unsigned long long capacity, unsigned long long* ctl) {
     __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
-    __shared__ unsigned long long s_ticket;
-    __shared__ unsigned s_word[2];
+    __shared__ unsigned long long s_entry;
     const unsigned long long NB = (unsigned long long)((a.R + 255) / 256);
-    unsigned long long* ticket = reinterpret_cast<unsigned long long*>(ctl);      // ctl[0..1]
-    unsigned* dead = ctl + 2;                                                     // bundles that have no live ray left
-    unsigned* stalled = ctl + 3;                                                  // set if a wait ran out (never expected)
-    unsigned* done = ctl + 4;                                                     // [NB] slices finished per bundle
-    const unsigned kDead = 0xffffffffu;
-    // The block's bookkeeping is done by wave 0 with all of its lanes (every lane the same address and value; the ticket
+    unsigned long long* head = ctl;
+    unsigned long long* pushed = ctl + 1;
+    unsigned long long* finished = ctl + 2;
+    unsigned long long* stalled = ctl + 3;
+    unsigned long long* entries = ctl + 4;                   // [capacity]: entry NB + j
+    const unsigned long long kStop = ~0ull;
+    // The block's bookkeeping is done by wave 0 with all of its lanes (every lane the same address and value; an atomic
     // add is 1 from lane 0 and 0 from the others): a branch on the wave index is scalar, whereas `if (threadIdx.x == 0)`
     // in front of a barrier had the compiler split this loop into a lane-0 loop around an other-lanes loop, with the
-    // barriers in the inner one -- lane 0 never came back for a second ticket.
+    // barriers in the inner one -- lane 0 never came back for a second entry.
     const bool wave0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) == 0;
-    const unsigned one = (threadIdx.x & 63) == 0 ? 1u : 0u;
+    const unsigned long long one = (threadIdx.x & 63) == 0 ? 1ull : 0ull;
     bool running = true;
     while (running) {
         if (wave0) {
-            const unsigned long long old = atomicAdd(ticket, (unsigned long long)one);
-            s_ticket = uniform_u64(old);                     // lane 0's return value is the ticket
-            s_word[0] = __hip_atomic_load(dead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            s_word[1] = __hip_atomic_load(stalled, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long i = uniform_u64(atomicAdd(head, one));          // lane 0's return value is the index
+            unsigned long long e = kStop;
+            if (ld_u64(stalled) == 0ull) {
+                if (i < NB) {
+                    e = i + 1ull;                                                     // slices done: 0
+                } else if (i - NB < capacity) {
+                    e = ld_u64(entries + (i - NB));
+                    for (unsigned spins = 0; e == 0ull && spins < (1u << 19); ++spins) {   // ~2 s: then report, do not hang
+                        const unsigned long long f = ld_u64(finished);
+                        const unsigned long long p = ld_u64(pushed + (f >> 63));     // address depends on f: read after it
+                        if (f == NB + p && i >= NB + p) { e = kStop; break; }         // nothing in flight, nothing left
+                        __builtin_amdgcn_s_sleep(RTMI_SLICED_SLEEP);
+                        e = ld_u64(entries + (i - NB));
+                    }
+                    if (e == 0ull) { __hip_atomic_store(stalled, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); e = kStop; }
+                } else {
+                    __hip_atomic_store(stalled, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // queue capacity (never expected)
+                }
+            }
+            s_entry = e;
         }
         __syncthreads();
         // block-uniform values read from LDS are pinned to scalar registers: the loop and its barriers must be uniform
         // control flow for the compiler too
-        const unsigned long long t = uniform_u64(s_ticket);
-        const unsigned ndead = __builtin_amdgcn_readfirstlane(s_word[0]), nstall = __builtin_amdgcn_readfirstlane(s_word[1]);
-        const bool stop = ndead >= (unsigned)NB || nstall != 0u || t >= NB * (unsigned long long)passes;
-        __syncthreads();                                     // the shared words are rewritten below / next round
-        if (stop) {
+        const unsigned long long e = uniform_u64(s_entry);
+        __syncthreads();                                     // s_entry is rewritten next round
+        if (e == kStop) {
             running = false;
         } else {
-            const long bundle = (long)(t % NB);
-            const unsigned pass = (unsigned)(t / NB);
+            const long bundle = (long)((e & 0xffffffffull) - 1ull);
+            const unsigned k = (unsigned)(e >> 32);           // slices this bundle has had
+            const int nsteps = k == 0u ? 4 * slice : k == 1u ? 2 * slice : slice;
+            const bool alive = advance_bundle<T, METHOD, ISO, LDS, false, true>(a, lds, bundle * 256, nsteps);
+            __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): this lane's state stores are acknowledged
+            const int any = __builtin_amdgcn_readfirstlane(__syncthreads_or(alive));
             if (wave0) {
-                unsigned d = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&done[bundle], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                // the block that holds this bundle's previous slice is running; the bound only turns a logic error into
-                // a reported failure (RTMI_ERR_STATE) instead of a hung device
-                for (unsigned spins = 0; d < pass && spins < (1u << 19); ++spins) {   // ~2 s
-                    __builtin_amdgcn_s_sleep(RTMI_SLICED_SLEEP);
-                    d = __builtin_amdgcn_readfirstlane(__hip_atomic_load(&done[bundle], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (any) {
+                    const unsigned long long slot = uniform_u64(atomicAdd(pushed, one));
+                    if (slot < capacity)
+                        __hip_atomic_store(entries + slot, ((unsigned long long)(k + 1u) << 32) | (unsigned long long)(bundle + 1),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);      // the entry before this slice counts as finished
                 }
-                if (d < pass) { __hip_atomic_store(stalled, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); d = kDead; }
-                s_word[0] = d;
-            }
-            __syncthreads();
-            const bool finished = __builtin_amdgcn_readfirstlane(s_word[0]) == kDead;   // no live ray left (or the wait was abandoned)
-            __syncthreads();
-            if (!finished) {
-                // state through device-scope accesses (ld_state / st_state); every lane's stores are acknowledged before
-                // the barrier, the flag is written after it
-                // long slices first (4x, 2x, then 1x `slice` steps): balance is decided at the end of a fan's life, and
-                // every slice costs an inter-slice latency
-                const int nsteps = pass == 0u ? 4 * slice : pass == 1u ? 2 * slice : slice;
-                const bool alive = advance_bundle<T, METHOD, ISO, LDS, false, true>(a, lds, bundle * 256, nsteps);
-                __builtin_amdgcn_s_waitcnt(0x0F70);          // vmcnt(0)
-                const int any = __builtin_amdgcn_readfirstlane(__syncthreads_or(alive));
-                if (wave0) {
-                    atomicAdd(dead, any ? 0u : one);
-                    __hip_atomic_store(&done[bundle], any ? pass + 1 : kDead, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
+                atomicAdd(finished, one);
             }
         }
     }
@@ -960,7 +968,7 @@ struct rtmi_batch {
     int persistent_blocks = 0;   // resident 256-thread blocks of the refill kernel on this device
     const void* kfn_sliced = nullptr;
     int sliced_blocks = 0;       // resident 256-thread blocks of the sliced kernel on this device
-    unsigned* sliced_ctl = nullptr;   // launch_mode 2: ticket counter [2 words], dead bundles [2 words], done[bundles]
+    unsigned long long* sliced_ctl = nullptr;   // launch_mode 2: head, pushed, finished, stalled, queue entries (k_advance_sliced)
     bool dirty = false;          // rows may hold data a re-run will not overwrite (set_state / set_per_ray since the last clear)
     bool dirty_state = false;    // rtmi_batch_set_state ran since create / reset
 };
@@ -1054,6 +1062,17 @@ static const void* pick_advance(const rtmi_batch* b) {
     if (b->vstep || !uniform_rows_ok(b))
         return b->p.dtype == RTMI_F64 ? advance_var_fn<double>(b->p.method, iso) : advance_var_fn<float>(b->p.method, iso);
     return b->p.dtype == RTMI_F64 ? advance_fn<double>(b->p.method, iso, lds) : advance_fn<float>(b->p.method, iso, lds);
+}
+// queue entries beyond the implicit first NB: every bundle is pushed back once per slice it survives
+static unsigned long long sliced_capacity(const rtmi_batch* b, int slice) {
+    const unsigned long long NB = ((unsigned long long)b->R + 255) / 256;
+    const long rest = (long)b->p.max_size - 6L * slice;
+    // + slack: at the end every idle block holds one index past the last entry
+    return NB * (unsigned long long)(2 + (rest > 0 ? (rest + slice - 1) / slice : 0)) + 8192;
+}
+static int sliced_steps(const rtmi_batch* b) {
+    const int s = b->p.slice_steps > 0 ? b->p.slice_steps : 256;
+    return s < (1 << 20) ? s : (1 << 20);
 }
 static const void* pick_sliced(const rtmi_batch* b) {
     const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
@@ -1187,7 +1206,7 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, b->kfn_sliced, 256, 0));
             b->sliced_blocks = cus * (per_cu > 0 ? per_cu : 1);
             if (getenv("RTMI_DEBUG")) fprintf(stderr, "rtmi: sliced kernel: %d CUs x %d resident blocks\n", cus, per_cu);
-            HIP_TRY(hipMalloc(&b->sliced_ctl, (4 + (Rz + 255) / 256) * sizeof(unsigned)));
+            HIP_TRY(hipMalloc(&b->sliced_ctl, (4 + sliced_capacity(b, sliced_steps(b))) * sizeof(unsigned long long)));
         }
         return batch_init_state(b, true);
     };
@@ -1400,10 +1419,10 @@ template <typename T> static void launch_refill(const rtmi_batch* b) {
     (void)hipLaunchKernel(b->kfn_refill, g, blk, args, 0, b->stream);
 }
 
-template <typename T> static void launch_sliced(const rtmi_batch* b, int slice, int passes) {
+template <typename T> static void launch_sliced(const rtmi_batch* b, int slice, unsigned long long capacity) {
     BatchDev<T> a = batch_dev<T>(b);
-    unsigned* ctl = b->sliced_ctl;
-    void* args[] = {&a, &slice, &passes, &ctl};
+    unsigned long long* ctl = b->sliced_ctl;
+    void* args[] = {&a, &slice, &capacity, &ctl};
     const long need = (b->R + 255) / 256;
     const dim3 g((unsigned)(need < b->sliced_blocks ? need : b->sliced_blocks)), blk(256);
     (void)hipLaunchKernel(b->kfn_sliced, g, blk, args, 0, b->stream);
@@ -1419,22 +1438,21 @@ RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
         std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
         rc = next_event_pair(b, &ev);
         if (rc) return rc;
-        const int slice = b->p.slice_steps > 0 ? (b->p.slice_steps < (1 << 20) ? b->p.slice_steps : (1 << 20)) : 256;
-        // the first two slices of a bundle are 4 and 2 slices long (k_advance_sliced)
-        const long rest = (long)b->p.max_size - 6L * slice;
-        const int passes = 2 + (int)(rest > 0 ? (rest + slice - 1) / slice : 0);
-        HIP_TRY(hipMemsetAsync(b->sliced_ctl, 0, (4 + ((size_t)b->R + 255) / 256) * sizeof(unsigned), b->stream));
+        const int slice = sliced_steps(b);
+        const unsigned long long capacity = sliced_capacity(b, slice);
+        HIP_TRY(hipMemsetAsync(b->sliced_ctl, 0, (4 + capacity) * sizeof(unsigned long long), b->stream));
         HIP_TRY(hipEventRecord(ev->first, b->stream));
-        if (b->p.dtype == RTMI_F64) launch_sliced<double>(b, slice, passes);
-        else launch_sliced<float>(b, slice, passes);
+        if (b->p.dtype == RTMI_F64) launch_sliced<double>(b, slice, capacity);
+        else launch_sliced<float>(b, slice, capacity);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev->second, b->stream));
         b->launches++;
         rc = read_counters(b);
         if (rc) return rc;
-        unsigned ctl4[4] = {0, 0, 0, 0};
+        unsigned long long ctl4[4] = {0, 0, 0, 0};
         HIP_TRY(hipMemcpy(ctl4, b->sliced_ctl, sizeof(ctl4), hipMemcpyDeviceToHost));
-        if (ctl4[3] != 0) return fail(RTMI_ERR_STATE, "rtmi_run: the sliced launch abandoned a wait for a bundle's previous slice");
+        if (ctl4[3] != 0) return fail(RTMI_ERR_STATE, ctl4[3] == 1 ? "rtmi_run: the sliced launch abandoned a wait for a queue entry"
+                                                                  : "rtmi_run: the sliced launch ran out of queue entries");
         if (b->h_counters[1] != 0) return fail(RTMI_ERR_STATE, "rtmi_run: rays still live after the sliced launch");
         return RTMI_OK;
     }
