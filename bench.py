@@ -120,10 +120,12 @@ def main():
     ap.add_argument("--n-ray", action="store_true",
                     help="also keep n_ray rows (coef*n per row): internal to the reference's trazar (RT_bench.py:803), not among "
                          "its return values (:948), so off by default")
-    ap.add_argument("--mode", default="lane", choices=["lane", "refill", "sliced"],
-                    help="lane: one lane per ray; refill: persistent waves with ballot/prefix lane refill; "
-                         "sliced: persistent blocks advancing 256-ray bundles in time slices (launch_mode 2)")
-    ap.add_argument("--slice-steps", type=int, default=0, help="--mode sliced: DELTA_S steps per slice (0 = 256)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "lane", "refill", "sliced"],
+                    help="lane: one block slot per 256 rays to completion; refill: persistent waves with ballot/prefix "
+                         "lane refill; sliced: persistent blocks advancing 256-ray bundles in time slices (launch_mode 2); "
+                         "auto (default): sliced for fp64 batches run to completion (level with or ahead of lane on "
+                         "every fp64 configuration measured, DESIGN.md 5.1/5.3), lane otherwise")
+    ap.add_argument("--slice-steps", type=int, default=0, help="--mode sliced: DELTA_S steps per slice (0 = 512 here)")
     ap.add_argument("--order", default="fan", choices=["fan", "shuffled"],
                     help="ray order inside the batch: the sorted fan, or a seeded random permutation of it")
     ap.add_argument("--refill-min", type=int, default=0)
@@ -144,6 +146,10 @@ def main():
     args = ap.parse_args()
     if args.method is None:
         args.method = 11 if args.scenario == "anisotropy" else 6
+    if args.mode == "auto":
+        args.mode = "sliced" if args.dtype == "f64" and args.chunk <= 0 else "lane"
+    if args.mode == "sliced" and args.slice_steps <= 0:
+        args.slice_steps = 512
 
     import torch
     import torch.distributed as dist
@@ -226,7 +232,18 @@ def main():
             if batch.stats()["live_rays"] == 0:
                 break
 
-    for _ in range(args.warmup):
+    try:
+        one_pass()                                # untimed trial pass (also the first warm-up pass)
+    except _lib.RtmiError as e:
+        if args.mode != "sliced":
+            raise
+        # launch_mode 2 bounds its waits and reports instead of hanging; fall back to the plain launch
+        print(f"bench.py: sliced launch failed ({e}); falling back to --mode lane", file=sys.stderr)
+        args.mode = "lane"
+        batch.close()
+        batch = make_batch(stride, rec_rows)
+        one_pass()
+    for _ in range(max(args.warmup - 1, 0)):
         one_pass()
     barrier()
     t0 = time.perf_counter()
@@ -266,6 +283,8 @@ def main():
         balg = alg_bytes_per_step(args.dtype, stride)
         ksec = kern_ms * 1e-3
         key = f"{args.scenario}:{R_local}:{args.record}{'+n_ray' if args.n_ray and stride else ''}:{args.dtype}:op{args.method}"
+        if args.mode != "lane":
+            key += ":" + args.mode            # profiles/traffic.json keeps the other launch modes under their own keys
         prof = {}
         try:
             prof = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}) or {}
@@ -273,7 +292,7 @@ def main():
             prof = {}
         if not isinstance(prof, dict):        # round-1 format: a bare byte count
             prof = {"hbm_bytes": prof, "source": "profiles/r01_f_head_pmc_summary.txt"}
-        measured = prof.get("hbm_bytes") if args.chunk <= 0 and args.mode == "lane" else None
+        measured = prof.get("hbm_bytes") if args.chunk <= 0 else None
         model = min_hbm_bytes(args.dtype, stride, steps_per_pass, R_local, args.method, args.n_ray)
         hbm_bytes = measured if measured else model
         hbm = {"achieved": hbm_bytes / ksec / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
