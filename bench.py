@@ -123,7 +123,7 @@ def main():
     ap.add_argument("--mode", default="auto", choices=["auto", "lane", "refill", "sliced"],
                     help="lane: one block slot per 256 rays to completion; refill: persistent waves with ballot/prefix "
                          "lane refill; sliced: persistent blocks advancing 256-ray bundles in time slices (launch_mode 2); "
-                         "auto (default): sliced for fp64 fans whose rays differ in length (vert, fisheye, anisotropy; "
+                         "auto (default): sliced for fans whose rays differ in length (vert, fisheye, anisotropy; "
                          "DESIGN.md 5.1/5.3), lane otherwise")
     ap.add_argument("--slice-steps", type=int, default=0, help="--mode sliced: DELTA_S steps per slice (0 = 512 here)")
     ap.add_argument("--order", default="fan", choices=["fan", "shuffled"],
@@ -148,8 +148,8 @@ def main():
         args.method = 11 if args.scenario == "anisotropy" else 6
     if args.mode == "auto":
         # time slicing pays where rays differ in length (vert, fisheye, anisotropy fans); the interface fan's rays are all
-        # about equally long and the plain launch is 3-7 % ahead there, as it is for fp32 (a fatter sliced build)
-        args.mode = "sliced" if args.dtype == "f64" and args.chunk <= 0 and args.scenario != "interface" else "lane"
+        # about equally long and the plain launch is 3-7 % ahead there
+        args.mode = "sliced" if args.chunk <= 0 and args.scenario != "interface" else "lane"
     if args.mode == "sliced" and args.slice_steps <= 0:
         args.slice_steps = 512
 

@@ -592,6 +592,9 @@ constexpr bool heavy_method(int m) { return m == 4 || m == 5 || m >= 9; }
 #ifndef RTMI_SLICED_SLEEP
 #define RTMI_SLICED_SLEEP 32   // s_sleep argument (x64 clocks) between two polls of a bundle's slice counter
 #endif
+#ifndef RTMI_F32_SLICED_WAVES
+#define RTMI_F32_SLICED_WAVES 5   // the fp32 k_advance fits five waves per SIMD by itself (94 VGPRs); the sliced build has to be told
+#endif
 #ifndef RTMI_F32_WAVES
 #define RTMI_F32_WAVES 4       // waves per SIMD the fp32 builds of k_advance are compiled for
 #endif
@@ -774,7 +777,7 @@ __device__ __forceinline__ unsigned long long ld_u64(const unsigned long long* p
     return uniform_u64(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
 template <typename T, int METHOD, bool ISO, bool LDS>
-__global__ __launch_bounds__(256, sizeof(T) == 4 ? RTMI_F32_WAVES : LDS ? (light_method(METHOD) ? RTMI_TILE_WAVES : heavy_method(METHOD) ? 2 : 3) : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES))
+__global__ __launch_bounds__(256, sizeof(T) == 4 ? RTMI_F32_SLICED_WAVES : LDS ? (light_method(METHOD) ? RTMI_TILE_WAVES : heavy_method(METHOD) ? 2 : 3) : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES))
 void k_advance_sliced(BatchDev<T> a, int slice, unsigned long long capacity, unsigned long long* ctl) {
     __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
     __shared__ unsigned long long s_entry;
