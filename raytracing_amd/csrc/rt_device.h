@@ -563,8 +563,8 @@ template <typename T> struct LdsGather {
     }
 
     // fetch + field_combine.  With every lane in the tile the window is read and summed in RTMI_TILE_PHASES groups of rows
-    // (same sums in the same order as field_combine, so the same bits): 8 LDS reads in flight instead of 16, 146 instead of
-    // 182 VGPRs, i.e. three waves per SIMD without spilling (A/B in one session: 22.9 vs 24.8 ms with the full record).
+    // (same sums in the same order as field_combine, so the same bits).  Row by row (RTMI_TILE_PHASES 4): 4 LDS reads in
+    // flight instead of 16 and 128 instead of 182 VGPRs, i.e. four waves per SIMD without spilling for op2/op6.
     __device__ __forceinline__ void lookup(const FieldDev<T>& F, const Cell<T>& c, bool active, T& n, T& gx, T& gy) {
         int cx, cy;
         const bool fits = place(F, c, active, cx, cy);

@@ -1042,9 +1042,7 @@ template <typename T> static const void* refill_fn(int m, bool iso, bool lds) {
 #undef RTMI_ADV_
 #undef RTMI_ADVVAR_
 #undef RTMI_REFILL_
-// field_path 0 (auto): the LDS tile pays when the step loop also streams trajectory rows (its lookups then stay off
-// the vector-memory queue the stores occupy: 27.0 vs 29.0 ms at full record); without dense recording the plain
-// gather is ahead (18.9 vs 20.3 ms) because the kernel is VALU-bound and the tile costs ~25 integer instructions.
+// field_path 0 (auto): which gather policy the step kernels are built with.
 static bool use_lds_tile(const rtmi_batch* b) {
     if (b->p.field_path == 1) return false;
     if (b->p.field_path == 2) return true;
