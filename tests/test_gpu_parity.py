@@ -313,6 +313,38 @@ def test_sliced_bundles_are_bit_identical(scen, m, dtype, slice_steps, stride, r
     a.close(); b.close()
 
 
+def test_sliced_bundles_randomised(rb, gpu_fields):
+    """launch_mode 2 vs the plain launch over seeded random shapes: ray counts from 1 to 300 000, slices from 1 to 5 000
+    steps, methods of every class, record strides 0 / 1 / 5, sorted and shuffled fans, both precisions."""
+    rng = np.random.default_rng(2026)
+    for case in range(18):
+        scen = ["vert_heterogeneous", "fisheye", "interface"][case % 3]
+        m = int(rng.choice([1, 2, 6, 7, 8, 9, 3]))
+        dt = rb.F32 if (case % 7 == 3 and m in (1, 2, 6, 7, 8)) else rb.F64
+        R = int(rng.choice([1, 63, 257, 1000, 5000, 40000, 300000])) if m not in (9, 3) else int(rng.choice([1, 300, 3000]))
+        sl = int(rng.choice([1, 7, 50, 128, 333, 1024, 5000]))
+        stride = int(rng.choice([0, 1, 5]))
+        if scen == "fisheye":
+            th = np.sort(rng.uniform(np.pi / 4, 3 * np.pi / 4, R)); x0, y0, step, ms = 1.0, 0.0, 2 * np.pi / 303, 3040
+        else:
+            th = np.sort(rng.uniform(0.06, np.pi / 2, R)); x0, y0, step = -2.0, -2.0, rb.DELTA_S
+            ms = 4000 if scen == "vert_heterogeneous" else 6000
+        if rng.random() < 0.3:
+            th = rng.permutation(th)
+        kw = dict(record_stride=stride, rec_rows=min(ms, 1200) if stride == 1 and R > 20000 else 0)
+        F = gpu_fields(scen, dt)
+        a = rb.Batch(F, m, step, ms, LIMITS[scen], 1, th, x0, y0, **kw)
+        a.run()
+        b = rb.Batch(F, m, step, ms, LIMITS[scen], 1, th, x0, y0, launch_mode=2, slice_steps=sl, **kw)
+        b.run()
+        tag = f"case {case}: {scen} op{m} R={R} slice={sl} stride={stride}"
+        assert b.stats()["live_rays"] == 0, tag
+        assert np.array_equal(a.d_ray(), b.d_ray()) and np.array_equal(a.final(), b.final()), tag
+        if stride and R <= 40000:
+            assert np.array_equal(a.rows(), b.rows()), tag
+        a.close(); b.close()
+
+
 def test_sliced_bundles_more_bundles_than_resident_blocks(rb, gpu_fields):
     """launch_mode 2 with 1 954 bundles for at most 1 024 resident blocks and short slices: tickets of one bundle are drawn
     by different blocks while its previous slice may still be running elsewhere (the per-bundle ordering), bundles die at
