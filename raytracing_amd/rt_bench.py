@@ -527,14 +527,15 @@ def moment_cv(s_ray, ray_count=None):
 
 
 def trazar(selected_func, z, grd, show, step, divisor, user_choice, *, thetas=None, starts=None, box=None,
-           gamma=None, max_size=None, record="full", return_batch=False):
+           gamma=None, max_size=None, record="full", return_batch=False, launch_mode="auto"):
     """RT_bench.py:766-948 on the GPU.  Positional arguments and the returned
     (s_ray[max_size,6,R], d_ray[3,R], compute_times[R], errors[R]) are the reference's.
 
     Keyword extensions for synthetic batches: thetas / starts ((R,2) or (2,)) / box / gamma / max_size replace
     the preset of `user_choice`; record = "full" (reference layout), an int stride, or None (s_ray is None).
     compute_times holds the device propagation time split evenly over rays, so np.sum(compute_times) is the
-    quantity the reference's benchmark reads (:1526).
+    quantity the reference's benchmark reads (:1526).  launch_mode: 0 / 1 / 2 as in rtmi_params, or "auto": time-sliced
+    bundles (2) for large batches of the fans whose rays differ in length, the plain launch otherwise -- same bits.
     """
     g, ray_count, theta_v, pos_x, s, limx_i, limx_s, limy_i, limy_s, op_if, op_fish, _, _ = constants(user_choice)
     fld = _field_of(z, grd)
@@ -557,8 +558,11 @@ def trazar(selected_func, z, grd, show, step, divisor, user_choice, *, thetas=No
     if max_size is None:
         max_size = N * divisor if op_fish else int(np.ceil(s / step) + 1)   # :796-799
     stride = 0 if record is None else (1 if record == "full" else int(record))
+    if launch_mode == "auto":
+        launch_mode = 2 if (ray_count >= 65536 and not op_if) else 0
     b = Batch(fld, selected_func, step, max_size, box, gamma, theta_v[:ray_count], x0, y0, record_stride=stride,
-              sort_rays="auto", keep_n_ray=False)          # n_ray is internal to the reference's trazar (:803), never returned
+              sort_rays="auto", keep_n_ray=False,          # n_ray is internal to the reference's trazar (:803), never returned
+              launch_mode=int(launch_mode), slice_steps=512 if int(launch_mode) == 2 else 0)
     t1 = time.perf_counter()
     b.run()
     b.sync()

@@ -313,6 +313,15 @@ def test_sliced_bundles_are_bit_identical(scen, m, dtype, slice_steps, stride, r
     a.close(); b.close()
 
 
+def test_trazar_auto_launch_mode_is_the_plain_launch_bit_for_bit(rb, gpu_fields):
+    """The reference call surface picks launch_mode 2 by itself for large batches; the return values must not notice."""
+    F = gpu_fields("vert_heterogeneous")
+    z, grd = rb.FieldSpline(F, "n"), (rb.FieldSpline(F, "dy"), rb.FieldSpline(F, "dx"))
+    th = np.linspace(0.0, np.pi / 2, 70000)
+    outs = [rb.trazar(rb.op6, z, grd, False, rb.DELTA_S, 91, "3", thetas=th, record=16, launch_mode=lm) for lm in ("auto", 0)]
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+
+
 def test_sliced_bundles_randomised(rb, gpu_fields):
     """launch_mode 2 vs the plain launch over seeded random shapes: ray counts from 1 to 300 000, slices from 1 to 5 000
     steps, methods of every class, record strides 0 / 1 / 5, sorted and shuffled fans, both precisions."""
