@@ -450,6 +450,24 @@ template <typename T> struct GlobalGather {
     __device__ __forceinline__ void lookup(const FieldDev<T>& F, const Cell<T>& c, bool active, T& n, T& gx, T& gy);
 };
 
+// Wave-wide min / max of an int, returned wave-uniform.  DPP row shifts and row broadcasts (an inclusive scan within each
+// row of 16, then rows 0/2 into 1/3 and the lower half into the upper) leave the result in lane 63: six v_min/v_max with
+// a DPP operand and one v_readlane, instead of six ds_bpermute round trips through the LDS crossbar (__shfl_xor).
+#ifndef RTMI_SHFL_REDUCE
+template <bool MIN> __device__ __forceinline__ int wave_reduce_i(int v) {
+    constexpr int ident = MIN ? 0x7fffffff : (int)0x80000000;
+    auto op = [](int a, int b) { return MIN ? (b < a ? b : a) : (b > a ? b : a); };
+    v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x111, 0xf, 0xf, false));   // row_shr:1
+    v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x112, 0xf, 0xf, false));   // row_shr:2
+    v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x114, 0xf, 0xf, false));   // row_shr:4
+    v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x118, 0xf, 0xf, false));   // row_shr:8
+    v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x142, 0xa, 0xf, false));   // row_bcast:15 into rows 1 and 3
+    v = op(v, __builtin_amdgcn_update_dpp(ident, v, 0x143, 0xc, 0xf, false));   // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_min_i(int v) { return wave_reduce_i<true>(v); }
+__device__ __forceinline__ int wave_max_i(int v) { return wave_reduce_i<false>(v); }
+#else
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
@@ -460,6 +478,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
     for (int o = 32; o > 0; o >>= 1) { const int w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
     return v;
 }
+#endif
 
 // Gather policy 2: a wave-private LDS tile of the field.  The rays of a wave travel together (they leave one
 // origin with neighbouring angles), so their 4x4 windows overlap almost completely and move ~0.15 cell per step:
