@@ -506,16 +506,21 @@ template <typename T> struct LdsGather {
     }
 
     __device__ __forceinline__ void stage(const FieldDev<T>& F) {
-        const unsigned lane = __lane_id();
-        const Pair<T>* gsrc = reinterpret_cast<const Pair<T>*>(F.g);
+        // lane l copies tile column l % 16 of rows l / 16, +4, +8, +12: one source offset, then a constant stride
+        const int lane = (int)__lane_id(), row0 = lane >> 4, col = lane & 15;
+        const size_t src0 = (size_t)(oy + row0) * F.qx + (size_t)(ox + col), stride = (size_t)4 * F.qx;
+        const Pair<T>* gp = reinterpret_cast<const Pair<T>*>(F.g) + src0;
+        const T* zp = F.zn + src0;
+        RT_LDS Pair<T>* gl = gt + (row0 * GPITCH + col);
+        RT_LDS T* zl = zt + (row0 * ZPITCH + col);
+        static_assert(TILE == 16, "stage() copies 4 rows per pass with 64 lanes");
         __builtin_amdgcn_wave_barrier();
+        Pair<T> gv[4];
+        T zv[4];
 #pragma unroll
-        for (int q = 0; q < TILE * TILE / 64; q++) {
-            const int p = (int)lane + 64 * q, row = p / TILE, col = p % TILE;
-            const size_t src = (size_t)(oy + row) * F.qx + (ox + col);
-            gt[row * GPITCH + col] = gsrc[src];
-            zt[row * ZPITCH + col] = F.zn[src];
-        }
+        for (int q = 0; q < 4; q++) { gv[q] = gp[q * stride]; zv[q] = zp[q * stride]; }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { gl[q * 4 * GPITCH] = gv[q]; zl[q * 4 * ZPITCH] = zv[q]; }
         __builtin_amdgcn_wave_barrier();
     }
 
