@@ -38,7 +38,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured for a float4 copy)
-HBM_FILL_GBS = 6730.0            # profiles/r02_e_hbm_write_ceiling.txt: a bare fill kernel writing the record's rows in k_advance's pattern
+HBM_FILL_GBS = 6730.0            # profiles/r02_f_hbm_write_ceiling.txt: a bare fill kernel writing the record's rows in k_advance's pattern
 SIMDS = 256 * 4                  # CUs x SIMDs
 PEAK_CLOCK_HZ = 2.4e9            # MI355X_MICROARCH.md: max clock
 SCEN = {"vert_heterogeneous": dict(choice="3", theta=(0.0, np.pi / 2), start=(-2.0, -2.0), gamma=1),
@@ -303,7 +303,7 @@ def main():
                "bytes_source": prof.get("source") if measured else "model: recorded rows x 6 values (7 with n_ray) + ray state in and out"}
         if stride:   # secondary yardstick for the row stream: what a write-only kernel reaches on this memory system
             hbm["write_only_ceiling"] = {"peak": HBM_FILL_GBS, "unit": "GB/s", "frac": hbm_bytes / ksec / 1e9 / HBM_FILL_GBS,
-                                         "source": "profiles/r02_e_hbm_write_ceiling.txt (tools/hbm_fill.hip)"}
+                                         "source": "profiles/r02_f_hbm_write_ceiling.txt (tools/hbm_fill.hip)"}
         roof = dict(hbm, bound="hbm", traffic=measured, traffic_source=prof.get("source") if measured else None)
         roof.pop("write_only_ceiling", None)
         # vector-ALU issue time from the profiled instruction counts: a 64-lane fp64 instruction holds a SIMD for 4 cycles
