@@ -1207,6 +1207,10 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, b->kfn_sliced, 256, 0));
             b->sliced_blocks = cus * (per_cu > 0 ? per_cu : 1);
             if (getenv("RTMI_DEBUG")) fprintf(stderr, "rtmi: sliced kernel: %d CUs x %d resident blocks\n", cus, per_cu);
+            // one queue entry per slice a bundle survives: tiny slices on a large batch with a large max_size would ask for
+            // gigabytes of queue (and a memset of it per run); refuse beyond 256 MB
+            ARG_TRY(sliced_capacity(b, sliced_steps(b)) <= (1ull << 25),
+                    "rtmi_batch_create: launch_mode 2: slice_steps too small for this batch size and max_size (queue > 256 MB)");
             HIP_TRY(hipMalloc(&b->sliced_ctl, (4 + sliced_capacity(b, sliced_steps(b))) * sizeof(unsigned long long)));
         }
         return batch_init_state(b, true);
