@@ -15,7 +15,17 @@ Multi-GPU (one process per GPU, no data-path collective -- rays are independent)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
       bench.py --gpus N --steps K --warmup W [--total-rays 1048576]
 
+Single-GPU rehearsals of the N-GPU run (no torch.distributed involved):
+  --emulate-world N --emulate-rank r   run rank r's shard of the N-way split on this GPU: the per-GPU operating point of an
+                    N-GPU run (there is no collective in the timed region, so the per-shard rate IS the scaling curve)
+  --force-dist      initialise torch.distributed (--backend nccl = RCCL) with world_size 1 and run the all_reduce / gather
+                    of the N>1 path through it: the part of the multi-GPU path one MI355X can execute
+
 Rank 0 prints ONE JSON line.
+  parity_check  after the timed passes: every 512th ray of the batch that was just timed (d_ray, final state and -- with a
+                full record -- every recorded row, read from the device copy) against the CPU oracle on the same launch
+                angles; the run exits non-zero if a step count differs or an fp64 value is further than 1e-9 (relative)
+                from the oracle's.
   roofline      what bounds the advance kernel, as a fraction <= 1 of a hardware peak: HBM bytes per launch (rocprofv3
                 counters, profiles/traffic.json; or, without a profile of this configuration, the bytes the launch must
                 write and read: recorded rows + state) over the kernel time measured here with HIP events, against
@@ -98,6 +108,47 @@ def cpu_baseline(args, rb, budget_s, rays):
                       f"{dt:.2f} s, OpenMP over rays, final-state mode"}
 
 
+def parity_check(args, rb, batch, th, stride, step, max_size, lim):
+    """The batch that was just timed against the oracle: every args.parity_stride-th ray -- step counts (exactly), d_ray and
+    final state, and with a dense record every recorded row of those rays, read from the device copy.  fp64: 1e-9 relative
+    (|a - b| / max(|b|, 1), the tolerance of tests/test_gpu_parity.py); fp32 has no reference and is only reported."""
+    from oracle import rt_oracle as O
+    sc = SCEN[args.scenario]
+    sub = slice(0, len(th), args.parity_stride)
+    ths = np.ascontiguousarray(th[sub])
+    fld = O.Field("vert_heterogeneous" if args.scenario == "anisotropy" else args.scenario, lim, rb.DELTA)
+    want_rows = stride > 0
+    rec_rows = batch.rec_rows
+    o = O.trazar(fld, args.method, sc["gamma"], step, max_size, lim, sc["start"][0], sc["start"][1], ths,
+                 record_stride=stride, rec_rows=rec_rows if want_rows else None,
+                 nthreads=min(O.max_threads(), os.cpu_count() or 1))
+    d = batch.d_ray()[:, sub]
+    fin = batch.final()[:, sub]
+
+    def rel(a, b):
+        return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0))) if a.size else 0.0
+    steps_equal = bool(np.array_equal(d[2], o["d_ray"][2]))
+    same = d[2] == o["d_ray"][2]
+    err = max(rel(fin[:, same], o["final"][:, same]), rel(d[:2, same], o["d_ray"][:2, same]))
+    out = {"rays": int(len(ths)), "every": args.parity_stride, "steps_equal": steps_equal,
+           "rays_with_equal_steps": int(same.sum()), "max_rel_err": err, "oracle": "oracle/rt_oracle.c (kind: port)"}
+    if want_rows:
+        import torch
+        s_dev = batch.device_tensors()["s_ray"][:, :, sub]                   # strided view of the device record
+        s = s_dev.to(torch.float64).cpu().numpy()
+        out["rows_compared"] = int(s.shape[0])
+        out["rows_max_rel_err"] = rel(s[:, :, same], o["s_ray"][:, :, same])
+        # rows past a ray's last written row must read 0 like the reference's np.zeros (RT_bench.py:802)
+        last = (d[2] // stride).astype(np.int64)
+        tail_ok = all(not s[int(last[k]) + 1:, :, k].any() for k in range(0, len(ths), max(1, len(ths) // 64)))
+        out["rows_beyond_last_are_zero"] = bool(tail_ok)
+        err = max(err, out["rows_max_rel_err"])
+    tol = 1e-9 if args.dtype == "f64" else None
+    out["tolerance"] = tol
+    out["ok"] = bool(tol is None or (steps_equal and err < tol and out.get("rows_beyond_last_are_zero", True)))
+    return out
+
+
 def trace_step(args, rb):
     c = rb.constants(SCEN[args.scenario]["choice"])
     if args.scenario == "fisheye":
@@ -120,12 +171,12 @@ def main():
     ap.add_argument("--n-ray", action="store_true",
                     help="also keep n_ray rows (coef*n per row): internal to the reference's trazar (RT_bench.py:803), not among "
                          "its return values (:948), so off by default")
-    ap.add_argument("--mode", default="auto", choices=["auto", "lane", "refill", "sliced"],
-                    help="lane: one block slot per 256 rays to completion; refill: persistent waves with ballot/prefix "
-                         "lane refill; sliced: persistent blocks advancing 256-ray bundles in time slices (launch_mode 2); "
-                         "auto (default): sliced for fans whose rays differ in length (vert, fisheye, anisotropy; "
-                         "DESIGN.md 5.1/5.3), lane otherwise")
-    ap.add_argument("--slice-steps", type=int, default=0, help="--mode sliced: DELTA_S steps per slice (0 = 512 here)")
+    ap.add_argument("--mode", default="auto", choices=["auto", "lane", "plain", "refill", "sliced"],
+                    help="auto (default): rtmi_params' own default, RTMI_LAUNCH_AUTO -- the library picks between the "
+                         "time-sliced and the plain schedule and keeps the faster on re-runs; plain (= lane): one block slot "
+                         "per 256 rays to completion; refill: persistent waves with ballot/prefix lane refill; sliced: "
+                         "persistent blocks advancing 256-ray bundles in time slices")
+    ap.add_argument("--slice-steps", type=int, default=0, help="time-sliced schedule: DELTA_S steps per slice (0 = the library's 512)")
     ap.add_argument("--order", default="fan", choices=["fan", "shuffled"],
                     help="ray order inside the batch: the sorted fan, or a seeded random permutation of it")
     ap.add_argument("--refill-min", type=int, default=0)
@@ -143,15 +194,17 @@ def main():
                          "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--all-on-device", type=int, default=None,
                     help="rehearsal only: every rank uses this HIP device instead of LOCAL_RANK")
+    ap.add_argument("--emulate-world", type=int, default=0,
+                    help="single GPU, no torch.distributed: run the shard rank --emulate-rank would own in a world of this size")
+    ap.add_argument("--emulate-rank", type=int, default=0)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed even with one rank and run the N>1 collectives through it")
+    ap.add_argument("--parity-stride", type=int, default=512, help="parity_check: every this-many-th ray (0 = skip)")
     args = ap.parse_args()
     if args.method is None:
         args.method = 11 if args.scenario == "anisotropy" else 6
-    if args.mode == "auto":
-        # time slicing pays where rays differ in length (vert, fisheye, anisotropy fans); the interface fan's rays are all
-        # about equally long and the plain launch is 3-7 % ahead there
-        args.mode = "sliced" if args.chunk <= 0 and args.scenario != "interface" else "lane"
-    if args.mode == "sliced" and args.slice_steps <= 0:
-        args.slice_steps = 512
+    if args.mode == "lane":
+        args.mode = "plain"
 
     import torch
     import torch.distributed as dist
@@ -167,12 +220,22 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     cdev = dev if args.backend == "nccl" else torch.device("cpu")     # where the collectives' tensors live
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        kw = {} if world > 1 else dict(rank=0, world_size=1)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, **kw)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", **kw)
+    if args.emulate_world:
+        if world != 1:
+            sys.exit("bench.py: --emulate-world is a single-process rehearsal (run it with --gpus 1)")
+        if not 0 <= args.emulate_rank < args.emulate_world:
+            sys.exit("bench.py: --emulate-rank must be in [0, --emulate-world)")
+    # the partition this process computes: its own rank of the real world, or one rank of an emulated one
+    part_world, part_rank = (args.emulate_world, args.emulate_rank) if args.emulate_world else (world, rank)
 
     from raytracing_amd import rt_bench as rb
     from raytracing_amd import _lib
@@ -188,8 +251,8 @@ def main():
     if stride and not rec_rows and args.scenario in ("vert_heterogeneous", "anisotropy"):
         rec_rows = (3072 + stride - 1) // stride     # the fan's longest ray takes 2 938 steps
     strong = args.total_rays > 0
-    R_total = args.total_rays if strong else args.rays * world
-    th = fan(args.scenario, R_total, rank, world)    # rank r owns rays r, r+world, ... of the R_total-ray fan
+    R_total = args.total_rays if strong else args.rays * part_world
+    th = fan(args.scenario, R_total, part_rank, part_world)    # rank r owns rays r, r+world, ... of the R_total-ray fan
     R_local = len(th)
     if args.order == "shuffled":
         th = np.random.default_rng(1234 + rank).permutation(th)
@@ -198,7 +261,7 @@ def main():
     def make_batch(stride_, rec_rows_):
         return rb.Batch(fld, args.method, step, max_size, lim, sc["gamma"], th, sc["start"][0], sc["start"][1],
                         record_stride=stride_, rec_rows=rec_rows_, block_size=args.block,
-                        launch_mode={"lane": 0, "refill": 1, "sliced": 2}[args.mode], refill_min=args.refill_min, slice_steps=args.slice_steps,
+                        launch_mode=args.mode, refill_min=args.refill_min, slice_steps=args.slice_steps,
                         field_path={"auto": 0, "global": 1, "lds": 2}[args.field_path], sort_rays=args.sort,
                         lazy_clear=True,    # every pass re-runs the same launch conditions: same rows rewritten
                         keep_n_ray=args.n_ray)
@@ -216,7 +279,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -234,18 +297,9 @@ def main():
             if batch.stats()["live_rays"] == 0:
                 break
 
-    try:
-        one_pass()                                # untimed trial pass (also the first warm-up pass)
-    except _lib.RtmiError as e:
-        if args.mode != "sliced":
-            raise
-        # launch_mode 2 bounds its waits and reports instead of hanging; fall back to the plain launch
-        print(f"bench.py: sliced launch failed ({e}); falling back to --mode lane", file=sys.stderr)
-        args.mode = "lane"
-        batch.close()
-        batch = make_batch(stride, rec_rows)
-        one_pass()
-    for _ in range(max(args.warmup - 1, 0)):
+    # untimed passes: --warmup of them, at least two -- RTMI_LAUNCH_AUTO times one run under each of its two schedules
+    # (rtmi_params.launch_mode) before it settles on the faster, and that belongs to the warm-up, not to the timed region
+    for _ in range(max(args.warmup, 2)):
         one_pass()
     barrier()
     t0 = time.perf_counter()
@@ -258,7 +312,10 @@ def main():
     steps_per_pass = st["ray_steps"]
     kern_ms = st["kernel_ms"]                # all advance launches of the pass together
     launches = max(st["launches"], 1)
-    if world > 1:
+    mode_used = st["launch_mode_used"] if args.chunk <= 0 else "plain"
+    gathered = None
+    parity_failed = False
+    if use_dist:
         dt = rd.max_over_ranks(dt, cdev)
         total_steps = rd.sum_over_ranks(steps_per_pass, cdev) * args.steps
         # Read-back of the sharded layout (outside the timed region): d_ray = (dist_real, dist_sim, last row) and the
@@ -267,17 +324,20 @@ def main():
             t_ = batch.device_tensors()
             loc = torch.stack((t_["dist_real"].double(), t_["dist_sim"].double(), t_["istep"].double(),
                                t_["x"].double(), t_["y"].double())).to(cdev)            # [5, R_local]
-            Rmax = (R_total + world - 1) // world
+            Rmax = (R_total + world - 1) // world if not args.emulate_world else R_local
             if loc.shape[1] < Rmax:                                                      # ragged strong split: pad
                 loc = torch.cat((loc, torch.full((5, Rmax - loc.shape[1]), float("nan"), dtype=loc.dtype, device=loc.device)), 1)
             g = [torch.empty_like(loc) for _ in range(world)] if rank == 0 else None
             dist.gather(loc.contiguous(), g, dst=0)
             if rank == 0:
-                allr = rd.interleave(g, R_total)                                         # ray k*world + r  <-  rank r, slot k
+                allr = rd.interleave(g, R_local if args.emulate_world else R_total)                                      # ray k*world + r  <-  rank r, slot k
                 assert int(allr[2].sum().item()) * args.steps == total_steps
                 assert torch.isfinite(allr[3:5]).all()
+                gathered = {"rays": int(allr.shape[1]), "backend": args.backend, "world": world,
+                            "bytes_per_rank": int(loc.numel() * loc.element_size())}
         except Exception as e:   # the timed result is already in hand; report and carry on
             print(f"bench.py: read-back gather failed: {e}", file=sys.stderr)
+            gathered = {"error": str(e)}
     else:
         total_steps = steps_per_pass * args.steps
 
@@ -285,11 +345,15 @@ def main():
         balg = alg_bytes_per_step(args.dtype, stride)
         ksec = kern_ms * 1e-3
         key = f"{args.scenario}:{R_local}:{args.record}{'+n_ray' if args.n_ray and stride else ''}:{args.dtype}:op{args.method}"
-        if args.mode != "lane":
-            key += ":" + args.mode            # profiles/traffic.json keeps the other launch modes under their own keys
+        if mode_used != "plain":
+            key += ":" + mode_used            # profiles/traffic.json keeps the other launch modes under their own keys
+        # the profiles were taken with every other option at its default: a run that changes one of them (ray order, sort,
+        # field path, slice length, block size, refill threshold, a shard of a larger fan) has no profile of its own
+        defaults = (args.order == "fan" and not args.sort and args.field_path == "auto" and args.slice_steps in (0, 512)
+                    and args.block == 0 and args.refill_min == 0 and part_world == 1)
         prof = {}
         try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}) or {}
+            prof = (json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}) or {}) if defaults else {}
         except Exception:
             prof = {}
         if not isinstance(prof, dict):        # round-1 format: a bare byte count
@@ -304,7 +368,8 @@ def main():
         if stride:   # secondary yardstick for the row stream: what a write-only kernel reaches on this memory system
             hbm["write_only_ceiling"] = {"peak": HBM_FILL_GBS, "unit": "GB/s", "frac": hbm_bytes / ksec / 1e9 / HBM_FILL_GBS,
                                          "source": "profiles/r02_f_hbm_write_ceiling.txt (tools/hbm_fill.hip)"}
-        roof = dict(hbm, bound="hbm", traffic=measured, traffic_source=prof.get("source") if measured else None)
+        roof = dict(hbm, bound="hbm", traffic=measured, traffic_source=prof.get("source") if measured else None,
+                    traffic_key=key if measured else None)
         roof.pop("write_only_ceiling", None)
         # vector-ALU issue time from the profiled instruction counts: a 64-lane fp64 instruction holds a SIMD for 4 cycles
         # (16 lanes/clk), any other VALU instruction for 2 (SIMD-32); against 1024 SIMDs at the 2.4 GHz peak clock
@@ -318,7 +383,7 @@ def main():
             roof["valu_issue"] = valu
             if frac > roof["frac"]:
                 roof.update(bound="valu", achieved=valu["achieved"], peak=valu["peak"], unit=valu["unit"], frac=frac)
-        roof.update(kernel={"refill": "k_trace_refill", "sliced": "k_advance_sliced"}.get(args.mode, "k_advance"), kernel_ms=kern_ms / launches,
+        roof.update(kernel={"refill": "k_trace_refill", "sliced": "k_advance_sliced"}.get(mode_used, "k_advance"), kernel_ms=kern_ms / launches,
                     kernel_ms_per_pass=kern_ms, launches_per_pass=launches, ray_steps_per_pass=int(steps_per_pass),
                     vgprs=st["vgprs"], hbm=hbm,
                     alg_model={"bytes_per_ray_step": balg, "GB_per_s": balg * steps_per_pass / ksec / 1e9,
@@ -328,25 +393,37 @@ def main():
         out = {
             "metric": "ray-steps/sec (whole node) on vert_heterogeneous, 1M rays; % HBM roofline",
             "value": total_steps / dt, "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "warmup": args.warmup, "untimed_passes": max(args.warmup, 2), "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.scenario}, {R_total} rays in total ({R_local} on rank 0; fan linspace over {R_total} "
                                    f"rays, interleaved across ranks), op{args.method}, DELTA_S={step:.12g}, "
                                    f"box={tuple(float(v) for v in lim)}, record={args.record}",
                        "rays_total": R_total, "rays_rank0": R_local, "ray_steps_per_pass_rank0": int(steps_per_pass),
-                       "method": f"op{args.method}", "record": args.record, "n_ray_rows": bool(args.n_ray and stride), "launch_mode": args.mode,
+                       "method": f"op{args.method}", "record": args.record, "n_ray_rows": bool(args.n_ray and stride), "launch_mode": args.mode, "launch_mode_used": mode_used,
                        "ray_order": args.order, "sort_rays": bool(args.sort), "field_path": args.field_path,
                        "steps_per_launch": args.chunk or "all", "parallelism": f"ray-shard x{world}"},
             "roofline": roof,
         }
+        if args.emulate_world:
+            out["config"]["emulated"] = {"world": part_world, "rank": part_rank,
+                                         "note": "one rank's shard of the N-way split, run alone on one GPU"}
+        if use_dist:
+            out["config"]["dist"] = {"backend": args.backend, "world_size": world, "forced": bool(args.force_dist and world == 1),
+                                     "gather": gathered}
         if world == 1 and args.cpu_seconds > 0:
             out["cpu_baseline"] = cpu_baseline(args, rb, args.cpu_seconds, R_local)
+        if args.parity_stride > 0 and args.chunk <= 0:
+            out["parity_check"] = parity_check(args, rb, batch, th, stride, step, max_size, lim)
         print(json.dumps(out), flush=True)
+        if args.parity_stride > 0 and args.chunk <= 0 and not out["parity_check"]["ok"]:
+            parity_failed = True
     batch.close()
     fld.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if parity_failed:
+        sys.exit("bench.py: parity_check failed -- the timed batch differs from the oracle (see the JSON line)")
 
 
 if __name__ == "__main__":

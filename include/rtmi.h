@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 3
+#define RTMI_ABI_VERSION 4
 
 typedef enum {
     RTMI_OK = 0,
@@ -40,6 +40,16 @@ typedef enum { RTMI_INTERFACE = 1, RTMI_FISHEYE = 2, RTMI_VERT_HETEROGENEOUS = 3
 typedef enum { RTMI_OP_MIN = 1, RTMI_OP_MAX = 11 } rtmi_method_range;
 
 typedef enum { RTMI_F64 = 0, RTMI_F32 = 1 } rtmi_dtype;
+
+/* Device schedules of the loop at RT_bench.py:866-879 (rtmi_params.launch_mode).  The reference runs rays one after another
+ * (:807); every schedule here gives each ray the same arithmetic, hence the same bits. */
+typedef enum {
+    RTMI_LAUNCH_AUTO = 0,    /* the library chooses between SLICED and PLAIN (see rtmi_params.launch_mode) */
+    RTMI_LAUNCH_REFILL = 1,  /* persistent waves; terminated lanes are refilled from a device queue (ballot + prefix compaction) */
+    RTMI_LAUNCH_SLICED = 2,  /* persistent blocks advance 256-ray bundles in time slices of slice_steps rows: balances fans
+                                whose rays differ much in length */
+    RTMI_LAUNCH_PLAIN = 3    /* one lane per ray to completion, one block slot per 256 rays */
+} rtmi_launch_mode;
 
 typedef struct rtmi_field rtmi_field;   /* z + grd of interpolacion() (:435-464), resident in HBM */
 typedef struct rtmi_batch rtmi_batch;   /* one trazar() call's ray batch (:766-948), resident in HBM */
@@ -83,11 +93,13 @@ typedef struct {
     int32_t record_stride;   /* 0: keep no trajectory; s>=1: store rows i with i % s == 0 (1 = reference layout) */
     int64_t rec_rows;        /* rows allocated for s_ray/n_ray (row r holds step r*stride); 0 -> derived from max_size */
     double box[4];           /* limx_i, limx_s, limy_i, limy_s (:878) */
-    int32_t launch_mode;     /* 0: one lane per ray to completion; 1: persistent waves with lane refill; 2: persistent blocks
-                                that advance 256-ray bundles in time slices of slice_steps rows (rtmi_run only; balances fans
-                                whose rays differ much in length); results are bit-identical in all three */
+    int32_t launch_mode;     /* how rtmi_run schedules the loop on the device (rtmi_launch_mode); results are bit-identical in
+                                all of them.  0 = RTMI_LAUNCH_AUTO, the value a zero-initialised struct gets: time-sliced bundles
+                                when the batch has more 256-ray bundles than the device holds resident blocks, else the plain
+                                launch; a batch that is re-run (rtmi_batch_reset + rtmi_run) tries the other schedule once and
+                                keeps the faster by its measured kernel time (rtmi_stats.launch_mode_used tells which ran) */
     int32_t block_size;      /* 0 -> default */
-    int32_t refill_min;      /* launch_mode 1: compact when this many lanes of a wave are idle (0 -> 32) */
+    int32_t refill_min;      /* RTMI_LAUNCH_REFILL: compact when this many lanes of a wave are idle (0 -> 32) */
     int32_t exact_basis;     /* 0: uniform-knot cubic basis in interior cells (<= 4e-14 from FITPACK's weights);
                                 1: FITPACK's fpbspl arithmetic on the true knots in every cell (slower) */
     int32_t field_path;      /* where lookups read the field: 0 auto (wave-private LDS tile, except global memory for fp64
@@ -105,7 +117,7 @@ typedef struct {
     int32_t no_n_ray;        /* 1: keep no n_ray rows.  n_ray (coef*n per row, :803) is an internal array of trazar -- it feeds the
                                 traveltime recurrence (:874) and is not among trazar's return values (:948) -- so a caller of the
                                 reference's call surface never sees it; dropping it saves 1/7 of the recorded bytes */
-    int32_t slice_steps;     /* launch_mode 2: DELTA_S steps per time slice of a bundle (0 -> 256); a bundle's first two
+    int32_t slice_steps;     /* time-sliced schedule: DELTA_S steps per time slice of a bundle (0 -> 512); a bundle's first two
                                 slices are 4 and 2 times as long */
 } rtmi_params;
 
@@ -117,8 +129,16 @@ int rtmi_batch_create(const rtmi_field *f, const rtmi_params *p, int64_t R, cons
  * dn/dy, dist_sim, dist_real, T; hist4[4][R] = the two positions before (x,y), oldest first (op7's
  * VECTOR_LIST, :73; may be NULL for other methods); istep[R] = last written row (NULL keeps it).  Every ray
  * with istep+1 < max_size becomes live.  This is the explicit-argument form of one selected_func call
- * (:868): opN(i_angle, init_n, i_grad, i_unitv, i_vpos, coef_i, grd, z, step) with caller-chosen inputs. */
+ * (:868): opN(i_angle, init_n, i_grad, i_unitv, i_vpos, coef_i, grd, z, step) with caller-chosen inputs.
+ * fp64 op2/op6 batches carry the unit tangent (cos theta, sin theta) as ray state (it is advanced by rotation, not
+ * recomputed from theta every step): there hist4[0], hist4[1] = (cos, sin) as rtmi_batch_get_state returned them, so that
+ * a checkpointed run resumes bit for bit; with hist4 == NULL the unit tangent restarts from sin/cos of theta (a state
+ * of the caller's own making has no other), which may differ from the carried pair in the last bits. */
 int rtmi_batch_set_state(rtmi_batch *b, const double *state9, const double *hist4, const int32_t *istep);
+/* The inverse of rtmi_batch_set_state: copy the current ray state to host buffers (any may be NULL), same layouts, caller's
+ * ray order.  hist4 rows that the method does not use are written as 0.  get_state + set_state on a batch with the same
+ * parameters continues a run bit for bit (checkpoint / resume; the reference has no counterpart, :866 runs to the end). */
+int rtmi_batch_get_state(rtmi_batch *b, double *state9, double *hist4, int32_t *istep);
 /* Give every ray its own DELTA_S and max_size (host arrays [R], caller's ray order): one batch then holds the whole
  * DELTA_S calibration sweep, candidate x ray (search_delta over delta_s_options, RT_bench.py:950-958, 1317-1318).
  * max_size[k] <= params.max_size (which sizes the trajectory arrays).  Survives rtmi_batch_reset.  Only valid on a
@@ -190,6 +210,7 @@ typedef struct {
     double kernel_ms;        /* sum of advance-kernel durations since create/reset (HIP events on the batch's stream) */
     uint32_t launches;       /* advance-kernel launches since create/reset */
     uint32_t vgprs, sgprs, lds_bytes;   /* of the advance kernel in use */
+    uint32_t launch_mode_used;          /* rtmi_launch_mode of the last rtmi_run (RTMI_LAUNCH_PLAIN after rtmi_step) */
 } rtmi_stats;
 /* Synchronises the stream, then fills *s. */
 int rtmi_batch_stats(rtmi_batch *b, rtmi_stats *s);

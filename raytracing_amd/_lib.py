@@ -7,6 +7,12 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RTMI_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants in one session)
 LIB_PATH = os.environ.get("RTMI_LIB_PATH") or os.path.join(_HERE, "librtmi.so")
 
+ABI_VERSION = 4
+# rtmi_launch_mode (include/rtmi.h)
+LAUNCH_AUTO, LAUNCH_REFILL, LAUNCH_SLICED, LAUNCH_PLAIN = 0, 1, 2, 3
+LAUNCH_MODES = {"auto": LAUNCH_AUTO, "refill": LAUNCH_REFILL, "sliced": LAUNCH_SLICED, "plain": LAUNCH_PLAIN, "lane": LAUNCH_PLAIN}
+LAUNCH_NAMES = {LAUNCH_AUTO: "auto", LAUNCH_REFILL: "refill", LAUNCH_SLICED: "sliced", LAUNCH_PLAIN: "plain"}
+
 _dp = C.POINTER(C.c_double)
 _ip = C.POINTER(C.c_int32)
 
@@ -36,7 +42,8 @@ class DeviceView(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("ray_steps", C.c_uint64), ("live_rays", C.c_uint64), ("kernel_ms", C.c_double),
-                ("launches", C.c_uint32), ("vgprs", C.c_uint32), ("sgprs", C.c_uint32), ("lds_bytes", C.c_uint32)]
+                ("launches", C.c_uint32), ("vgprs", C.c_uint32), ("sgprs", C.c_uint32), ("lds_bytes", C.c_uint32),
+                ("launch_mode_used", C.c_uint32)]
 
 
 # every symbol include/rtmi.h declares: name -> (restype, argtypes)
@@ -55,6 +62,7 @@ SYMBOLS = {
     "rtmi_batch_create": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int64, _dp, _dp, _dp, C.c_void_p,
                                     C.POINTER(C.c_void_p)]),
     "rtmi_batch_set_state": (C.c_int, [C.c_void_p, _dp, _dp, _ip]),
+    "rtmi_batch_get_state": (C.c_int, [C.c_void_p, _dp, _dp, _ip]),
     "rtmi_batch_set_per_ray": (C.c_int, [C.c_void_p, _dp, _ip]),
     "rtmi_batch_reset": (C.c_int, [C.c_void_p]),
     "rtmi_step": (C.c_int, [C.c_void_p, C.c_int32]),
@@ -100,7 +108,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-        if L.rtmi_abi_version() != 3:
+        if L.rtmi_abi_version() != ABI_VERSION:
             raise ImportError("librtmi.so ABI version mismatch")
         _lib = L
     return _lib

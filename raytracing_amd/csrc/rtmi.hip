@@ -776,9 +776,15 @@ __device__ __forceinline__ unsigned long long uniform_u64(unsigned long long v) 
 __device__ __forceinline__ unsigned long long ld_u64(const unsigned long long* p) {
     return uniform_u64(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 }
+// 100 MHz constant counter (s_memrealtime): the wait bound below is wall-clock, not a poll count
+__device__ __forceinline__ unsigned long long realtime_ticks() { return __builtin_amdgcn_s_memrealtime(); }
+// Compiler-only fence: the hand-over below orders its memory operations for the HARDWARE with device-scope atomics to the
+// coherence point, s_waitcnt vmcnt(0) and the block barrier; this keeps the optimizer from moving state accesses across the
+// entry load / entry store (s_waitcnt is not a memory operation to it, and the barrier's fence is workgroup scope).
+__device__ __forceinline__ void compiler_fence() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
 template <typename T, int METHOD, bool ISO, bool LDS>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? RTMI_F32_SLICED_WAVES : LDS ? (light_method(METHOD) ? RTMI_TILE_WAVES : heavy_method(METHOD) ? 2 : 3) : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES))
-void k_advance_sliced(BatchDev<T> a, int slice, unsigned long long capacity, unsigned long long* ctl) {
+void k_advance_sliced(BatchDev<T> a, int slice, unsigned long long capacity, unsigned long long* ctl, unsigned long long timeout_ticks) {
     __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
     __shared__ unsigned long long s_entry;
     const unsigned long long NB = (unsigned long long)((a.R + 255) / 256);
@@ -804,10 +810,19 @@ void k_advance_sliced(BatchDev<T> a, int slice, unsigned long long capacity, uns
                     e = i + 1ull;                                                     // slices done: 0
                 } else if (i - NB < capacity) {
                     e = ld_u64(entries + (i - NB));
-                    for (unsigned spins = 0; e == 0ull && spins < (1u << 19); ++spins) {   // ~2 s: then report, do not hang
+                    // Wait for the entry.  Blocks past the queue's tail sit here until the last live bundles finish, which
+                    // may legitimately take as long as the longest slice of the slowest method; the wait is abandoned only
+                    // after timeout_ticks of wall-clock time in which NOTHING moved (no slice finished, nothing pushed) --
+                    // the host sizes that from the longest possible slice (sliced_timeout_ticks) -- and the launch then
+                    // reports RTMI_ERR_STATE instead of hanging.
+                    unsigned long long f0 = ~0ull, p0 = ~0ull, t0 = realtime_ticks();
+                    while (e == 0ull) {
                         const unsigned long long f = ld_u64(finished);
                         const unsigned long long p = ld_u64(pushed + (f >> 63));     // address depends on f: read after it
                         if (f == NB + p && i >= NB + p) { e = kStop; break; }         // nothing in flight, nothing left
+                        const unsigned long long now = realtime_ticks();
+                        if (f != f0 || p != p0) { f0 = f; p0 = p; t0 = now; }         // progress somewhere: start over
+                        else if (now - t0 > timeout_ticks) break;
                         __builtin_amdgcn_s_sleep(RTMI_SLICED_SLEEP);
                         e = ld_u64(entries + (i - NB));
                     }
@@ -816,6 +831,7 @@ void k_advance_sliced(BatchDev<T> a, int slice, unsigned long long capacity, uns
                     __hip_atomic_store(stalled, 2ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // queue capacity (never expected)
                 }
             }
+            compiler_fence();                                // no state load of the bundle moves above the entry load
             s_entry = e;
         }
         __syncthreads();
@@ -829,12 +845,15 @@ void k_advance_sliced(BatchDev<T> a, int slice, unsigned long long capacity, uns
             const long bundle = (long)((e & 0xffffffffull) - 1ull);
             const unsigned k = (unsigned)(e >> 32);           // slices this bundle has had
             const int nsteps = k == 0u ? 4 * slice : k == 1u ? 2 * slice : slice;
+            compiler_fence();
             const bool alive = advance_bundle<T, METHOD, ISO, LDS, false, true>(a, lds, bundle * 256, nsteps);
+            compiler_fence();                                // no state store of the bundle moves below the entry store
             __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): this lane's state stores are acknowledged
             const int any = __builtin_amdgcn_readfirstlane(__syncthreads_or(alive));
             if (wave0) {
                 if (any) {
                     const unsigned long long slot = uniform_u64(atomicAdd(pushed, one));
+                    compiler_fence();
                     if (slot < capacity)
                         __hip_atomic_store(entries + slot, ((unsigned long long)(k + 1u) << 32) | (unsigned long long)(bundle + 1),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -933,7 +952,10 @@ template <typename T> __global__ void k_pack_final(BatchDev<T> a, double* out) {
     if (k >= a.R) return;
     rt::Ray<T> r;
     r.x = a.acc(0)[k]; r.y = a.acc(1)[k]; r.th = a.acc(2)[k]; r.n = a.aux(0)[k]; r.gx = a.aux(1)[k]; r.gy = a.aux(2)[k]; r.tt = a.acc(5)[k];
-    derive_rt(a, r);
+    if (a.rot) {   // the carried unit tangent is what the last recorded row's momenta were formed from
+        r.ux = a.unit(0)[k]; r.uy = a.unit(1)[k];
+        if (a.iso) rt::derive<T, true, true>(a.K, r); else rt::derive<T, false, true>(a.K, r);
+    } else derive_rt(a, r);
     const double v[9] = {(double)r.x, (double)r.y, (double)r.th, (double)r.n, (double)r.gx, (double)r.gy,
                          (double)r.mx, (double)r.my, (double)r.tt};
     const long o = out_index(a, k);
@@ -974,7 +996,27 @@ struct rtmi_batch {
     unsigned long long* sliced_ctl = nullptr;   // launch_mode 2: head, pushed, finished, stalled, queue entries (k_advance_sliced)
     bool dirty = false;          // rows may hold data a re-run will not overwrite (set_state / set_per_ray since the last clear)
     bool dirty_state = false;    // rtmi_batch_set_state ran since create / reset
+    // RTMI_LAUNCH_AUTO: kernel time of the last complete run from the launch conditions under each schedule
+    // ([0] sliced, [1] plain; < 0: not measured yet), and what the last rtmi_run used
+    double auto_ms[2] = {-1.0, -1.0};
+    int mode_used = RTMI_LAUNCH_PLAIN;
+    void* staging = nullptr;     // device scratch of the read / metric / set_state paths, grown on demand, freed with the batch
+    size_t staging_bytes = 0;
 };
+
+// device scratch owned by the batch (one allocation reused by every read path instead of a hipMalloc/hipFree per call)
+static int batch_staging(rtmi_batch* b, size_t bytes, void** out) {
+    if (bytes > b->staging_bytes) {
+        HIP_TRY(hipStreamSynchronize(b->stream));     // nothing may still use the old buffer
+        (void)hipFree(b->staging);
+        b->staging = nullptr; b->staging_bytes = 0;
+        hipError_t e = hipMalloc(&b->staging, bytes);
+        if (e != hipSuccess) return fail(RTMI_ERR_ALLOC, std::string("staging buffer: ") + hipGetErrorString(e));
+        b->staging_bytes = bytes;
+    }
+    *out = b->staging;
+    return RTMI_OK;
+}
 
 template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     BatchDev<T> a;
@@ -1072,9 +1114,21 @@ static unsigned long long sliced_capacity(const rtmi_batch* b, int slice) {
     return NB * (unsigned long long)(2 + (rest > 0 ? (rest + slice - 1) / slice : 0)) + 8192;
 }
 static int sliced_steps(const rtmi_batch* b) {
-    const int s = b->p.slice_steps > 0 ? b->p.slice_steps : 256;
+    const int s = b->p.slice_steps > 0 ? b->p.slice_steps : 512;   // 128..1024 measure alike
     return s < (1 << 20) ? s : (1 << 20);
 }
+// Wall-clock bound (100 MHz ticks) on a wait in which nothing moves: 2 s plus the longest slice any block can be in --
+// min(4 * slice, max_size) steps at a generous per-step cost (golden-section methods evaluate 74 costs per step; a
+// wave-step of op11 measures ~16 us at three waves per SIMD, of op6 ~0.4 us) -- so a long slice elsewhere is not a stall.
+static unsigned long long sliced_timeout_ticks(const rtmi_batch* b, int slice) {
+    const double steps = std::min(4.0 * (double)slice, (double)b->p.max_size);
+    const int m = b->p.method;
+    const double us_per_step = (m == 5 || m >= 9) ? 200.0 : 20.0;
+    const double seconds = 2.0 + steps * us_per_step * 1e-6;
+    return (unsigned long long)(seconds * 1e8);
+}
+// can this batch run the time-sliced schedule at all (queue within 256 MB, uniform DELTA_S, rays in lockstep)?
+static bool sliced_feasible(const rtmi_batch* b) { return sliced_capacity(b, sliced_steps(b)) <= (1ull << 25); }
 static const void* pick_sliced(const rtmi_batch* b) {
     const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
     return b->p.dtype == RTMI_F64 ? sliced_fn<double>(b->p.method, iso, lds) : sliced_fn<float>(b->p.method, iso, lds);
@@ -1107,7 +1161,7 @@ RTMI_EXPORT void rtmi_batch_destroy(rtmi_batch* b) {
     (void)hipFree(b->state); (void)hipFree(b->istep); (void)hipFree(b->alive); (void)hipFree(b->launch);
     (void)hipFree(b->perm);
     (void)hipFree(b->vstep); (void)hipFree(b->vstep2h); (void)hipFree(b->vmax);
-    (void)hipFree(b->counters); (void)hipFree(b->sliced_ctl);
+    (void)hipFree(b->counters); (void)hipFree(b->sliced_ctl); (void)hipFree(b->staging);
     if (b->h_counters) (void)hipHostFree(b->h_counters);
     if (b->own_s) (void)hipFree(b->s_ray);
     if (b->own_n) (void)hipFree(b->n_ray);
@@ -1127,7 +1181,8 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     ARG_TRY(p->method != 7 || p->max_size >= 4, "rtmi_batch_create: op7 needs max_size >= 4 (two bootstrap rows)");
     ARG_TRY(p->record_stride >= 0, "rtmi_batch_create: record_stride < 0");
     ARG_TRY(p->box[1] > p->box[0] && p->box[3] > p->box[2], "rtmi_batch_create: empty box");
-    ARG_TRY(p->launch_mode >= 0 && p->launch_mode <= 2, "rtmi_batch_create: launch_mode must be 0, 1 or 2");
+    ARG_TRY(p->launch_mode >= RTMI_LAUNCH_AUTO && p->launch_mode <= RTMI_LAUNCH_PLAIN,
+            "rtmi_batch_create: launch_mode must be 0 (auto), 1 (refill), 2 (sliced) or 3 (plain)");
     ARG_TRY(p->slice_steps >= 0, "rtmi_batch_create: slice_steps must be >= 0");
     ARG_TRY(p->refill_min >= 0 && p->refill_min <= 64, "rtmi_batch_create: refill_min must be in [0, 64]");
     ARG_TRY(p->exact_basis == 0 || p->exact_basis == 1, "rtmi_batch_create: exact_basis must be 0 or 1");
@@ -1202,16 +1257,20 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, b->kfn_refill, 256, 0));
         b->persistent_blocks = cus * (per_cu > 0 ? per_cu : 1);
-        if (b->p.launch_mode == 2) {
+        if (b->p.launch_mode == RTMI_LAUNCH_SLICED || b->p.launch_mode == RTMI_LAUNCH_AUTO) {
             b->kfn_sliced = pick_sliced(b);
             HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, b->kfn_sliced, 256, 0));
             b->sliced_blocks = cus * (per_cu > 0 ? per_cu : 1);
             if (getenv("RTMI_DEBUG")) fprintf(stderr, "rtmi: sliced kernel: %d CUs x %d resident blocks\n", cus, per_cu);
             // one queue entry per slice a bundle survives: tiny slices on a large batch with a large max_size would ask for
-            // gigabytes of queue (and a memset of it per run); refuse beyond 256 MB
-            ARG_TRY(sliced_capacity(b, sliced_steps(b)) <= (1ull << 25),
-                    "rtmi_batch_create: launch_mode 2: slice_steps too small for this batch size and max_size (queue > 256 MB)");
-            HIP_TRY(hipMalloc(&b->sliced_ctl, (4 + sliced_capacity(b, sliced_steps(b))) * sizeof(unsigned long long)));
+            // gigabytes of queue (and a memset of it per run); refuse beyond 256 MB (auto: such a batch runs the plain launch)
+            if (b->p.launch_mode == RTMI_LAUNCH_SLICED)
+                ARG_TRY(sliced_feasible(b),
+                        "rtmi_batch_create: RTMI_LAUNCH_SLICED: slice_steps too small for this batch size and max_size (queue > 256 MB)");
+            // auto only ever slices a batch with more bundles than resident blocks (auto_wants_sliced)
+            const bool may_slice = b->p.launch_mode == RTMI_LAUNCH_SLICED || (sliced_feasible(b) && (R + 255) / 256 > b->sliced_blocks);
+            if (may_slice)
+                HIP_TRY(hipMalloc(&b->sliced_ctl, (4 + sliced_capacity(b, sliced_steps(b))) * sizeof(unsigned long long)));
         }
         return batch_init_state(b, true);
     };
@@ -1236,7 +1295,9 @@ __global__ void k_set_per_ray(BatchDev<T> a, const double* step, const double* s
 
 RTMI_EXPORT int rtmi_batch_set_per_ray(rtmi_batch* b, const double* step, const int32_t* max_size) {
     ARG_TRY(b && step && max_size, "rtmi_batch_set_per_ray: null");
-    ARG_TRY(b->p.launch_mode == 0, "rtmi_batch_set_per_ray: per-ray steps run on the one-lane-per-ray kernel (launch_mode 0)");
+    ARG_TRY(b->p.launch_mode == RTMI_LAUNCH_PLAIN || b->p.launch_mode == RTMI_LAUNCH_AUTO,
+            "rtmi_batch_set_per_ray: per-ray steps run on the one-lane-per-ray kernel (RTMI_LAUNCH_PLAIN or RTMI_LAUNCH_AUTO)");
+    DEVICE_TRY(b->field, "rtmi_batch_set_per_ray");
     if (b->launches != 0 || b->dirty_state)
         return fail(RTMI_ERR_STATE, "rtmi_batch_set_per_ray: only valid on a fresh or reset batch (before any rtmi_step / rtmi_run / "
                                     "rtmi_batch_set_state): rays that already stopped would be revived");
@@ -1265,11 +1326,12 @@ RTMI_EXPORT int rtmi_batch_set_per_ray(rtmi_batch* b, const double* step, const 
         }
         b->vstep = v1; b->vstep2h = v2; b->vmax = v3;
     }
-    double* d = nullptr;
-    int* di = nullptr;
-    HIP_TRY(hipMalloc(&d, 2 * R * sizeof(double)));
-    hipError_t e = hipMalloc(&di, R * sizeof(int));
-    if (e == hipSuccess) e = hipMemcpyAsync(d, step, R * 8, hipMemcpyHostToDevice, b->stream);
+    void* stg = nullptr;
+    int rcs = batch_staging(b, 2 * R * sizeof(double) + R * sizeof(int), &stg);
+    if (rcs) return rcs;
+    double* d = (double*)stg;
+    int* di = (int*)(d + 2 * R);
+    hipError_t e = hipMemcpyAsync(d, step, R * 8, hipMemcpyHostToDevice, b->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d + R, h2.data(), R * 8, hipMemcpyHostToDevice, b->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(di, max_size, R * sizeof(int), hipMemcpyHostToDevice, b->stream);
     if (e == hipSuccess) {
@@ -1281,8 +1343,6 @@ RTMI_EXPORT int rtmi_batch_set_per_ray(rtmi_batch* b, const double* step, const 
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-    (void)hipFree(d);
-    (void)hipFree(di);
     if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_batch_set_per_ray: ") + hipGetErrorString(e));
     b->kfn = pick_advance(b);
     b->dirty = true;   // rows written under the previous steps would no longer be rewritten: clear on the next reset
@@ -1307,25 +1367,46 @@ template <typename T> __global__ void k_set_state(BatchDev<T> a, const double* s
     for (int q = 0; q < 3; q++) a.acc(3 + q)[k] = st[(size_t)(6 + q) * a.R + o];
     if (a.has_hist && hist)
         for (int q = 0; q < 4; q++) a.aux(3 + q)[k] = (T)hist[(size_t)q * a.R + o];
-    if (a.rot) {                                  // a state given from outside starts from its angle's own sin/cos
-        T sn, cs;
-        rt::M<T>::sincos_(a.acc(2)[k], &sn, &cs);
-        a.unit(0)[k] = cs; a.unit(1)[k] = sn;
+    if (a.rot) {
+        if (hist) {                               // the carried unit tangent of a checkpoint (rtmi_batch_get_state)
+            a.unit(0)[k] = (T)hist[o]; a.unit(1)[k] = (T)hist[(size_t)a.R + o];
+        } else {                                  // a state given from outside starts from its angle's own sin/cos
+            T sn, cs;
+            rt::M<T>::sincos_(a.acc(2)[k], &sn, &cs);
+            a.unit(0)[k] = cs; a.unit(1)[k] = sn;
+        }
     }
     if (istep) a.istep[k] = istep[o];
     a.alive[k] = a.istep[k] + 1 < max_size_of(a, k);
 }
+// out: state9[9][R] then hist4[4][R] (fp64), oi: istep[R]; caller's ray order
+template <typename T> __global__ void k_get_state(BatchDev<T> a, double* out, int* oi) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.R) return;
+    const long o = out_index(a, k);
+    const size_t R = (size_t)a.R;
+    out[o] = a.acc(0)[k]; out[R + o] = a.acc(1)[k]; out[2 * R + o] = a.acc(2)[k];
+    for (int q = 0; q < 3; q++) out[(3 + q) * R + o] = (double)a.aux(q)[k];
+    for (int q = 0; q < 3; q++) out[(6 + q) * R + o] = a.acc(3 + q)[k];
+    double h[4] = {0, 0, 0, 0};
+    if (a.has_hist) for (int q = 0; q < 4; q++) h[q] = (double)a.aux(3 + q)[k];
+    else if (a.rot) { h[0] = (double)a.unit(0)[k]; h[1] = (double)a.unit(1)[k]; }
+    for (int q = 0; q < 4; q++) out[(9 + q) * R + o] = h[q];
+    oi[o] = a.istep[k];
+}
 
 RTMI_EXPORT int rtmi_batch_set_state(rtmi_batch* b, const double* state9, const double* hist4, const int32_t* istep) {
     ARG_TRY(b && state9, "rtmi_batch_set_state: null");
+    DEVICE_TRY(b->field, "rtmi_batch_set_state");
     const size_t R = (size_t)b->R;
     b->dirty = true;
     b->dirty_state = true;
-    double* d = nullptr;
-    int* di = nullptr;
-    HIP_TRY(hipMalloc(&d, 13 * R * sizeof(double)));
-    hipError_t e = hipMalloc(&di, R * sizeof(int));
-    if (e == hipSuccess) e = hipMemcpyAsync(d, state9, 9 * R * 8, hipMemcpyHostToDevice, b->stream);
+    void* stg = nullptr;
+    int rc = batch_staging(b, 13 * R * sizeof(double) + R * sizeof(int), &stg);
+    if (rc) return rc;
+    double* d = (double*)stg;
+    int* di = (int*)(d + 13 * R);
+    hipError_t e = hipMemcpyAsync(d, state9, 9 * R * 8, hipMemcpyHostToDevice, b->stream);
     if (e == hipSuccess && hist4) e = hipMemcpyAsync(d + 9 * R, hist4, 4 * R * 8, hipMemcpyHostToDevice, b->stream);
     if (e == hipSuccess && istep) e = hipMemcpyAsync(di, istep, R * sizeof(int), hipMemcpyHostToDevice, b->stream);
     if (e == hipSuccess) {
@@ -1337,9 +1418,28 @@ RTMI_EXPORT int rtmi_batch_set_state(rtmi_batch* b, const double* state9, const 
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-    (void)hipFree(d);
-    (void)hipFree(di);
     if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_batch_set_state: ") + hipGetErrorString(e));
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_batch_get_state(rtmi_batch* b, double* state9, double* hist4, int32_t* istep) {
+    ARG_TRY(b, "rtmi_batch_get_state: null");
+    DEVICE_TRY(b->field, "rtmi_batch_get_state");
+    const size_t R = (size_t)b->R;
+    void* stg = nullptr;
+    int rc = batch_staging(b, 13 * R * sizeof(double) + R * sizeof(int), &stg);
+    if (rc) return rc;
+    double* d = (double*)stg;
+    int* di = (int*)(d + 13 * R);
+    const dim3 g((unsigned)((R + 255) / 256)), blk(256);
+    if (b->p.dtype == RTMI_F64) hipLaunchKernelGGL(k_get_state<double>, g, blk, 0, b->stream, batch_dev<double>(b), d, di);
+    else hipLaunchKernelGGL(k_get_state<float>, g, blk, 0, b->stream, batch_dev<float>(b), d, di);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && state9) e = hipMemcpyAsync(state9, d, 9 * R * 8, hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess && hist4) e = hipMemcpyAsync(hist4, d + 9 * R, 4 * R * 8, hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess && istep) e = hipMemcpyAsync(istep, di, R * sizeof(int), hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
+    if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_batch_get_state: ") + hipGetErrorString(e));
     return RTMI_OK;
 }
 
@@ -1400,6 +1500,7 @@ RTMI_EXPORT int rtmi_step(rtmi_batch* b, int32_t nsteps) {
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, b->stream));
     b->launches++;
+    b->mode_used = RTMI_LAUNCH_PLAIN;
     return RTMI_OK;
 }
 
@@ -1427,43 +1528,61 @@ template <typename T> static void launch_refill(const rtmi_batch* b) {
 template <typename T> static void launch_sliced(const rtmi_batch* b, int slice, unsigned long long capacity) {
     BatchDev<T> a = batch_dev<T>(b);
     unsigned long long* ctl = b->sliced_ctl;
-    void* args[] = {&a, &slice, &capacity, &ctl};
+    unsigned long long timeout = sliced_timeout_ticks(b, slice);
+    void* args[] = {&a, &slice, &capacity, &ctl, &timeout};
     const long need = (b->R + 255) / 256;
     const dim3 g((unsigned)(need < b->sliced_blocks ? need : b->sliced_blocks)), blk(256);
     (void)hipLaunchKernel(b->kfn_sliced, g, blk, args, 0, b->stream);
 }
 
-RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
-    ARG_TRY(b, "rtmi_run: null");
-    int rc;
-    if (b->p.launch_mode == 2 && !b->vstep && uniform_rows_ok(b)) {
-        // persistent blocks, bundles advanced in time slices (k_advance_sliced); per-ray DELTA_S or rays at rows of their
-        // own (the VAR build's cases) run as launch_mode 0 below
-        DEVICE_TRY(b->field, "rtmi_run");
-        std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
-        rc = next_event_pair(b, &ev);
-        if (rc) return rc;
-        const int slice = sliced_steps(b);
-        const unsigned long long capacity = sliced_capacity(b, slice);
-        HIP_TRY(hipMemsetAsync(b->sliced_ctl, 0, (4 + capacity) * sizeof(unsigned long long), b->stream));
-        HIP_TRY(hipEventRecord(ev->first, b->stream));
-        if (b->p.dtype == RTMI_F64) launch_sliced<double>(b, slice, capacity);
-        else launch_sliced<float>(b, slice, capacity);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(ev->second, b->stream));
-        b->launches++;
-        rc = read_counters(b);
-        if (rc) return rc;
+// the time-sliced schedule can take this run: queue allocated, uniform DELTA_S, rows through the wave-uniform descriptor
+static bool sliced_ready(const rtmi_batch* b) { return b->sliced_ctl && !b->vstep && uniform_rows_ok(b); }
+
+static int run_sliced(rtmi_batch* b, std::pair<hipEvent_t, hipEvent_t>** evp) {
+    // persistent blocks, bundles advanced in time slices (k_advance_sliced)
+    int rc = next_event_pair(b, evp);
+    if (rc) return rc;
+    auto* ev = *evp;
+    const int slice = sliced_steps(b);
+    const unsigned long long capacity = sliced_capacity(b, slice);
+    HIP_TRY(hipMemsetAsync(b->sliced_ctl, 0, (4 + capacity) * sizeof(unsigned long long), b->stream));
+    HIP_TRY(hipEventRecord(ev->first, b->stream));
+    if (b->p.dtype == RTMI_F64) launch_sliced<double>(b, slice, capacity);
+    else launch_sliced<float>(b, slice, capacity);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ev->second, b->stream));
+    b->launches++;
+    b->mode_used = RTMI_LAUNCH_SLICED;
+    rc = read_counters(b);
+    if (rc) return rc;
+    if (b->h_counters[1] != 0) {   // every wait is bounded: a launch that gave one up reports here instead of hanging
         unsigned long long ctl4[4] = {0, 0, 0, 0};
         HIP_TRY(hipMemcpy(ctl4, b->sliced_ctl, sizeof(ctl4), hipMemcpyDeviceToHost));
-        if (ctl4[3] != 0) return fail(RTMI_ERR_STATE, ctl4[3] == 1 ? "rtmi_run: the sliced launch abandoned a wait for a queue entry"
-                                                                  : "rtmi_run: the sliced launch ran out of queue entries");
-        if (b->h_counters[1] != 0) return fail(RTMI_ERR_STATE, "rtmi_run: rays still live after the sliced launch");
-        return RTMI_OK;
+        return fail(RTMI_ERR_STATE, ctl4[3] == 1 ? "rtmi_run: the sliced launch abandoned a wait for a queue entry"
+                                  : ctl4[3] == 2 ? "rtmi_run: the sliced launch ran out of queue entries"
+                                                 : "rtmi_run: rays still live after the sliced launch");
     }
-    if (b->p.launch_mode == 1) {
+    return RTMI_OK;
+}
+
+static int run_plain(rtmi_batch* b, std::pair<hipEvent_t, hipEvent_t>** evp) {
+    // one lane per ray to completion: a single launch covers every remaining row
+    int rc = rtmi_step(b, b->p.max_size);
+    if (rc) return rc;
+    *evp = &b->events[b->ev_used - 1];
+    rc = read_counters(b);
+    if (rc) return rc;
+    if (b->h_counters[1] != 0) return fail(RTMI_ERR_STATE, "rtmi_run: rays still live after a full-length launch");
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
+    ARG_TRY(b, "rtmi_run: null");
+    DEVICE_TRY(b->field, "rtmi_run");
+    int rc;
+    std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+    if (b->p.launch_mode == RTMI_LAUNCH_REFILL) {
         // persistent waves with lane refill: one launch drains the ray queue
-        std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
         rc = next_event_pair(b, &ev);
         if (rc) return rc;
         HIP_TRY(hipMemsetAsync(b->counters + 2, 0, sizeof(unsigned long long), b->stream));   // refill queue head
@@ -1473,15 +1592,28 @@ RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev->second, b->stream));
         b->launches++;
+        b->mode_used = RTMI_LAUNCH_REFILL;
         return read_counters(b);
     }
-    // one lane per ray to completion: a single launch covers every remaining row
-    rc = rtmi_step(b, b->p.max_size);
-    if (rc) return rc;
-    rc = read_counters(b);
-    if (rc) return rc;
-    if (b->h_counters[1] != 0) return fail(RTMI_ERR_STATE, "rtmi_run: rays still live after a full-length launch");
-    return RTMI_OK;
+    // per-ray DELTA_S or rays at rows of their own (the VAR build's cases) always run the plain launch
+    if (b->p.launch_mode == RTMI_LAUNCH_SLICED) return sliced_ready(b) ? run_sliced(b, &ev) : run_plain(b, &ev);
+    if (b->p.launch_mode == RTMI_LAUNCH_PLAIN || !sliced_ready(b)) return run_plain(b, &ev);
+    // RTMI_LAUNCH_AUTO on a batch with more bundles than resident blocks.  Slicing first: it wins by up to 25 % where whole
+    // bundles would be dispatched in rounds (cfg3) and loses a few per cent where they would not.  A run
+    // that starts from the launch conditions is timed; once both schedules have a time the faster one is kept.
+    const bool fresh = b->launches == 0 && !b->dirty_state;
+    const int pick = b->auto_ms[0] < 0 ? 0 : b->auto_ms[1] < 0 ? 1 : (b->auto_ms[0] <= b->auto_ms[1] ? 0 : 1);
+    rc = pick == 0 ? run_sliced(b, &ev) : run_plain(b, &ev);
+    if (rc == RTMI_ERR_STATE && pick == 0) {
+        // the sliced launch gave up a wait (it reports instead of hanging); what it advanced is valid state: finish plainly
+        b->auto_ms[0] = 1e30;
+        return run_plain(b, &ev);
+    }
+    if (rc == RTMI_OK && fresh && ev) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev->first, ev->second) == hipSuccess) b->auto_ms[pick] = ms;   // stream is idle (read_counters)
+    }
+    return rc;
 }
 
 RTMI_EXPORT int rtmi_sync(rtmi_batch* b) {
@@ -1492,32 +1624,36 @@ RTMI_EXPORT int rtmi_sync(rtmi_batch* b) {
 
 RTMI_EXPORT int rtmi_read_d_ray(rtmi_batch* b, double* d_ray) {
     ARG_TRY(b && d_ray, "rtmi_read_d_ray: null");
-    double* d = nullptr;
+    DEVICE_TRY(b->field, "rtmi_read_d_ray");
     const size_t nb = 3 * (size_t)b->R * sizeof(double);
-    HIP_TRY(hipMalloc(&d, nb));
+    void* stg = nullptr;
+    int rc = batch_staging(b, nb, &stg);
+    if (rc) return rc;
+    double* d = (double*)stg;
     const dim3 g((unsigned)((b->R + 255) / 256)), blk(256);
     if (b->p.dtype == RTMI_F64) hipLaunchKernelGGL(k_pack_d_ray<double>, g, blk, 0, b->stream, batch_dev<double>(b), d);
     else hipLaunchKernelGGL(k_pack_d_ray<float>, g, blk, 0, b->stream, batch_dev<float>(b), d);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(d_ray, d, nb, hipMemcpyDeviceToHost, b->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-    (void)hipFree(d);
     if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_read_d_ray: ") + hipGetErrorString(e));
     return RTMI_OK;
 }
 
 RTMI_EXPORT int rtmi_read_final(rtmi_batch* b, double* final9) {
     ARG_TRY(b && final9, "rtmi_read_final: null");
-    double* d = nullptr;
+    DEVICE_TRY(b->field, "rtmi_read_final");
     const size_t nb = 9 * (size_t)b->R * sizeof(double);
-    HIP_TRY(hipMalloc(&d, nb));
+    void* stg = nullptr;
+    int rc = batch_staging(b, nb, &stg);
+    if (rc) return rc;
+    double* d = (double*)stg;
     const dim3 g((unsigned)((b->R + 255) / 256)), blk(256);
     if (b->p.dtype == RTMI_F64) hipLaunchKernelGGL(k_pack_final<double>, g, blk, 0, b->stream, batch_dev<double>(b), d);
     else hipLaunchKernelGGL(k_pack_final<float>, g, blk, 0, b->stream, batch_dev<float>(b), d);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(final9, d, nb, hipMemcpyDeviceToHost, b->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-    (void)hipFree(d);
     if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_read_final: ") + hipGetErrorString(e));
     return RTMI_OK;
 }
@@ -1535,6 +1671,7 @@ RTMI_EXPORT int rtmi_read_rows(rtmi_batch* b, int64_t row0, int64_t nrows, doubl
     ARG_TRY(b->p.record_stride > 0, "rtmi_read_rows: batch keeps no trajectory (record_stride = 0)");
     ARG_TRY(row0 >= 0 && nrows >= 0 && row0 + nrows <= b->p.rec_rows, "rtmi_read_rows: row range outside rec_rows");
     ARG_TRY(!(n_ray && !b->n_ray), "rtmi_read_rows: n_ray requested but the batch keeps none (params.no_n_ray)");
+    DEVICE_TRY(b->field, "rtmi_read_rows");
     if (nrows == 0) return RTMI_OK;
     const size_t R = (size_t)b->R;
     for (int which = 0; which < 2; which++) {
@@ -1549,8 +1686,10 @@ RTMI_EXPORT int rtmi_read_rows(rtmi_batch* b, int64_t row0, int64_t nrows, doubl
         }
         // convert / un-permute on the device through a bounded staging buffer (<= 256 MB)
         const int64_t chunk = std::max<int64_t>(1, std::min<int64_t>(nrows, (int64_t)((256u << 20) / (per_row * 8))));
-        double* d = nullptr;
-        HIP_TRY(hipMalloc(&d, (size_t)chunk * per_row * 8));
+        void* stg = nullptr;
+        const int rcs = batch_staging(b, (size_t)chunk * per_row * 8, &stg);
+        if (rcs) return rcs;
+        double* d = (double*)stg;
         hipError_t e = hipSuccess;
         for (int64_t r0 = 0; r0 < nrows && e == hipSuccess; r0 += chunk) {
             const int64_t n = std::min<int64_t>(chunk, nrows - r0);
@@ -1563,7 +1702,6 @@ RTMI_EXPORT int rtmi_read_rows(rtmi_batch* b, int64_t row0, int64_t nrows, doubl
             if (e == hipSuccess) e = hipMemcpyAsync(dst + (size_t)r0 * per_row, d, (size_t)n * per_row * 8, hipMemcpyDeviceToHost, b->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
         }
-        (void)hipFree(d);
         if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_read_rows: ") + hipGetErrorString(e));
     }
     return RTMI_OK;
@@ -1622,9 +1760,12 @@ RTMI_EXPORT int rtmi_metric(rtmi_batch* b, int kind, double* out) {
         ARG_TRY(b->p.record_stride == 1 && b->p.rec_rows >= b->p.max_size,
                 "rtmi_metric: the exit-angle metric needs the full trajectory (record_stride 1, rec_rows >= max_size)");
     if (kind == RTMI_METRIC_PX_CV) ARG_TRY(b->p.record_stride >= 1, "rtmi_metric: the p_x metric needs recorded rows");
-    double* d = nullptr;
+    DEVICE_TRY(b->field, "rtmi_metric");
     const size_t nb = (size_t)b->R * sizeof(double);
-    HIP_TRY(hipMalloc(&d, nb));
+    void* stg = nullptr;
+    int rc = batch_staging(b, nb, &stg);
+    if (rc) return rc;
+    double* d = (double*)stg;
     const dim3 g((unsigned)((b->R + 255) / 256)), blk(256);
 #define LAUNCH_(K)                                                                                          \
     do {                                                                                                    \
@@ -1638,7 +1779,6 @@ RTMI_EXPORT int rtmi_metric(rtmi_batch* b, int kind, double* out) {
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(out, d, nb, hipMemcpyDeviceToHost, b->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-    (void)hipFree(d);
     if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_metric: ") + hipGetErrorString(e));
     return RTMI_OK;
 }
@@ -1778,7 +1918,9 @@ RTMI_EXPORT int rtmi_batch_stats(rtmi_batch* b, rtmi_stats* s) {
     s->launches = b->launches;
     hipFuncAttributes fa;
     s->vgprs = s->sgprs = s->lds_bytes = 0;
-    if (hipFuncGetAttributes(&fa, b->p.launch_mode == 1 ? b->kfn_refill : (b->p.launch_mode == 2 && b->kfn_sliced) ? b->kfn_sliced : b->kfn) == hipSuccess) { s->vgprs = fa.numRegs; s->lds_bytes = (uint32_t)fa.sharedSizeBytes; }
+    s->launch_mode_used = (uint32_t)b->mode_used;
+    const void* kfn = b->mode_used == RTMI_LAUNCH_REFILL ? b->kfn_refill : (b->mode_used == RTMI_LAUNCH_SLICED && b->kfn_sliced) ? b->kfn_sliced : b->kfn;
+    if (hipFuncGetAttributes(&fa, kfn) == hipSuccess) { s->vgprs = fa.numRegs; s->lds_bytes = (uint32_t)fa.sharedSizeBytes; }
     return RTMI_OK;
 }
 

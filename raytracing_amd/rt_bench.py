@@ -12,7 +12,7 @@ import time
 import numpy as np
 
 from . import _lib
-from ._lib import Params, Stats, DeviceView, check, dptr, lib
+from ._lib import Params, Stats, DeviceView, check, dptr, lib, LAUNCH_MODES, LAUNCH_NAMES, LAUNCH_AUTO, LAUNCH_REFILL, LAUNCH_SLICED, LAUNCH_PLAIN
 
 # --------------------------------------------------------------------------- constants (:59-97)
 THCK_PARAM = 0.005                                   # :59
@@ -274,7 +274,7 @@ class Batch:
     """One trazar() call's rays, resident in HBM (rtmi_batch)."""
 
     def __init__(self, field, method, step, max_size, box, gamma, thetas, x0, y0, record_stride=1, rec_rows=0,
-                 gamma_step=None, stream=None, ext_s_ray=None, ext_n_ray=None, block_size=0, launch_mode=0,
+                 gamma_step=None, stream=None, ext_s_ray=None, ext_n_ray=None, block_size=0, launch_mode="auto",
                  refill_min=0, exact_basis=0, field_path=0, sort_rays=False, lazy_clear=False, keep_n_ray=True, slice_steps=0):
         self.field = field
         th = np.ascontiguousarray(thetas, dtype=np.float64)
@@ -288,7 +288,10 @@ class Batch:
         p.record_stride = int(record_stride); p.rec_rows = int(rec_rows)
         for i in range(4):
             p.box[i] = float(box[i])
-        p.launch_mode = int(launch_mode); p.block_size = int(block_size); p.refill_min = int(refill_min)
+        # launch_mode: "auto" (default: the library chooses and, on re-runs, keeps the faster), "plain", "refill", "sliced",
+        # or the rtmi_launch_mode integer; results are bit-identical in all of them
+        p.launch_mode = LAUNCH_MODES[launch_mode] if isinstance(launch_mode, str) else int(launch_mode)
+        p.block_size = int(block_size); p.refill_min = int(refill_min)
         p.exact_basis = int(exact_basis); p.field_path = int(field_path)
         if isinstance(sort_rays, str):
             if sort_rays != "auto":
@@ -314,6 +317,12 @@ class Batch:
         h = np.ascontiguousarray(hist4, dtype=np.float64) if hist4 is not None else None
         i = np.ascontiguousarray(istep, dtype=np.int32) if istep is not None else None
         check(lib().rtmi_batch_set_state(self._h, dptr(st), dptr(h), i.ctypes.data_as(_lib._ip) if i is not None else None))
+
+    def get_state(self):
+        """(state9 [9,R], hist4 [4,R], istep [R]) -- rtmi_batch_get_state; set_state(*get_state()) resumes bit for bit."""
+        st = np.empty((9, self.R)); h = np.empty((4, self.R)); i = np.empty(self.R, dtype=np.int32)
+        check(lib().rtmi_batch_get_state(self._h, dptr(st), dptr(h), i.ctypes.data_as(_lib._ip)))
+        return st, h, i
 
     def set_per_ray(self, step, max_size):
         """Per-ray DELTA_S and max_size ([R] each, caller's ray order): rtmi_batch_set_per_ray."""
@@ -390,7 +399,9 @@ class Batch:
     def stats(self):
         s = Stats()
         check(lib().rtmi_batch_stats(self._h, C.byref(s)))
-        return {k: getattr(s, k) for k, _ in Stats._fields_}
+        out = {k: getattr(s, k) for k, _ in Stats._fields_}
+        out["launch_mode_used"] = LAUNCH_NAMES.get(out["launch_mode_used"], out["launch_mode_used"])
+        return out
 
     def view(self):
         v = DeviceView()
@@ -534,8 +545,8 @@ def trazar(selected_func, z, grd, show, step, divisor, user_choice, *, thetas=No
     Keyword extensions for synthetic batches: thetas / starts ((R,2) or (2,)) / box / gamma / max_size replace
     the preset of `user_choice`; record = "full" (reference layout), an int stride, or None (s_ray is None).
     compute_times holds the device propagation time split evenly over rays, so np.sum(compute_times) is the
-    quantity the reference's benchmark reads (:1526).  launch_mode: 0 / 1 / 2 as in rtmi_params, or "auto": time-sliced
-    bundles (2) for large batches of the fans whose rays differ in length, the plain launch otherwise -- same bits.
+    quantity the reference's benchmark reads (:1526).  launch_mode: "auto" (rtmi_params' default: the library picks the
+    schedule), "plain", "refill", "sliced" or the rtmi_launch_mode integer -- same bits in all of them.
     """
     g, ray_count, theta_v, pos_x, s, limx_i, limx_s, limy_i, limy_s, op_if, op_fish, _, _ = constants(user_choice)
     fld = _field_of(z, grd)
@@ -558,11 +569,9 @@ def trazar(selected_func, z, grd, show, step, divisor, user_choice, *, thetas=No
     if max_size is None:
         max_size = N * divisor if op_fish else int(np.ceil(s / step) + 1)   # :796-799
     stride = 0 if record is None else (1 if record == "full" else int(record))
-    if launch_mode == "auto":
-        launch_mode = 2 if (ray_count >= 65536 and not op_if) else 0
     b = Batch(fld, selected_func, step, max_size, box, gamma, theta_v[:ray_count], x0, y0, record_stride=stride,
               sort_rays="auto", keep_n_ray=False,          # n_ray is internal to the reference's trazar (:803), never returned
-              launch_mode=int(launch_mode), slice_steps=512 if int(launch_mode) == 2 else 0)
+              launch_mode=launch_mode)
     t1 = time.perf_counter()
     b.run()
     b.sync()

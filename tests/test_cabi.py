@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     L = C.CDLL(_lib.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(L, name), name
-    assert _lib.lib().rtmi_abi_version() == 3
+    assert _lib.lib().rtmi_abi_version() == _lib.ABI_VERSION == 4
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -44,3 +44,15 @@ def test_argument_errors_do_not_touch_the_gpu():
     assert L.rtmi_batch_stats(None, None) == -1
     with pytest.raises(_lib.RtmiError):
         _lib.check(L.rtmi_read_d_ray(None, None))
+
+
+def test_ctypes_structs_match_the_header(tmp_path):
+    """sizeof of the ctypes mirrors == sizeof of the C structs (gcc on include/rtmi.h)."""
+    import subprocess
+    src = tmp_path / "sz.c"
+    src.write_text('#include "rtmi.h"\n#include <stdio.h>\nint main(void){printf("%zu %zu %zu\\n", sizeof(rtmi_params), '
+                   'sizeof(rtmi_stats), sizeof(rtmi_device_view)); return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
+    assert sizes == [C.sizeof(_lib.Params), C.sizeof(_lib.Stats), C.sizeof(_lib.DeviceView)]

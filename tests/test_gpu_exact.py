@@ -116,7 +116,7 @@ def test_trajectories_are_the_oracles_bits(scen, m, R, rb, fields):
         th, x0, y0, step, ms = np.linspace(0, np.pi / 2, R), -2.0, -2.0, rb.DELTA_S, 30228
     rows = 9000
     o = O.trazar(OF, m, gam, step, ms, lim, x0, y0, th, record_stride=1, rec_rows=rows, want_n_ray=True, nthreads=8)
-    for path, mode in ((1, 0), (2, 0), (2, 1)):
+    for path, mode in ((1, "plain"), (2, "plain"), (2, "refill")):
         b = rb.Batch(F, m, step, ms, lim, gam, th, x0, y0, record_stride=1, rec_rows=rows, field_path=path, launch_mode=mode)
         b.run()
         d, fin = b.d_ray(), b.final()

@@ -281,7 +281,7 @@ def test_sharding_is_bit_identical(m, rb, gpu_fields):
                                                          ("vert_heterogeneous", 7, "f64", 37, 16), ("vert_heterogeneous", 9, "f64", 64, 1),
                                                          ("vert_heterogeneous", 6, "f32", 300, 1), ("interface", 2, "f64", 1000, 0)])
 def test_sliced_bundles_are_bit_identical(scen, m, dtype, slice_steps, stride, rb, gpu_fields, oracle_fields):
-    """launch_mode 2 (persistent blocks, 256-ray bundles advanced in time slices through a ticket counter) vs one lane
+    """RTMI_LAUNCH_SLICED (persistent blocks, 256-ray bundles advanced in time slices through a ticket counter) vs one lane
     per ray to completion: same rows, same final state, same step counts; more bundles than resident blocks would need
     a large batch, so the ordering of a bundle's slices is exercised with short slices instead."""
     R = 5000 if m != 9 else 600
@@ -293,9 +293,9 @@ def test_sliced_bundles_are_bit_identical(scen, m, dtype, slice_steps, stride, r
         th = np.linspace(0.06, np.pi / 2, R); x0, y0 = -2.0, -2.0
         step, ms = rb.DELTA_S, int(np.ceil(80 / rb.DELTA_S) + 1)
     F = gpu_fields(scen, rb.F64 if dtype == "f64" else rb.F32)
-    a = rb.Batch(F, m, step, ms, lim, 1, th, x0, y0, record_stride=stride)
+    a = rb.Batch(F, m, step, ms, lim, 1, th, x0, y0, record_stride=stride, launch_mode="plain")
     a.run()
-    b = rb.Batch(F, m, step, ms, lim, 1, th, x0, y0, record_stride=stride, launch_mode=2, slice_steps=slice_steps)
+    b = rb.Batch(F, m, step, ms, lim, 1, th, x0, y0, record_stride=stride, launch_mode="sliced", slice_steps=slice_steps)
     b.run()
     sa, sb = a.stats(), b.stats()
     assert sa["ray_steps"] == sb["ray_steps"] == int(a.d_ray()[2].sum()) and sb["live_rays"] == 0 and sb["launches"] == 1
@@ -314,16 +314,16 @@ def test_sliced_bundles_are_bit_identical(scen, m, dtype, slice_steps, stride, r
 
 
 def test_trazar_auto_launch_mode_is_the_plain_launch_bit_for_bit(rb, gpu_fields):
-    """The reference call surface picks launch_mode 2 by itself for large batches; the return values must not notice."""
+    """The reference call surface picks the time-sliced schedule by itself for large batches; the return values must not notice."""
     F = gpu_fields("vert_heterogeneous")
     z, grd = rb.FieldSpline(F, "n"), (rb.FieldSpline(F, "dy"), rb.FieldSpline(F, "dx"))
     th = np.linspace(0.0, np.pi / 2, 70000)
-    outs = [rb.trazar(rb.op6, z, grd, False, rb.DELTA_S, 91, "3", thetas=th, record=16, launch_mode=lm) for lm in ("auto", 0)]
+    outs = [rb.trazar(rb.op6, z, grd, False, rb.DELTA_S, 91, "3", thetas=th, record=16, launch_mode=lm) for lm in ("auto", "plain")]
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
 
 
 def test_sliced_bundles_randomised(rb, gpu_fields):
-    """launch_mode 2 vs the plain launch over seeded random shapes: ray counts from 1 to 300 000, slices from 1 to 5 000
+    """RTMI_LAUNCH_SLICED vs the plain launch over seeded random shapes: ray counts from 1 to 300 000, slices from 1 to 5 000
     steps, methods of every class, record strides 0 / 1 / 5, sorted and shuffled fans, both precisions."""
     rng = np.random.default_rng(2026)
     for case in range(18):
@@ -342,9 +342,9 @@ def test_sliced_bundles_randomised(rb, gpu_fields):
             th = rng.permutation(th)
         kw = dict(record_stride=stride, rec_rows=min(ms, 1200) if stride == 1 and R > 20000 else 0)
         F = gpu_fields(scen, dt)
-        a = rb.Batch(F, m, step, ms, LIMITS[scen], 1, th, x0, y0, **kw)
+        a = rb.Batch(F, m, step, ms, LIMITS[scen], 1, th, x0, y0, launch_mode="plain", **kw)
         a.run()
-        b = rb.Batch(F, m, step, ms, LIMITS[scen], 1, th, x0, y0, launch_mode=2, slice_steps=sl, **kw)
+        b = rb.Batch(F, m, step, ms, LIMITS[scen], 1, th, x0, y0, launch_mode="sliced", slice_steps=sl, **kw)
         b.run()
         tag = f"case {case}: {scen} op{m} R={R} slice={sl} stride={stride}"
         assert b.stats()["live_rays"] == 0, tag
@@ -355,35 +355,94 @@ def test_sliced_bundles_randomised(rb, gpu_fields):
 
 
 def test_sliced_bundles_more_bundles_than_resident_blocks(rb, gpu_fields):
-    """launch_mode 2 with 1 954 bundles for at most 1 024 resident blocks and short slices: tickets of one bundle are drawn
+    """RTMI_LAUNCH_SLICED with 1 954 bundles for at most 1 024 resident blocks and short slices: tickets of one bundle are drawn
     by different blocks while its previous slice may still be running elsewhere (the per-bundle ordering), bundles die at
     very different rows (the fisheye fan); the final state must still be the lane kernel's bits."""
     R = 500_000
     lim = LIMITS["fisheye"]
     th = np.linspace(np.pi / 4, 3 * np.pi / 4, R)
     F = gpu_fields("fisheye")
-    a = rb.Batch(F, 6, 2 * np.pi / 303, 3040, lim, 1, th, 1.0, 0.0, record_stride=0)
+    a = rb.Batch(F, 6, 2 * np.pi / 303, 3040, lim, 1, th, 1.0, 0.0, record_stride=0, launch_mode="plain")
     a.run()
-    b = rb.Batch(F, 6, 2 * np.pi / 303, 3040, lim, 1, th, 1.0, 0.0, record_stride=0, launch_mode=2, slice_steps=96)
+    b = rb.Batch(F, 6, 2 * np.pi / 303, 3040, lim, 1, th, 1.0, 0.0, record_stride=0, launch_mode="sliced", slice_steps=96)
     b.run()
     assert b.stats()["live_rays"] == 0 and a.stats()["ray_steps"] == b.stats()["ray_steps"]
     assert np.array_equal(a.d_ray(), b.d_ray()) and np.array_equal(a.final(), b.final())
     a.close(); b.close()
 
 
+def test_sliced_long_slices_do_not_trip_the_wait_bound(rb, gpu_fields):
+    """The time-sliced kernel bounds its waits by wall-clock time WITHOUT PROGRESS, scaled to the longest possible slice --
+    a block that waits for the last live bundle is not a stall.  (1) op11 (74 cost evaluations per step) with slice_steps
+    2^20: every bundle runs to its end in its first slice, idle blocks wait for the slowest.  (2) one long-lived bundle
+    among 1 171 short ones, more bundles than resident blocks, slice longer than max_size (nothing is ever pushed back)."""
+    lim = LIMITS["anisotropy"]
+    th = np.linspace(0, np.pi / 2, 20000)
+    ms = int(np.ceil(80 / rb.DELTA_S) + 1)
+    a = rb.Batch(gpu_fields("anisotropy"), 11, rb.DELTA_S, ms, lim, 3, th, -2.0, -2.0, record_stride=0, launch_mode="plain")
+    a.run()
+    b = rb.Batch(gpu_fields("anisotropy"), 11, rb.DELTA_S, ms, lim, 3, th, -2.0, -2.0, record_stride=0, launch_mode="sliced",
+                 slice_steps=1 << 20)
+    b.run()                                                  # raises RtmiError(RTMI_ERR_STATE) if a wait was abandoned
+    assert b.stats()["live_rays"] == 0 and np.array_equal(a.final(), b.final()) and np.array_equal(a.d_ray(), b.d_ray())
+    a.close(); b.close()
+    R = 300_000
+    th = np.full(R, np.pi / 4 + 0.01)                        # leaves the fisheye box after a few hundred rows ...
+    th[150_000:150_256] = np.pi / 2                          # ... except one bundle on the closed circle: all 3 039 rows
+    F = gpu_fields("fisheye")
+    a = rb.Batch(F, 6, 2 * np.pi / 303, 3040, LIMITS["fisheye"], 1, th, 1.0, 0.0, record_stride=0, launch_mode="plain")
+    a.run()
+    b = rb.Batch(F, 6, 2 * np.pi / 303, 3040, LIMITS["fisheye"], 1, th, 1.0, 0.0, record_stride=0, launch_mode="sliced",
+                 slice_steps=5000)
+    b.run()
+    d = b.d_ray()
+    assert d[2].max() == 3039 and np.median(d[2]) < 1000
+    assert np.array_equal(a.final(), b.final()) and np.array_equal(a.d_ray(), d)
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("scen,m,dtype", [("vert_heterogeneous", 6, "f64"), ("fisheye", 2, "f64"), ("vert_heterogeneous", 7, "f64"),
+                                          ("vert_heterogeneous", 9, "f64"), ("vert_heterogeneous", 6, "f32")])
+def test_checkpoint_resume_is_bit_identical(scen, m, dtype, rb, gpu_fields):
+    """rtmi_batch_get_state -> rtmi_batch_set_state on a fresh batch continues a run bit for bit: the whole ray state
+    travels, including op7's position history and the unit tangent fp64 op2/op6 carry by rotation (hist4 rows 0-1)."""
+    R = 700
+    lim = LIMITS[scen]
+    if scen == "fisheye":
+        th, x0, y0, step, ms = np.linspace(np.pi / 4, 3 * np.pi / 4, R), 1.0, 0.0, 2 * np.pi / 303, 3040
+    else:
+        th, x0, y0, step, ms = np.linspace(0.06, np.pi / 2, R), -2.0, -2.0, rb.DELTA_S, 30228
+    F = gpu_fields(scen, rb.F64 if dtype == "f64" else rb.F32)
+    a = rb.Batch(F, m, step, ms, lim, 1, th, x0, y0, record_stride=1, rec_rows=3100)
+    a.run()
+    b = rb.Batch(F, m, step, ms, lim, 1, th, x0, y0, record_stride=1, rec_rows=3100)
+    b.step(777)
+    st, hist, istep = b.get_state()
+    if m in (2, 6) and dtype == "f64":
+        assert np.allclose(hist[0] ** 2 + hist[1] ** 2, 1.0, atol=1e-12) and not hist[2:].any()
+    c = rb.Batch(F, m, step, ms, lim, 1, th, x0, y0, record_stride=1, rec_rows=3100)
+    c.set_state(st, hist, istep)
+    c.run()
+    assert np.array_equal(c.d_ray(), a.d_ray()) and np.array_equal(c.final(), a.final())
+    assert np.array_equal(c.rows(778, 2300), a.rows(778, 2300))      # the rows written after the resume
+    at = istep == 777                                         # rtmi_read_final's momenta are the last recorded row's
+    assert at.any() and np.array_equal(b.final()[6:8][:, at], b.rows(777, 1)[0, 2:4][:, at])
+    a.close(); b.close(); c.close()
+
+
 @pytest.mark.parametrize("scen,m,refill_min", [("vert_heterogeneous", 6, 0), ("vert_heterogeneous", 7, 1),
                                                ("interface", 6, 48), ("vert_heterogeneous", 9, 16)])
 def test_lane_refill_is_bit_identical(scen, m, refill_min, rb, gpu_fields, oracle_fields):
-    """launch_mode 1 (persistent waves, ballot/mbcnt compaction of terminated lanes) vs one lane per ray, on a
+    """RTMI_LAUNCH_REFILL (persistent waves, ballot/mbcnt compaction of terminated lanes) vs one lane per ray, on a
     batch whose rays are in random order (neighbouring lanes terminate hundreds of steps apart)."""
     rng = np.random.default_rng(5)
     R = 3000 if m != 9 else 300
     lim = LIMITS[scen]
     th = rng.permutation(np.linspace(0.06, np.pi / 2, R))
     ms = int(np.ceil(80 / rb.DELTA_S) + 1)
-    a = rb.Batch(gpu_fields(scen), m, rb.DELTA_S, ms, lim, 1, th, -2.0, -2.0, record_stride=16)
+    a = rb.Batch(gpu_fields(scen), m, rb.DELTA_S, ms, lim, 1, th, -2.0, -2.0, record_stride=16, launch_mode="plain")
     a.run()
-    b = rb.Batch(gpu_fields(scen), m, rb.DELTA_S, ms, lim, 1, th, -2.0, -2.0, record_stride=16, launch_mode=1,
+    b = rb.Batch(gpu_fields(scen), m, rb.DELTA_S, ms, lim, 1, th, -2.0, -2.0, record_stride=16, launch_mode="refill",
                  refill_min=refill_min)
     b.step(100)                                # part of the way with the plain kernel, then drain the queue
     b.run()
@@ -430,9 +489,9 @@ def test_uniform_basis_vs_exact_basis(scen, m, rb, gpu_fields, oracle_fields):
     assert gap < 1e-11 and e_fast < REL and e_exact < REL
 
 
-@pytest.mark.parametrize("scen,m,shuffle,mode", [("vert_heterogeneous", 6, False, 0), ("vert_heterogeneous", 6, True, 0),
-                                                 ("interface", 6, False, 0), ("fisheye", 6, False, 0),
-                                                 ("vert_heterogeneous", 7, True, 1), ("anisotropy", 11, False, 0)])
+@pytest.mark.parametrize("scen,m,shuffle,mode", [("vert_heterogeneous", 6, False, "plain"), ("vert_heterogeneous", 6, True, "plain"),
+                                                 ("interface", 6, False, "plain"), ("fisheye", 6, False, "plain"),
+                                                 ("vert_heterogeneous", 7, True, "refill"), ("anisotropy", 11, False, "plain")])
 def test_lds_tile_equals_global_gather(scen, m, shuffle, mode, rb, gpu_fields):
     """field_path 2 (wave-private LDS tile of the field, re-staged as the wave moves; lanes outside the tile fall
     back to global loads) must give the same bits as field_path 1 (every lookup gathers from global memory):
@@ -721,7 +780,7 @@ def test_bad_launch_conditions_do_not_disturb_neighbours(rb, gpu_fields):
     lim = LIMITS["vert_heterogeneous"]
     th = np.array([0.3, np.nan, np.inf, 0.5, 0.7, 1e12, 0.9])
     x0 = np.array([-2.0, -2.0, -2.0, -2.0, 1e6, -2.0, np.nan])
-    for mode, path in ((0, 2), (0, 1), (1, 2)):
+    for mode, path in (("plain", 2), ("plain", 1), ("refill", 2)):
         b = rb.Batch(F, 6, rb.DELTA_S, 600, lim, 1, th, x0, -2.0, record_stride=1, launch_mode=mode, field_path=path)
         b.run()
         d, fin, rows = b.d_ray(), b.final(), b.rows()
@@ -737,7 +796,7 @@ def test_bad_launch_conditions_do_not_disturb_neighbours(rb, gpu_fields):
         rb.Batch(F, 6, rb.DELTA_S, 600, lim, 1, np.array([]), -2.0, -2.0)      # empty batch: rejected, not launched
 
 
-@pytest.mark.parametrize("scen,m,mode", [("vert_heterogeneous", 6, 0), ("interface", 7, 0), ("vert_heterogeneous", 6, 1)])
+@pytest.mark.parametrize("scen,m,mode", [("vert_heterogeneous", 6, "plain"), ("interface", 7, "plain"), ("vert_heterogeneous", 6, "refill")])
 def test_sort_rays_answers_in_caller_order(scen, m, mode, rb, gpu_fields, oracle_fields):
     """sort_rays=1 reorders rays inside the batch (coherent lanes) but every read -- d_ray, final state, rows,
     n_ray, metrics, isochrones, set_state -- answers in the caller's order, bit-identical to the unsorted batch."""
@@ -797,6 +856,57 @@ def test_north_star_1m_rays_vs_oracle_subsample(rb, gpu_fields, oracle_fields):
     assert err < REL and relerr(d[:2, sub], o["d_ray"][:2]) < REL
     n0 = 0.07142864686293911
     assert np.max(np.abs(fin[6] - n0 * np.cos(th))) / n0 < 5e-4          # the scheme's own p_x drift (CV threshold scale)
+
+
+def test_headline_bench_configuration_every_row_and_whole_record_checksum(rb, gpu_fields, oracle_fields):
+    """The configuration bench.py times, exactly (vert_heterogeneous, 1 048 576 rays, op6, fp64, full record in
+    s_ray[3072][6][R] = 151 GB, no n_ray, lazy_clear, the library's default schedule RTMI_LAUNCH_AUTO, 512-step slices):
+      * every recorded row of every 512th ray against the oracle's s_ray at 1e-9 (what the rows must hold: RT_bench.py:871-875),
+        rows past a ray's last one zero (np.zeros, :802);
+      * RTMI_LAUNCH_AUTO really runs the time-sliced kernel first and the plain launch on the re-run, and the two leave the
+        same 151 GB: a per-quantity checksum of the whole record (the bits summed as 64-bit integers, wrap-around, so the
+        order of summation does not matter) is equal between them, after the record was zeroed in between."""
+    import torch
+    from oracle import rt_oracle as O
+    R, rows = 1 << 20, 3072
+    th = np.linspace(0, np.pi / 2, R)
+    lim = LIMITS["vert_heterogeneous"]
+    ms = int(np.ceil(80 / rb.DELTA_S) + 1)
+    b = rb.Batch(gpu_fields("vert_heterogeneous"), 6, rb.DELTA_S, ms, lim, 1, th, -2.0, -2.0, record_stride=1, rec_rows=rows,
+                 lazy_clear=True, keep_n_ray=False)          # launch_mode, slice_steps: rtmi_params' defaults
+    b.run()
+    st = b.stats()
+    assert st["launch_mode_used"] == "sliced" and st["ray_steps"] == 1937541698 and st["live_rays"] == 0
+    s = b.device_tensors()["s_ray"]
+    assert tuple(s.shape) == (rows, 6, R) and s.dtype == torch.float64
+
+    def checksum():
+        return [int(v) for v in s.view(torch.int64).sum(dim=(0, 2)).cpu()]
+
+    sub = slice(0, R, 512)
+    got = s[:, :, sub].cpu().numpy()                          # 3072 x 6 x 2048 values: 302 MB of the 151 GB
+    d = b.d_ray()
+    o = O.trazar(oracle_fields("vert_heterogeneous"), 6, 1, rb.DELTA_S, ms, lim, -2.0, -2.0, th[sub], record_stride=1,
+                 rec_rows=rows, nthreads=8)
+    assert np.array_equal(d[2][sub], o["d_ray"][2])
+    err = relerr(got, o["s_ray"])
+    print(f"headline configuration: {got.shape[0]} rows x 6 x {got.shape[2]} rays vs oracle: max rel err {err:.2e}")
+    assert err < REL
+    last = d[2][sub].astype(int)
+    for k in range(got.shape[2]):
+        assert not got[last[k] + 1:, :, k].any()             # rows beyond the last written one stay zero
+    c_sliced = checksum()
+    s.zero_()                                                 # lazy_clear: reset itself does not clear; make the re-run prove itself
+    torch.cuda.synchronize()
+    b.reset(); b.run()
+    st2 = b.stats()
+    assert st2["launch_mode_used"] == "plain" and st2["ray_steps"] == st["ray_steps"]
+    c_plain = checksum()
+    assert c_sliced == c_plain, (c_sliced, c_plain)
+    assert np.array_equal(s[:, :, sub].cpu().numpy(), got)
+    b.reset(); b.run()                                        # third run: the faster of the two, same record again
+    assert b.stats()["launch_mode_used"] in ("sliced", "plain") and checksum() == c_sliced
+    b.close()
 
 
 @pytest.mark.parametrize("scen,m", [("vert_heterogeneous", 6), ("fisheye", 2), ("interface", 8), ("vert_heterogeneous", 3),
