@@ -297,9 +297,11 @@ def main():
             if batch.stats()["live_rays"] == 0:
                 break
 
-    # untimed passes: --warmup of them, at least two -- RTMI_LAUNCH_AUTO times one run under each of its two schedules
-    # (rtmi_params.launch_mode) before it settles on the faster, and that belongs to the warm-up, not to the timed region
-    for _ in range(max(args.warmup, 2)):
+    # untimed passes: --warmup of them, at least four with --mode auto -- RTMI_LAUNCH_AUTO times two runs under each of its
+    # two schedules (rtmi_params.launch_mode) before it settles on the faster, and that belongs to the warm-up, not to the
+    # timed region
+    untimed = max(args.warmup, 4 if args.mode == "auto" else 1)
+    for _ in range(untimed):
         one_pass()
     barrier()
     t0 = time.perf_counter()
@@ -393,7 +395,7 @@ def main():
         out = {
             "metric": "ray-steps/sec (whole node) on vert_heterogeneous, 1M rays; % HBM roofline",
             "value": total_steps / dt, "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "untimed_passes": max(args.warmup, 2), "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+            "warmup": args.warmup, "untimed_passes": untimed, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
             "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.scenario}, {R_total} rays in total ({R_local} on rank 0; fan linspace over {R_total} "
                                    f"rays, interleaved across ranks), op{args.method}, DELTA_S={step:.12g}, "

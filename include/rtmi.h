@@ -96,8 +96,8 @@ typedef struct {
     int32_t launch_mode;     /* how rtmi_run schedules the loop on the device (rtmi_launch_mode); results are bit-identical in
                                 all of them.  0 = RTMI_LAUNCH_AUTO, the value a zero-initialised struct gets: time-sliced bundles
                                 when the batch has more 256-ray bundles than the device holds resident blocks, else the plain
-                                launch; a batch that is re-run (rtmi_batch_reset + rtmi_run) tries the other schedule once and
-                                keeps the faster by its measured kernel time (rtmi_stats.launch_mode_used tells which ran) */
+                                launch; a batch that is re-run (rtmi_batch_reset + rtmi_run) times each schedule twice and then
+                                keeps the faster (rtmi_stats.launch_mode_used tells which ran) */
     int32_t block_size;      /* 0 -> default */
     int32_t refill_min;      /* RTMI_LAUNCH_REFILL: compact when this many lanes of a wave are idle (0 -> 32) */
     int32_t exact_basis;     /* 0: uniform-knot cubic basis in interior cells (<= 4e-14 from FITPACK's weights);
@@ -131,14 +131,16 @@ int rtmi_batch_create(const rtmi_field *f, const rtmi_params *p, int64_t R, cons
  * with istep+1 < max_size becomes live.  This is the explicit-argument form of one selected_func call
  * (:868): opN(i_angle, init_n, i_grad, i_unitv, i_vpos, coef_i, grd, z, step) with caller-chosen inputs.
  * fp64 op2/op6 batches carry the unit tangent (cos theta, sin theta) as ray state (it is advanced by rotation, not
- * recomputed from theta every step): there hist4[0], hist4[1] = (cos, sin) as rtmi_batch_get_state returned them, so that
- * a checkpointed run resumes bit for bit; with hist4 == NULL the unit tangent restarts from sin/cos of theta (a state
- * of the caller's own making has no other), which may differ from the carried pair in the last bits. */
+ * recomputed from theta every step); a state set here restarts it from sin/cos of theta -- a state of the caller's own
+ * making has no other.  To continue a run from a checkpoint use rtmi_batch_get_state / rtmi_batch_restore_state. */
 int rtmi_batch_set_state(rtmi_batch *b, const double *state9, const double *hist4, const int32_t *istep);
-/* The inverse of rtmi_batch_set_state: copy the current ray state to host buffers (any may be NULL), same layouts, caller's
- * ray order.  hist4 rows that the method does not use are written as 0.  get_state + set_state on a batch with the same
- * parameters continues a run bit for bit (checkpoint / resume; the reference has no counterpart, :866 runs to the end). */
-int rtmi_batch_get_state(rtmi_batch *b, double *state9, double *hist4, int32_t *istep);
+/* Checkpoint: copy the current ray state to host buffers (any may be NULL), caller's ray order: state9 and istep as in
+ * rtmi_batch_set_state; aux4[4][R] = the method's private state -- op7: the position history (hist4); fp64 op2/op6: rows 0-1
+ * the carried unit tangent (cos, sin), rows 2-3 zero; otherwise zero. */
+int rtmi_batch_get_state(rtmi_batch *b, double *state9, double *aux4, int32_t *istep);
+/* Resume: rtmi_batch_set_state with the method's private state taken from aux4 as rtmi_batch_get_state returned it.  On a
+ * batch with the same parameters the run continues bit for bit (the reference has no counterpart: :866 runs to the end). */
+int rtmi_batch_restore_state(rtmi_batch *b, const double *state9, const double *aux4, const int32_t *istep);
 /* Give every ray its own DELTA_S and max_size (host arrays [R], caller's ray order): one batch then holds the whole
  * DELTA_S calibration sweep, candidate x ray (search_delta over delta_s_options, RT_bench.py:950-958, 1317-1318).
  * max_size[k] <= params.max_size (which sizes the trajectory arrays).  Survives rtmi_batch_reset.  Only valid on a

@@ -63,6 +63,7 @@ SYMBOLS = {
                                     C.POINTER(C.c_void_p)]),
     "rtmi_batch_set_state": (C.c_int, [C.c_void_p, _dp, _dp, _ip]),
     "rtmi_batch_get_state": (C.c_int, [C.c_void_p, _dp, _dp, _ip]),
+    "rtmi_batch_restore_state": (C.c_int, [C.c_void_p, _dp, _dp, _ip]),
     "rtmi_batch_set_per_ray": (C.c_int, [C.c_void_p, _dp, _ip]),
     "rtmi_batch_reset": (C.c_int, [C.c_void_p]),
     "rtmi_step": (C.c_int, [C.c_void_p, C.c_int32]),

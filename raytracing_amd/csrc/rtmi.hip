@@ -999,6 +999,7 @@ struct rtmi_batch {
     // RTMI_LAUNCH_AUTO: kernel time of the last complete run from the launch conditions under each schedule
     // ([0] sliced, [1] plain; < 0: not measured yet), and what the last rtmi_run used
     double auto_ms[2] = {-1.0, -1.0};
+    int auto_n[2] = {0, 0};      // timed runs per schedule so far
     int mode_used = RTMI_LAUNCH_PLAIN;
     void* staging = nullptr;     // device scratch of the read / metric / set_state paths, grown on demand, freed with the batch
     size_t staging_bytes = 0;
@@ -1357,7 +1358,7 @@ RTMI_EXPORT int rtmi_batch_reset(rtmi_batch* b) {
     return batch_init_state(b, b->dirty || !b->p.lazy_clear);
 }
 
-template <typename T> __global__ void k_set_state(BatchDev<T> a, const double* st, const double* hist, const int* istep) {
+template <typename T> __global__ void k_set_state(BatchDev<T> a, const double* st, const double* hist, const int* istep, int restore) {
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.R) return;
     const long o = out_index(a, k);
@@ -1368,7 +1369,7 @@ template <typename T> __global__ void k_set_state(BatchDev<T> a, const double* s
     if (a.has_hist && hist)
         for (int q = 0; q < 4; q++) a.aux(3 + q)[k] = (T)hist[(size_t)q * a.R + o];
     if (a.rot) {
-        if (hist) {                               // the carried unit tangent of a checkpoint (rtmi_batch_get_state)
+        if (hist && restore) {                    // the carried unit tangent of a checkpoint (rtmi_batch_get_state)
             a.unit(0)[k] = (T)hist[o]; a.unit(1)[k] = (T)hist[(size_t)a.R + o];
         } else {                                  // a state given from outside starts from its angle's own sin/cos
             T sn, cs;
@@ -1395,9 +1396,9 @@ template <typename T> __global__ void k_get_state(BatchDev<T> a, double* out, in
     oi[o] = a.istep[k];
 }
 
-RTMI_EXPORT int rtmi_batch_set_state(rtmi_batch* b, const double* state9, const double* hist4, const int32_t* istep) {
-    ARG_TRY(b && state9, "rtmi_batch_set_state: null");
-    DEVICE_TRY(b->field, "rtmi_batch_set_state");
+static int set_state_impl(rtmi_batch* b, const double* state9, const double* hist4, const int32_t* istep, int restore, const char* who) {
+    ARG_TRY(b && state9, std::string(who) + ": null");
+    DEVICE_TRY(b->field, who);
     const size_t R = (size_t)b->R;
     b->dirty = true;
     b->dirty_state = true;
@@ -1412,14 +1413,21 @@ RTMI_EXPORT int rtmi_batch_set_state(rtmi_batch* b, const double* state9, const 
     if (e == hipSuccess) {
         const dim3 g((unsigned)((R + 255) / 256)), blk(256);
         if (b->p.dtype == RTMI_F64)
-            hipLaunchKernelGGL(k_set_state<double>, g, blk, 0, b->stream, batch_dev<double>(b), d, hist4 ? d + 9 * R : nullptr, istep ? di : nullptr);
+            hipLaunchKernelGGL(k_set_state<double>, g, blk, 0, b->stream, batch_dev<double>(b), d, hist4 ? d + 9 * R : nullptr, istep ? di : nullptr, restore);
         else
-            hipLaunchKernelGGL(k_set_state<float>, g, blk, 0, b->stream, batch_dev<float>(b), d, hist4 ? d + 9 * R : nullptr, istep ? di : nullptr);
+            hipLaunchKernelGGL(k_set_state<float>, g, blk, 0, b->stream, batch_dev<float>(b), d, hist4 ? d + 9 * R : nullptr, istep ? di : nullptr, restore);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
-    if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_batch_set_state: ") + hipGetErrorString(e));
+    if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string(who) + ": " + hipGetErrorString(e));
     return RTMI_OK;
+}
+RTMI_EXPORT int rtmi_batch_set_state(rtmi_batch* b, const double* state9, const double* hist4, const int32_t* istep) {
+    return set_state_impl(b, state9, hist4, istep, 0, "rtmi_batch_set_state");
+}
+RTMI_EXPORT int rtmi_batch_restore_state(rtmi_batch* b, const double* state9, const double* aux4, const int32_t* istep) {
+    ARG_TRY(aux4 && istep, "rtmi_batch_restore_state: null (pass what rtmi_batch_get_state returned)");
+    return set_state_impl(b, state9, aux4, istep, 1, "rtmi_batch_restore_state");
 }
 
 RTMI_EXPORT int rtmi_batch_get_state(rtmi_batch* b, double* state9, double* hist4, int32_t* istep) {
@@ -1602,16 +1610,24 @@ RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
     // bundles would be dispatched in rounds (cfg3) and loses a few per cent where they would not.  A run
     // that starts from the launch conditions is timed; once both schedules have a time the faster one is kept.
     const bool fresh = b->launches == 0 && !b->dirty_state;
-    const int pick = b->auto_ms[0] < 0 ? 0 : b->auto_ms[1] < 0 ? 1 : (b->auto_ms[0] <= b->auto_ms[1] ? 0 : 1);
+    // explore: sliced, plain, sliced, plain (a batch's very first run is cold -- clocks, caches, page tables -- so one sample
+    // each would favour whichever ran second); then the smaller of each schedule's best times, slicing kept unless the
+    // plain launch is more than 1 % ahead (it is the schedule that does not depend on how the fan's lengths fall into rounds)
+    int pick;
+    if (b->auto_n[0] + b->auto_n[1] < 4 && b->auto_ms[0] < 1e29) pick = b->auto_n[0] <= b->auto_n[1] ? 0 : 1;
+    else pick = b->auto_ms[1] < 0.99 * b->auto_ms[0] ? 1 : 0;
     rc = pick == 0 ? run_sliced(b, &ev) : run_plain(b, &ev);
     if (rc == RTMI_ERR_STATE && pick == 0) {
         // the sliced launch gave up a wait (it reports instead of hanging); what it advanced is valid state: finish plainly
-        b->auto_ms[0] = 1e30;
+        b->auto_ms[0] = 1e30; b->auto_n[0] = 4;
         return run_plain(b, &ev);
     }
     if (rc == RTMI_OK && fresh && ev) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, ev->first, ev->second) == hipSuccess) b->auto_ms[pick] = ms;   // stream is idle (read_counters)
+        if (hipEventElapsedTime(&ms, ev->first, ev->second) == hipSuccess) {   // the stream is idle (read_counters)
+            b->auto_ms[pick] = b->auto_n[pick] == 0 ? (double)ms : std::min(b->auto_ms[pick], (double)ms);
+            b->auto_n[pick]++;
+        }
     }
     return rc;
 }

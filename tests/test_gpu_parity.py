@@ -404,7 +404,7 @@ def test_sliced_long_slices_do_not_trip_the_wait_bound(rb, gpu_fields):
 @pytest.mark.parametrize("scen,m,dtype", [("vert_heterogeneous", 6, "f64"), ("fisheye", 2, "f64"), ("vert_heterogeneous", 7, "f64"),
                                           ("vert_heterogeneous", 9, "f64"), ("vert_heterogeneous", 6, "f32")])
 def test_checkpoint_resume_is_bit_identical(scen, m, dtype, rb, gpu_fields):
-    """rtmi_batch_get_state -> rtmi_batch_set_state on a fresh batch continues a run bit for bit: the whole ray state
+    """rtmi_batch_get_state -> rtmi_batch_restore_state on a fresh batch continues a run bit for bit: the whole ray state
     travels, including op7's position history and the unit tangent fp64 op2/op6 carry by rotation (hist4 rows 0-1)."""
     R = 700
     lim = LIMITS[scen]
@@ -421,7 +421,7 @@ def test_checkpoint_resume_is_bit_identical(scen, m, dtype, rb, gpu_fields):
     if m in (2, 6) and dtype == "f64":
         assert np.allclose(hist[0] ** 2 + hist[1] ** 2, 1.0, atol=1e-12) and not hist[2:].any()
     c = rb.Batch(F, m, step, ms, lim, 1, th, x0, y0, record_stride=1, rec_rows=3100)
-    c.set_state(st, hist, istep)
+    c.restore_state(st, hist, istep)
     c.run()
     assert np.array_equal(c.d_ray(), a.d_ray()) and np.array_equal(c.final(), a.final())
     assert np.array_equal(c.rows(778, 2300), a.rows(778, 2300))      # the rows written after the resume
@@ -904,7 +904,8 @@ def test_headline_bench_configuration_every_row_and_whole_record_checksum(rb, gp
     c_plain = checksum()
     assert c_sliced == c_plain, (c_sliced, c_plain)
     assert np.array_equal(s[:, :, sub].cpu().numpy(), got)
-    b.reset(); b.run()                                        # third run: the faster of the two, same record again
+    for _ in range(3):                                        # two more exploration runs, then the faster: same record again
+        b.reset(); b.run()
     assert b.stats()["launch_mode_used"] in ("sliced", "plain") and checksum() == c_sliced
     b.close()
 
