@@ -136,11 +136,13 @@ int rtmi_batch_create(const rtmi_field *f, const rtmi_params *p, int64_t R, cons
 int rtmi_batch_set_state(rtmi_batch *b, const double *state9, const double *hist4, const int32_t *istep);
 /* Checkpoint: copy the current ray state to host buffers (any may be NULL), caller's ray order: state9 and istep as in
  * rtmi_batch_set_state; aux4[4][R] = the method's private state -- op7: the position history (hist4); fp64 op2/op6: rows 0-1
- * the carried unit tangent (cos, sin), rows 2-3 zero; otherwise zero. */
-int rtmi_batch_get_state(rtmi_batch *b, double *state9, double *aux4, int32_t *istep);
+ * the carried unit tangent (cos, sin), rows 2-3 zero; otherwise zero; alive[R] = 1 while the ray would still step (0 once it
+ * left the box, :878, or ran out of rows). */
+int rtmi_batch_get_state(rtmi_batch *b, double *state9, double *aux4, int32_t *istep, uint8_t *alive);
 /* Resume: rtmi_batch_set_state with the method's private state taken from aux4 as rtmi_batch_get_state returned it.  On a
  * batch with the same parameters the run continues bit for bit (the reference has no counterpart: :866 runs to the end). */
-int rtmi_batch_restore_state(rtmi_batch *b, const double *state9, const double *aux4, const int32_t *istep);
+int rtmi_batch_restore_state(rtmi_batch *b, const double *state9, const double *aux4, const int32_t *istep,
+                             const uint8_t *alive);
 /* Give every ray its own DELTA_S and max_size (host arrays [R], caller's ray order): one batch then holds the whole
  * DELTA_S calibration sweep, candidate x ray (search_delta over delta_s_options, RT_bench.py:950-958, 1317-1318).
  * max_size[k] <= params.max_size (which sizes the trajectory arrays).  Survives rtmi_batch_reset.  Only valid on a

@@ -50,24 +50,70 @@ static const double GOLD_TOL = 1.4901161193847656e-08;  /* sqrt(eps) = 2^-26, :6
 static double gold_ratio(void) { return (sqrt(5.0) - 1.0) / 2.0; } /* :65 */
 
 /* numpy's scalar x**2 is libm pow(x, 2.0).  On glibc 2.35 that differs from the rounded product x*x by one ulp for
- * ~0.09 % of arguments.  gcc folds pow(x, 2.0) into x*x, so SQ() below IS the rounded product: a known deviation
- * from the reference, kept because the device path reproduces x*x bit for bit and not glibc's pow (measured effect:
- * none of the reference's trajectory or single-step fixtures moves by more than 2e-13).  The one place where the
- * reference's pow is honoured is DELTA_S**2 (:330), computed once per call through libm_square(). */
+ * ~0.09 % of arguments.  gcc folds pow(x, 2.0) into x*x, so by default SQ() IS the rounded product: a known deviation
+ * from the reference, kept because the device path reproduces x*x bit for bit and not glibc's pow.  Built with
+ * -DRTO_SQ_POW (oracle/librt_oracle_pow.so, `make pow`) SQ() is the reference-faithful libm pow through a volatile
+ * exponent; tests/test_oracle_golden.py runs the trajectory fixtures with both and records what the deviation costs
+ * (none of the reference's fixtures moves by more than 3e-17 because of it).  The one place where the reference's pow is
+ * honoured in both builds is DELTA_S**2 (:330), computed once per call through libm_square(). */
+#ifdef RTO_SQ_POW
+static double SQ(double x) { volatile double two = 2.0; return pow(x, two); }
+#else
 static inline double SQ(double x) { return x * x; }
+#endif
 static double libm_square(double x) { volatile double two = 2.0; return pow(x, two); }
 static inline double DOT2(double a0, double a1, double b0, double b1) {
     return fma(a1, b1, a0 * b0);                                    /* np.dot, 2 elements */
 }
 static inline double NORM2(double a0, double a1) { return sqrt(DOT2(a0, a1, a0, a1)); }
 
+/* np.exp on float64 ARRAYS as numpy 2.2.6 evaluates it on an AVX512_SKX machine (the build container; RT_bench.py:107
+ * calls it on the meshgrid): numpy dispatches to Intel SVML's __svml_exp8_ha (numpy/_core/src/umath/svml, BSD-3), not
+ * to libm -- the two differ in the last bit for 4.5 % of arguments.  Restated from the published routine's main path:
+ * N = floor(x*log2(e)*16)/16 (an fma rounded toward zero onto a 2^-4 grid), r = x - N*ln2 (hi/lo), a degree-6
+ * polynomial in three interleaved pairs, 2^(j/16) from a 16-entry table with a correction term, scaled by 2^floor(N).
+ * tools/check_np_exp.py compares it with np.exp on 2.6e7 arguments: 0 mismatches.  |x| >= 707.7 takes SVML's scalar
+ * fallback, restated here as libm exp: there the interface field is sqrt(2) or 1 to the last bit whatever the
+ * exponential's last bits are (1 + e rounds to e or to 1). */
+static double np_exp(double x) {
+    static const double T16[16] = {0x1.0000000000000p+0, 0x1.0b5586cf9890fp+0, 0x1.172b83c7d517bp+0, 0x1.2387a6e756238p+0,
+        0x1.306fe0a31b715p+0, 0x1.3dea64c123422p+0, 0x1.4bfdad5362a27p+0, 0x1.5ab07dd485429p+0, 0x1.6a09e667f3bcdp+0,
+        0x1.7a11473eb0187p+0, 0x1.8ace5422aa0dbp+0, 0x1.9c49182a3f090p+0, 0x1.ae89f995ad3adp+0, 0x1.c199bdd85529cp+0,
+        0x1.d5818dcfba487p+0, 0x1.ea4afa2a490dap+0};                                  /* 2^(j/16), correctly rounded */
+    static const double TL16[16] = {0x0.0p+0, 0x1.79aa65d837b6dp-54, -0x1.01b15eaa59348p-55, 0x1.68efde3a8a894p-54,
+        0x1.34d754db0abb6p-55, 0x1.59f48a72a4c6dp-55, 0x1.690cebb7aafb0p-56, 0x1.063e1e21c5409p-54, -0x1.3b3efbf5e2228p-54,
+        -0x1.b32dcb94da51dp-56, 0x1.db72fc1f0eab4p-55, 0x1.1affc2b91ce27p-56, 0x1.c1a7792cb3387p-55, 0x1.36eae30af0cb3p-56,
+        0x1.4a385a63d07a7p-56, -0x1.ff7128fd391f0p-55};                                /* (2^(j/16) - T16[j]) / T16[j] */
+    const double L2E = 0x1.71547652b82fep+0, LN2H = 0x1.62e42fefa39efp-1, LN2L = 0x1.abc9e3b39803fp-56;
+    const double A = 0x1.7411836940c04p-10, B = 0x1.1101cbbc265c0p-7, C = 0x1.55557242d68fep-5, D = 0x1.5555553939732p-3,
+                 E = 0x1.000000000d008p-1, F = 0x1.fffffffffff70p-1;
+    if (!(fabs(x) < 0x1.61da04cbafe44p+9)) return exp(x);
+    /* fma(x, L2E, 1.5*2^48 + 1023) rounded toward zero, minus the shifter: floor of the EXACT product on the 1/16 grid */
+    double p = x * L2E, e = fma(x, L2E, -p);
+    double f16 = floor(p * 16.0);
+    if (f16 == p * 16.0 && e < 0) f16 -= 1.0;
+    double N = f16 / 16.0;
+    int j = (int)((long long)f16 & 15);
+    double r = fma(-N, LN2H, x);
+    r = fma(-N, LN2L, r);
+    double r2 = r * r;
+    double P1 = fma(A, r, B), P2 = fma(C, r, D), P3 = fma(E, r, F);
+    double q = fma(r2, P1, P2);
+    q = fma(r2, q, P3);
+    double t = fma(q, r, TL16[j]);
+    t = fma(T16[j], t, T16[j]);
+    return ldexp(t, (int)floor(N));
+}
+
+RTO_API void rto_np_exp_many(const double *x, double *y, long n) { for (long i = 0; i < n; i++) y[i] = np_exp(x[i]); }
+
 /* ---- scenario fields: RT_bench.py:106-116 -------------------------------- */
 enum { SC_INTERFACE = 1, SC_FISHEYE = 2, SC_VERT = 3, SC_ANISO = 4 };
 
 static double scenario_n(int sc, double a, double b) {
     switch (sc) {
-    case SC_INTERFACE: /* :107 */
-        return sqrt(2.0) - (sqrt(2.0) - 1.0) / (1.0 + exp(-b / THCK_PARAM));
+    case SC_INTERFACE: /* :107; np.exp on the meshgrid array -> numpy's vector loop, see np_exp() */
+        return sqrt(2.0) - (sqrt(2.0) - 1.0) / (1.0 + np_exp(-b / THCK_PARAM));
     case SC_FISHEYE:   /* :111, np.power(a,2) on arrays is an exact square */
         return 1.0 / (1.0 + a * a + b * b);
     default: {         /* :115-116, scenario 4 reuses it (:1579) */
@@ -196,6 +242,90 @@ static void collocation_solve(const double *x, int m, const double *t, double *d
     free(A);
 }
 
+/* FITPACK regrid with s = 0 (fpregr.f -> one call of fpgrre.f with p = -1): the interpolating spline's coefficients as the
+ * least-squares solution of (spy) c (spx)' = z by Givens rotations WITHOUT square-root-free tricks -- each data row of
+ * the observation matrix is rotated into the band triangle (fpgivs/fprota), the same rotations go over the right-hand
+ * sides, first along FITPACK's x (the rows of our [qy][qx] arrays, :456 passes (y, x, Z)), then along its y; two
+ * back substitutions (fpback) finish.  Restated operation by operation; the Fortran is compiled without FMA in scipy's
+ * wheels, this file with -ffp-contract=off.  Result: the coefficient arrays are scipy's get_coeffs() bit for bit
+ * (tests/test_oracle_golden.py: field_*.npz blocks compared with array_equal).  The banded LU above solves the same system
+ * and lands 1.3e-15 away; it is kept as rto_set_field_solver(1) to measure exactly that. */
+typedef struct { int m; int *nr; double (*cs)[4][2]; double (*a)[4]; } fp_axis;   /* rotations + band triangle of one axis */
+static void fpgivs(double piv, double *ww, double *c, double *s) {
+    double store = fabs(piv), dd;
+    if (store >= *ww) { double q = *ww / piv; dd = store * sqrt(1.0 + q * q); }
+    else { double q = piv / *ww; dd = *ww * sqrt(1.0 + q * q); }
+    *c = *ww / dd; *s = piv / dd; *ww = dd;
+}
+static inline void fprota(double c, double s, double *a, double *b) {
+    double s1 = *a, s2 = *b;
+    *b = c * s2 + s * s1;
+    *a = c * s1 - s * s2;
+}
+static fp_axis fp_axis_build(const double *x, int m, const double *t) {
+    fp_axis A; A.m = m;
+    A.nr = malloc(m * sizeof(int)); A.cs = calloc((size_t)m, sizeof *A.cs); A.a = calloc((size_t)m, sizeof *A.a);
+    int l = 3, number = 0;                        /* fpgrre: l = kx1 (1-based), the interval of x(it) */
+    for (int it = 0; it < m; it++) {
+        double h[5];
+        while (!(x[it] < t[l + 1] || l == m - 1)) { l++; number++; }
+        fpbspl(t, 3, x[it], l, h);
+        A.nr[it] = number;
+        int irot = number - 1;
+        for (int i = 0; i < 4; i++) {
+            irot++;
+            double piv = h[i];
+            A.cs[it][i][0] = A.cs[it][i][1] = 0.0;           /* (0, 0): no rotation (piv == 0) */
+            if (piv == 0.0) continue;
+            double c, s;
+            fpgivs(piv, &A.a[irot][0], &c, &s);
+            A.cs[it][i][0] = c; A.cs[it][i][1] = s;
+            for (int j = i + 1, i2 = 1; j < 4; j++, i2++) fprota(c, s, &h[j], &A.a[irot][i2]);
+        }
+    }
+    return A;
+}
+static void fp_axis_free(fp_axis *A) { free(A->nr); free(A->cs); free(A->a); }
+/* fpback with bandwidth 4 on n values of stride es */
+static void fpback4(const double (*a)[4], double *z, int n, long es) {
+    z[(n - 1) * es] = z[(n - 1) * es] / a[n - 1][0];
+    for (int i = n - 2, j = 2; i >= 0; i--, j++) {
+        double store = z[i * es];
+        int i1 = j <= 3 ? j - 1 : 3;
+        for (int l = 1; l <= i1; l++) store = store - z[(i + l) * es] * a[i][l];
+        z[i * es] = store / a[i][0];
+    }
+}
+static void regrid_interp(const double *xs, int qx, const double *tx, const double *ys, int qy, const double *ty, double *d) {
+    fp_axis AY = fp_axis_build(ys, qy, ty), AX = fp_axis_build(xs, qx, tx);   /* FITPACK's x is our y (rows) */
+    size_t nz = (size_t)qx * qy;
+    double *q = calloc(nz, sizeof(double)), *right = malloc((qx > qy ? qx : qy) * sizeof(double));
+    for (int it = 0; it < qy; it++) {               /* rows of z into the triangle of FITPACK-x; q = g [qy][qx] */
+        memcpy(right, d + (size_t)it * qx, qx * sizeof(double));
+        for (int i = 0; i < 4; i++) {
+            double c = AY.cs[it][i][0], s = AY.cs[it][i][1];
+            if (c == 0.0 && s == 0.0) continue;
+            double *qr = q + (size_t)(AY.nr[it] + i) * qx;
+            for (int j = 0; j < qx; j++) fprota(c, s, &right[j], &qr[j]);
+        }
+    }
+    memset(d, 0, nz * sizeof(double));               /* c = 0; columns of g into the triangle of FITPACK-y */
+    for (int it = 0; it < qx; it++) {
+        for (int j = 0; j < qy; j++) right[j] = q[(size_t)j * qx + it];
+        for (int i = 0; i < 4; i++) {
+            double c = AX.cs[it][i][0], s = AX.cs[it][i][1];
+            if (c == 0.0 && s == 0.0) continue;
+            int col = AX.nr[it] + i;
+            for (int j = 0; j < qy; j++) fprota(c, s, &right[j], &d[(size_t)j * qx + col]);
+        }
+    }
+    for (int i = 0; i < qy; i++) fpback4((const double (*)[4])AX.a, d + (size_t)i * qx, qx, 1);      /* (ry) c1 = h */
+    for (int j = 0; j < qx; j++) fpback4((const double (*)[4])AY.a, d + j, qy, qx);                    /* c (rx)' = c1 */
+    free(q); free(right); fp_axis_free(&AY); fp_axis_free(&AX);
+}
+static int g_field_solver = 0;    /* 0: FITPACK's Givens QR (the reference's bits); 1: banded LU (round 1-2's solver) */
+RTO_API void rto_set_field_solver(int lu) { g_field_solver = lu; }
+
 RTO_API void rto_field_free(rto_field *f) {
     if (!f) return;
     free(f->x); free(f->y); free(f->Z); free(f->cdy); free(f->cdx);
@@ -220,10 +350,15 @@ RTO_API rto_field *rto_field_from_samples(const double *x, int qx, const double 
     interp_knots(x, qx, 3, f->tx3); interp_knots(y, qy, 3, f->ty3);
     interp_knots(x, qx, 1, f->tx1); interp_knots(y, qy, 1, f->ty1);
     /* :456-457 separable interpolation: along axis 1 (x) for every row, then axis 0 (y) */
-    collocation_solve(x, qx, f->tx3, f->cdy, 1, qx, qy);
-    collocation_solve(y, qy, f->ty3, f->cdy, qx, 1, qx);
-    collocation_solve(x, qx, f->tx3, f->cdx, 1, qx, qy);
-    collocation_solve(y, qy, f->ty3, f->cdx, qx, 1, qx);
+    if (g_field_solver == 0) {
+        regrid_interp(x, qx, f->tx3, y, qy, f->ty3, f->cdy);
+        regrid_interp(x, qx, f->tx3, y, qy, f->ty3, f->cdx);
+    } else {
+        collocation_solve(x, qx, f->tx3, f->cdy, 1, qx, qy);
+        collocation_solve(y, qy, f->ty3, f->cdy, qx, 1, qx);
+        collocation_solve(x, qx, f->tx3, f->cdx, 1, qx, qy);
+        collocation_solve(y, qy, f->ty3, f->cdx, qx, 1, qx);
+    }
     return f;
 }
 

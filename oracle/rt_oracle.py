@@ -10,18 +10,22 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "librt_oracle.so")
+# two builds of rt_oracle.c: "default" squares with x*x (what the device reproduces); "pow" squares like the reference's numpy
+# scalars do, with libm pow(x, 2.0) (see SQ() in rt_oracle.c) -- the reference-faithful build the fixtures are ALSO checked with
+_SOS = {"default": os.path.join(_HERE, "librt_oracle.so"), "pow": os.path.join(_HERE, "librt_oracle_pow.so")}
+_SO = _SOS["default"]
 
 SCENARIOS = {"interface": 1, "fisheye": 2, "vert_heterogeneous": 3, "anisotropy": 4}
 
 _dp = C.POINTER(C.c_double)
 
 
-def build(force=False):
+def build(force=False, variant="default"):
     src = os.path.join(_HERE, "rt_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "librt_oracle.so"])
-    return _SO
+    so = _SOS[variant]
+    if force or not os.path.exists(so) or (os.path.exists(src) and os.path.getmtime(so) < os.path.getmtime(src)):
+        subprocess.check_call(["make", "-C", _HERE, "-s", os.path.basename(so)])
+    return so
 
 
 class _Params(C.Structure):
@@ -30,14 +34,29 @@ class _Params(C.Structure):
                 ("rec_rows", C.c_long), ("nthreads", C.c_int)]
 
 
-_lib = None
+_libs = {}
+_variant = "default"
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        build()
-        L = C.CDLL(_SO)
+def variant(name):
+    """Context manager: calls inside use the named build ("default" | "pow").  Fields remember the build they came from."""
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        global _variant
+        old, _variant = _variant, name
+        try:
+            yield
+        finally:
+            _variant = old
+    return cm()
+
+
+def lib(which=None):
+    which = which or _variant
+    if which not in _libs:
+        L = C.CDLL(build(variant=which))
         L.rto_field_build.restype = C.c_void_p
         L.rto_field_build.argtypes = [C.c_int] + [C.c_double] * 5
         L.rto_field_from_samples.restype = C.c_void_p
@@ -50,8 +69,22 @@ def lib():
         L.rto_trazar.restype = C.c_long
         L.rto_trazar.argtypes = [C.c_void_p, C.POINTER(_Params), C.c_int] + [_dp] * 7
         L.rto_max_threads.restype = C.c_int
-        _lib = L
-    return _lib
+        L.rto_set_field_solver.argtypes = [C.c_int]
+        L.rto_np_exp_many.argtypes = [_dp, _dp, C.c_long]
+        _libs[which] = L
+    return _libs[which]
+
+
+def set_field_solver(lu):
+    """0 (default): FITPACK's Givens QR, the reference's bits; 1: the banded LU rounds 1-2 used (1.3e-15 away)."""
+    lib().rto_set_field_solver(int(lu))
+
+
+def np_exp(x):
+    """The oracle's restatement of numpy's float64 array exp (SVML __svml_exp8_ha), for tools/check_np_exp.py."""
+    x = _f64(x); y = np.empty_like(x)
+    lib().rto_np_exp_many(_p(x), _p(y), x.size)
+    return y
 
 
 def _p(a):
@@ -67,9 +100,10 @@ class Field:
 
     def __init__(self, scenario, limits, delta):
         sc = SCENARIOS[scenario] if isinstance(scenario, str) else int(scenario)
-        self.h = lib().rto_field_build(sc, *[float(v) for v in limits], float(delta))
+        self.L = lib()
+        self.h = self.L.rto_field_build(sc, *[float(v) for v in limits], float(delta))
         qx, qy = C.c_int(), C.c_int()
-        lib().rto_field_dims(self.h, C.byref(qx), C.byref(qy))
+        self.L.rto_field_dims(self.h, C.byref(qx), C.byref(qy))
         self.qx, self.qy = qx.value, qy.value
 
     @classmethod
@@ -77,25 +111,26 @@ class Field:
         """interpolacion(x, y, Z, X, Y) (RT_bench.py:435) for caller-provided samples."""
         x = _f64(x); y = _f64(y); Z = _f64(Z)
         self = cls.__new__(cls)
-        self.h = lib().rto_field_from_samples(_p(x), len(x), _p(y), len(y), _p(Z), float(delta))
+        self.L = lib()
+        self.h = self.L.rto_field_from_samples(_p(x), len(x), _p(y), len(y), _p(Z), float(delta))
         self.qx, self.qy = len(x), len(y)
         return self
 
     def arrays(self):
         x = np.empty(self.qx); y = np.empty(self.qy)
         Z = np.empty((self.qy, self.qx)); cdy = np.empty_like(Z); cdx = np.empty_like(Z)
-        lib().rto_field_get(self.h, _p(x), _p(y), _p(Z), _p(cdy), _p(cdx))
+        self.L.rto_field_get(self.h, _p(x), _p(y), _p(Z), _p(cdy), _p(cdx))
         return x, y, Z, cdy, cdx
 
     def n_gradient(self, x, y):
         x = _f64(np.atleast_1d(x)); y = _f64(np.atleast_1d(y))
         n = np.empty_like(x); gx = np.empty_like(x); gy = np.empty_like(x)
-        lib().rto_n_gradient_many(self.h, len(x), _p(x), _p(y), _p(n), _p(gx), _p(gy))
+        self.L.rto_n_gradient_many(self.h, len(x), _p(x), _p(y), _p(n), _p(gx), _p(gy))
         return n, gx, gy
 
     def __del__(self):
-        if getattr(self, "h", None) and _lib is not None:
-            _lib.rto_field_free(self.h)
+        if getattr(self, "h", None) and getattr(self, "L", None) is not None:
+            self.L.rto_field_free(self.h)
             self.h = None
 
 
@@ -103,7 +138,7 @@ def single_step(field, method, gamma, step, st, hist=None):
     st = _f64(st); out = np.empty((st.shape[0], 6))
     hist = _f64(hist) if hist is not None else None
     for q in range(st.shape[0]):
-        lib().rto_single_step(field.h, method, float(gamma), float(step), _p(st[q]),
+        field.L.rto_single_step(field.h, method, float(gamma), float(step), _p(st[q]),
                               _p(hist[q]) if hist is not None else None, _p(out[q]))
     return out
 
@@ -127,7 +162,7 @@ def trazar(field, method, gamma, step, max_size, box, x0, y0, theta0, record_str
         s_ray = np.zeros((rows, 6, R))
         n_ray = np.zeros((rows, R)) if want_n_ray else None
     d_ray = np.zeros((3, R)); final = np.zeros((9, R))
-    steps = lib().rto_trazar(field.h, C.byref(p), R, _p(x0), _p(y0), _p(th), _p(s_ray), _p(n_ray), _p(d_ray),
+    steps = field.L.rto_trazar(field.h, C.byref(p), R, _p(x0), _p(y0), _p(th), _p(s_ray), _p(n_ray), _p(d_ray),
                              _p(final))
     return dict(s_ray=s_ray, n_ray=n_ray, d_ray=d_ray, final=final, steps=int(steps))
 

@@ -62,8 +62,8 @@ SYMBOLS = {
     "rtmi_batch_create": (C.c_int, [C.c_void_p, C.POINTER(Params), C.c_int64, _dp, _dp, _dp, C.c_void_p,
                                     C.POINTER(C.c_void_p)]),
     "rtmi_batch_set_state": (C.c_int, [C.c_void_p, _dp, _dp, _ip]),
-    "rtmi_batch_get_state": (C.c_int, [C.c_void_p, _dp, _dp, _ip]),
-    "rtmi_batch_restore_state": (C.c_int, [C.c_void_p, _dp, _dp, _ip]),
+    "rtmi_batch_get_state": (C.c_int, [C.c_void_p, _dp, _dp, _ip, C.c_void_p]),
+    "rtmi_batch_restore_state": (C.c_int, [C.c_void_p, _dp, _dp, _ip, C.c_void_p]),
     "rtmi_batch_set_per_ray": (C.c_int, [C.c_void_p, _dp, _ip]),
     "rtmi_batch_reset": (C.c_int, [C.c_void_p]),
     "rtmi_step": (C.c_int, [C.c_void_p, C.c_int32]),

@@ -90,9 +90,46 @@ template <typename T> static rt::FieldDev<T> field_dev(const rtmi_field* f, int 
 }
 
 // ================================================================== field build kernels (fp64)
+// np.exp on a float64 array as the reference's numpy evaluates it (RT_bench.py:107 calls it on the meshgrid): on the
+// AVX512 machines numpy's wheels dispatch to Intel SVML's __svml_exp8_ha (numpy/_core/src/umath/svml, BSD-3), which is not
+// libm's exp in the last bit for 4.5 % of arguments.  The routine's main path restated (oracle/rt_oracle.c np_exp has the
+// same text; tools/check_np_exp.py: 0 mismatches against np.exp on 2.6e7 arguments): N = floor(x*log2(e)*16)/16 -- an fma
+// rounded toward zero onto a 2^-4 grid -- r = x - N*ln2 in two pieces, a degree-6 polynomial in three interleaved pairs,
+// 2^(j/16) from a 16-entry table with its correction term, scaled by 2^floor(N).  |x| >= 707.7 (SVML's scalar fall-back):
+// ocml's exp -- there 1 + e rounds to e or to 1 and the interface's n is sqrt(2) or 1 whatever the last bits of e.
+__device__ static double np_exp(double x) {
+    static const double T16[16] = {0x1.0000000000000p+0, 0x1.0b5586cf9890fp+0, 0x1.172b83c7d517bp+0, 0x1.2387a6e756238p+0,
+        0x1.306fe0a31b715p+0, 0x1.3dea64c123422p+0, 0x1.4bfdad5362a27p+0, 0x1.5ab07dd485429p+0, 0x1.6a09e667f3bcdp+0,
+        0x1.7a11473eb0187p+0, 0x1.8ace5422aa0dbp+0, 0x1.9c49182a3f090p+0, 0x1.ae89f995ad3adp+0, 0x1.c199bdd85529cp+0,
+        0x1.d5818dcfba487p+0, 0x1.ea4afa2a490dap+0};
+    static const double TL16[16] = {0x0.0p+0, 0x1.79aa65d837b6dp-54, -0x1.01b15eaa59348p-55, 0x1.68efde3a8a894p-54,
+        0x1.34d754db0abb6p-55, 0x1.59f48a72a4c6dp-55, 0x1.690cebb7aafb0p-56, 0x1.063e1e21c5409p-54, -0x1.3b3efbf5e2228p-54,
+        -0x1.b32dcb94da51dp-56, 0x1.db72fc1f0eab4p-55, 0x1.1affc2b91ce27p-56, 0x1.c1a7792cb3387p-55, 0x1.36eae30af0cb3p-56,
+        0x1.4a385a63d07a7p-56, -0x1.ff7128fd391f0p-55};
+    const double L2E = 0x1.71547652b82fep+0, LN2H = 0x1.62e42fefa39efp-1, LN2L = 0x1.abc9e3b39803fp-56;
+    const double A = 0x1.7411836940c04p-10, B = 0x1.1101cbbc265c0p-7, C = 0x1.55557242d68fep-5, D = 0x1.5555553939732p-3,
+                 E = 0x1.000000000d008p-1, F = 0x1.fffffffffff70p-1;
+    if (!(fabs(x) < 0x1.61da04cbafe44p+9)) return exp(x);
+    // floor of the EXACT product x*L2E on the 1/16 grid (== the toward-zero fma onto the shifter 1.5*2^48 + 1023)
+    const double p = x * L2E, e = __builtin_fma(x, L2E, -p);
+    double f16 = floor(p * 16.0);
+    if (f16 == p * 16.0 && e < 0) f16 -= 1.0;
+    const double N = f16 * 0.0625;
+    const int j = (int)((long long)f16 & 15);
+    double r = __builtin_fma(-N, LN2H, x);
+    r = __builtin_fma(-N, LN2L, r);
+    const double r2 = r * r;
+    const double P1 = __builtin_fma(A, r, B), P2 = __builtin_fma(C, r, D), P3 = __builtin_fma(E, r, F);
+    double q = __builtin_fma(r2, P1, P2);
+    q = __builtin_fma(r2, q, P3);
+    double t = __builtin_fma(q, r, TL16[j]);
+    t = __builtin_fma(T16[j], t, T16[j]);
+    return ldexp(t, (int)floor(N));
+}
+
 __device__ static double scenario_n(int sc, double a, double b) {
     if (sc == RTMI_INTERFACE)  // :107 (exp overflows to inf for y < -3.55, result sqrt(2): same as numpy)
-        return __dsqrt_rn(2.0) - (__dsqrt_rn(2.0) - 1.0) / (1.0 + exp(-b / 0.005));
+        return __dsqrt_rn(2.0) - (__dsqrt_rn(2.0) - 1.0) / (1.0 + np_exp(-b / 0.005));
     if (sc == RTMI_FISHEYE)    // :111
         return 1.0 / (1.0 + a * a + b * b);
     return 1.0 / (18.0 + 2.0 * b);  // :115-116
@@ -124,28 +161,62 @@ __global__ void k_gradient(const double* Z, double* out, int qx, int qy, int axi
     out[(size_t)i * qx + j] = r;
 }
 
-// Banded (2/2) LU solve of the not-a-knot collocation system, one line per thread.
-// lu: [m][5] factors from the host (L multipliers in 0..1, U in 2..4).
-__global__ void k_solve_lines(double* d, int m, int nlines, long es, long ls, const double* lu) {
+// FITPACK regrid with s = 0 (fpregr.f -> fpgrre.f, p = -1), the fit behind RectBivariateSpline (:456-457): the
+// interpolating spline's coefficients as the least-squares solution of (spy) c (spx)' = z by Givens rotations.  Each data
+// row of an axis' observation matrix is rotated into a band triangle (fpgivs / fprota); the rotations depend on the axis
+// alone, so the host works them out once per axis (fp_axis_build) and the device applies them to all right-hand sides at
+// once -- first along FITPACK's x (the rows of our [qy][qx] arrays: the reference passes (y, x, Z)), then along its y --
+// followed by the two back substitutions (fpback).  Same operations in the same order as the Fortran (scipy's wheels carry
+// no FMA; this library is compiled with -ffp-contract=off), so the coefficient arrays are scipy's get_coeffs() bit for bit
+// -- where rounds 1-2's banded LU of the same system landed 1.3e-15 away, enough to move interface x op3/4/5 by 2e-7.
+//
+// k_givens: lane = one right-hand side (stride ls), it = data rows of the axis (stride is).  Data row it touches triangle
+// rows nr[it] .. nr[it]+3; nr never decreases and a triangle row is final once nr has passed it, so the four live rows
+// are a register window: no read-modify-write of memory at all (out starts as the zero matrix of the Fortran).
+__global__ void k_givens(const double* in, double* out, int m, int nlines, long is, long ls, const int* nr, const double* cs) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nlines) return;
-    double* b = d + (size_t)t * ls;
-    double p1 = 0, p2 = 0;  // b[i-1], b[i-2]
-    for (int i = 0; i < m; i++) {
-        double v = b[(size_t)i * es];
-        if (i >= 1) v -= lu[i * 5 + 1] * p1;
-        if (i >= 2) v -= lu[i * 5 + 0] * p2;
-        b[(size_t)i * es] = v;
-        p2 = p1; p1 = v;
+    const double* src = in + (size_t)t * ls;
+    double* dst = out + (size_t)t * ls;
+    double w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    int base = 0;
+    for (int it = 0; it < m; it++) {
+        for (const int number = nr[it]; base < number; ++base) {
+            dst[(size_t)base * is] = w0;
+            w0 = w1; w1 = w2; w2 = w3; w3 = 0;
+        }
+        double right = src[(size_t)it * is];
+        const double* r = cs + (size_t)it * 8;
+#define RT_ROTA_(W, I)                                                                  \
+        if (!(r[2 * I] == 0.0 && r[2 * I + 1] == 0.0)) {   /* (0, 0): piv == 0, no rotation */ \
+            const double c = r[2 * I], sn = r[2 * I + 1], s1 = right, s2 = W;               \
+            W = c * s2 + sn * s1;        /* fprota: b = cos*b + sin*a */                    \
+            right = c * s1 - sn * s2;    /*         a = cos*a - sin*b */                    \
+        }
+        RT_ROTA_(w0, 0) RT_ROTA_(w1, 1) RT_ROTA_(w2, 2) RT_ROTA_(w3, 3)
+#undef RT_ROTA_
     }
-    double n1 = 0, n2 = 0;  // b[i+1], b[i+2]
-    for (int i = m - 1; i >= 0; i--) {
-        double v = b[(size_t)i * es];
-        if (i + 1 < m) v -= lu[i * 5 + 3] * n1;
-        if (i + 2 < m) v -= lu[i * 5 + 4] * n2;
-        v = v / lu[i * 5 + 2];
-        b[(size_t)i * es] = v;
-        n2 = n1; n1 = v;
+    if (base < m) dst[(size_t)base * is] = w0;
+    if (base + 1 < m) dst[(size_t)(base + 1) * is] = w1;
+    if (base + 2 < m) dst[(size_t)(base + 2) * is] = w2;
+    if (base + 3 < m) dst[(size_t)(base + 3) * is] = w3;
+}
+// fpback with bandwidth 4: a[n][4] is the band triangle; one line (stride ls) per lane, elements es apart
+__global__ void k_fpback(double* d, int n, int nlines, long es, long ls, const double* a) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nlines) return;
+    double* z = d + (size_t)t * ls;
+    double c1 = z[(size_t)(n - 1) * es] / a[(size_t)(n - 1) * 4], c2 = 0, c3 = 0;   // c[i+1], c[i+2], c[i+3]
+    z[(size_t)(n - 1) * es] = c1;
+    for (int i = n - 2, j = 2; i >= 0; i--, j++) {
+        const double* ai = a + (size_t)i * 4;
+        double store = z[(size_t)i * es];
+        store = store - c1 * ai[1];
+        if (j > 2) store = store - c2 * ai[2];
+        if (j > 3) store = store - c3 * ai[3];
+        const double v = store / ai[0];
+        z[(size_t)i * es] = v;
+        c3 = c2; c2 = c1; c1 = v;
     }
 }
 
@@ -185,31 +256,41 @@ void host_bspl3(const std::vector<double>& t, double x, int l, double h[4]) {
         }
     }
 }
-// LU factors ([m][5]) of the collocation matrix of the interpolating cubic on axis x (not-a-knot knots).
-std::vector<double> collocation_lu(const std::vector<double>& x) {
+// One axis of fpgrre: the Givens rotations that take the axis' observation matrix (one cubic B-spline row per data point,
+// interpolating not-a-knot knots t = [x0 x4, x[2..m-3], x[m-1] x4]) to its band triangle.  Out: nr[it] = first triangle row
+// data row it touches, cs[it][i] = (cos, sin) of its i-th rotation ((0, 0): none, the pivot was zero), a[m][4] the triangle.
+struct FpAxis { std::vector<int> nr; std::vector<double> cs, a; };
+FpAxis fp_axis_build(const std::vector<double>& x) {
     const int m = (int)x.size();
     std::vector<double> t(m + 4);
     for (int i = 0; i <= 3; i++) { t[i] = x[0]; t[m + 3 - i] = x[m - 1]; }
     for (int i = 4, j = 2; i < m; i++, j++) t[i] = x[j];
-    std::vector<double> A((size_t)m * 5, 0.0);
-    for (int i = 0; i < m; i++) {
-        int l = 3;
-        while (x[i] >= t[l + 1] && l != m - 1) l++;
+    FpAxis A;
+    A.nr.assign(m, 0); A.cs.assign((size_t)m * 8, 0.0); A.a.assign((size_t)m * 4, 0.0);
+    int l = 3, number = 0;
+    for (int it = 0; it < m; it++) {
+        while (!(x[it] < t[l + 1] || l == m - 1)) { l++; number++; }
         double h[4];
-        host_bspl3(t, x[i], l, h);
-        for (int q = 0; q < 4; q++) {
-            const int off = (l - 3 + q) - i + 2;
-            if (off >= 0 && off < 5) A[(size_t)i * 5 + off] = h[q];
+        host_bspl3(t, x[it], l, h);
+        A.nr[it] = number;
+        for (int i = 0, irot = number; i < 4; i++, irot++) {
+            const double piv = h[i];
+            if (piv == 0.0) continue;
+            double& ww = A.a[(size_t)irot * 4];
+            const double store = std::fabs(piv);                 // fpgivs
+            double dd;
+            if (store >= ww) { const double q = ww / piv; dd = store * std::sqrt(1.0 + q * q); }
+            else { const double q = piv / ww; dd = ww * std::sqrt(1.0 + q * q); }
+            const double c = ww / dd, sn = piv / dd;
+            ww = dd;
+            A.cs[(size_t)it * 8 + 2 * i] = c; A.cs[(size_t)it * 8 + 2 * i + 1] = sn;
+            for (int j = i + 1, i2 = 1; j < 4; j++, i2++) {      // fprota on the rest of the row
+                const double s1 = h[j], s2 = A.a[(size_t)irot * 4 + i2];
+                A.a[(size_t)irot * 4 + i2] = c * s2 + sn * s1;
+                h[j] = c * s1 - sn * s2;
+            }
         }
     }
-    for (int i = 0; i < m; i++)
-        for (int r = i + 1; r <= i + 2 && r < m; r++) {
-            const int off = i - r + 2;
-            const double mlt = A[(size_t)r * 5 + off] / A[(size_t)i * 5 + 2];
-            A[(size_t)r * 5 + off] = mlt;
-            for (int q = 1; q <= 2; q++)
-                if (off + q < 5) A[(size_t)r * 5 + off + q] -= mlt * A[(size_t)i * 5 + 2 + q];
-        }
     return A;
 }
 std::vector<double> linspace(double a, double b, int n) {
@@ -231,18 +312,31 @@ static int field_finish_impl(rtmi_field* f, double delta) {
     hipLaunchKernelGGL(k_gradient, grd, blk, 0, st, f->dZ, f->dCdy, qx, qy, 0, delta);  // GradX = d/dy (Q2)
     hipLaunchKernelGGL(k_gradient, grd, blk, 0, st, f->dZ, f->dCdx, qx, qy, 1, delta);  // GradY = d/dx
     HIP_TRY(hipGetLastError());
-    // separable not-a-knot interpolation (:456-457): along x for every row, then along y for every column
-    const std::vector<double> lux = collocation_lu(linspace(f->ax, f->bx, qx));
-    const std::vector<double> luy = collocation_lu(linspace(f->ay, f->by, qy));
-    double *dlux = nullptr, *dluy = nullptr;
+    // RectBivariateSpline(y, x, Grad) (:456-457) = FITPACK regrid, s = 0: Givens QR along y (FITPACK's x), then along x
+    const FpAxis AX = fp_axis_build(linspace(f->ax, f->bx, qx));
+    const FpAxis AY = fp_axis_build(linspace(f->ay, f->by, qy));
+    double* dlux = nullptr;     // rotations + triangles of both axes, then the work matrix g
+    double* dluy = nullptr;
     auto solve_and_pack = [&]() -> int {   // dlux/dluy are released below whatever this returns
-        HIP_TRY(hipMalloc(&dlux, lux.size() * sizeof(double)));
-        HIP_TRY(hipMalloc(&dluy, luy.size() * sizeof(double)));
-        HIP_TRY(hipMemcpyAsync(dlux, lux.data(), lux.size() * sizeof(double), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(dluy, luy.data(), luy.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        const size_t nax = (size_t)qx * 12, nay = (size_t)qy * 12;                 // cs [m][8] + a [m][4]
+        HIP_TRY(hipMalloc(&dlux, (nax + nay) * sizeof(double) + (size_t)(qx + qy) * sizeof(int)));
+        HIP_TRY(hipMalloc(&dluy, nz * sizeof(double)));
+        double *csx = dlux, *ax4 = dlux + (size_t)qx * 8, *csy = dlux + nax, *ay4 = csy + (size_t)qy * 8;
+        int *nrx = (int*)(dlux + nax + nay), *nry = nrx + qx;
+        HIP_TRY(hipMemcpyAsync(csx, AX.cs.data(), (size_t)qx * 8 * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ax4, AX.a.data(), (size_t)qx * 4 * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(csy, AY.cs.data(), (size_t)qy * 8 * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ay4, AY.a.data(), (size_t)qy * 4 * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(nrx, AX.nr.data(), (size_t)qx * sizeof(int), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(nry, AY.nr.data(), (size_t)qy * sizeof(int), hipMemcpyHostToDevice, st));
+        double* g = dluy;
         for (double* c : {f->dCdy, f->dCdx}) {
-            hipLaunchKernelGGL(k_solve_lines, dim3((qy + 63) / 64), dim3(64), 0, st, c, qx, qy, 1L, (long)qx, dlux);
-            hipLaunchKernelGGL(k_solve_lines, dim3((qx + 63) / 64), dim3(64), 0, st, c, qy, qx, (long)qx, 1L, dluy);
+            // rows of z into FITPACK-x's triangle (one lane per column), columns of g into FITPACK-y's (one lane per row)
+            hipLaunchKernelGGL(k_givens, dim3((qx + 63) / 64), dim3(64), 0, st, c, g, qy, qx, (long)qx, 1L, nry, csy);
+            hipLaunchKernelGGL(k_givens, dim3((qy + 63) / 64), dim3(64), 0, st, g, c, qx, qy, 1L, (long)qx, nrx, csx);
+            // (ry) c1 = h along x for every row, then c (rx)' = c1 along y for every column
+            hipLaunchKernelGGL(k_fpback, dim3((qy + 63) / 64), dim3(64), 0, st, c, qx, qy, 1L, (long)qx, ax4);
+            hipLaunchKernelGGL(k_fpback, dim3((qx + 63) / 64), dim3(64), 0, st, c, qy, qx, (long)qx, 1L, ay4);
         }
         HIP_TRY(hipGetLastError());
         const size_t esz = f->dtype == RTMI_F64 ? 8 : 4;
@@ -1358,7 +1452,7 @@ RTMI_EXPORT int rtmi_batch_reset(rtmi_batch* b) {
     return batch_init_state(b, b->dirty || !b->p.lazy_clear);
 }
 
-template <typename T> __global__ void k_set_state(BatchDev<T> a, const double* st, const double* hist, const int* istep, int restore) {
+template <typename T> __global__ void k_set_state(BatchDev<T> a, const double* st, const double* hist, const int* istep, const unsigned char* live) {
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.R) return;
     const long o = out_index(a, k);
@@ -1369,7 +1463,7 @@ template <typename T> __global__ void k_set_state(BatchDev<T> a, const double* s
     if (a.has_hist && hist)
         for (int q = 0; q < 4; q++) a.aux(3 + q)[k] = (T)hist[(size_t)q * a.R + o];
     if (a.rot) {
-        if (hist && restore) {                    // the carried unit tangent of a checkpoint (rtmi_batch_get_state)
+        if (hist && live) {                       // the carried unit tangent of a checkpoint (rtmi_batch_get_state)
             a.unit(0)[k] = (T)hist[o]; a.unit(1)[k] = (T)hist[(size_t)a.R + o];
         } else {                                  // a state given from outside starts from its angle's own sin/cos
             T sn, cs;
@@ -1378,10 +1472,11 @@ template <typename T> __global__ void k_set_state(BatchDev<T> a, const double* s
         }
     }
     if (istep) a.istep[k] = istep[o];
-    a.alive[k] = a.istep[k] + 1 < max_size_of(a, k);
+    // a checkpoint knows which rays had left the box (a position outside it does not say so: op7's bootstrap rows skip the test)
+    a.alive[k] = (live ? live[o] != 0 : true) && a.istep[k] + 1 < max_size_of(a, k);
 }
-// out: state9[9][R] then hist4[4][R] (fp64), oi: istep[R]; caller's ray order
-template <typename T> __global__ void k_get_state(BatchDev<T> a, double* out, int* oi) {
+// out: state9[9][R] then hist4[4][R] (fp64), oi: istep[R], ol: alive[R]; caller's ray order
+template <typename T> __global__ void k_get_state(BatchDev<T> a, double* out, int* oi, unsigned char* ol) {
     const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= a.R) return;
     const long o = out_index(a, k);
@@ -1394,28 +1489,31 @@ template <typename T> __global__ void k_get_state(BatchDev<T> a, double* out, in
     else if (a.rot) { h[0] = (double)a.unit(0)[k]; h[1] = (double)a.unit(1)[k]; }
     for (int q = 0; q < 4; q++) out[(9 + q) * R + o] = h[q];
     oi[o] = a.istep[k];
+    ol[o] = a.alive[k];
 }
 
-static int set_state_impl(rtmi_batch* b, const double* state9, const double* hist4, const int32_t* istep, int restore, const char* who) {
+static int set_state_impl(rtmi_batch* b, const double* state9, const double* hist4, const int32_t* istep, const uint8_t* live, const char* who) {
     ARG_TRY(b && state9, std::string(who) + ": null");
     DEVICE_TRY(b->field, who);
     const size_t R = (size_t)b->R;
     b->dirty = true;
     b->dirty_state = true;
     void* stg = nullptr;
-    int rc = batch_staging(b, 13 * R * sizeof(double) + R * sizeof(int), &stg);
+    int rc = batch_staging(b, 13 * R * sizeof(double) + R * sizeof(int) + R, &stg);
     if (rc) return rc;
     double* d = (double*)stg;
     int* di = (int*)(d + 13 * R);
+    unsigned char* dl = (unsigned char*)(di + R);
     hipError_t e = hipMemcpyAsync(d, state9, 9 * R * 8, hipMemcpyHostToDevice, b->stream);
     if (e == hipSuccess && hist4) e = hipMemcpyAsync(d + 9 * R, hist4, 4 * R * 8, hipMemcpyHostToDevice, b->stream);
     if (e == hipSuccess && istep) e = hipMemcpyAsync(di, istep, R * sizeof(int), hipMemcpyHostToDevice, b->stream);
+    if (e == hipSuccess && live) e = hipMemcpyAsync(dl, live, R, hipMemcpyHostToDevice, b->stream);
     if (e == hipSuccess) {
         const dim3 g((unsigned)((R + 255) / 256)), blk(256);
         if (b->p.dtype == RTMI_F64)
-            hipLaunchKernelGGL(k_set_state<double>, g, blk, 0, b->stream, batch_dev<double>(b), d, hist4 ? d + 9 * R : nullptr, istep ? di : nullptr, restore);
+            hipLaunchKernelGGL(k_set_state<double>, g, blk, 0, b->stream, batch_dev<double>(b), d, hist4 ? d + 9 * R : nullptr, istep ? di : nullptr, live ? dl : nullptr);
         else
-            hipLaunchKernelGGL(k_set_state<float>, g, blk, 0, b->stream, batch_dev<float>(b), d, hist4 ? d + 9 * R : nullptr, istep ? di : nullptr, restore);
+            hipLaunchKernelGGL(k_set_state<float>, g, blk, 0, b->stream, batch_dev<float>(b), d, hist4 ? d + 9 * R : nullptr, istep ? di : nullptr, live ? dl : nullptr);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
@@ -1423,29 +1521,31 @@ static int set_state_impl(rtmi_batch* b, const double* state9, const double* his
     return RTMI_OK;
 }
 RTMI_EXPORT int rtmi_batch_set_state(rtmi_batch* b, const double* state9, const double* hist4, const int32_t* istep) {
-    return set_state_impl(b, state9, hist4, istep, 0, "rtmi_batch_set_state");
+    return set_state_impl(b, state9, hist4, istep, nullptr, "rtmi_batch_set_state");
 }
-RTMI_EXPORT int rtmi_batch_restore_state(rtmi_batch* b, const double* state9, const double* aux4, const int32_t* istep) {
-    ARG_TRY(aux4 && istep, "rtmi_batch_restore_state: null (pass what rtmi_batch_get_state returned)");
-    return set_state_impl(b, state9, aux4, istep, 1, "rtmi_batch_restore_state");
+RTMI_EXPORT int rtmi_batch_restore_state(rtmi_batch* b, const double* state9, const double* aux4, const int32_t* istep, const uint8_t* alive) {
+    ARG_TRY(aux4 && istep && alive, "rtmi_batch_restore_state: null (pass what rtmi_batch_get_state returned)");
+    return set_state_impl(b, state9, aux4, istep, alive, "rtmi_batch_restore_state");
 }
 
-RTMI_EXPORT int rtmi_batch_get_state(rtmi_batch* b, double* state9, double* hist4, int32_t* istep) {
+RTMI_EXPORT int rtmi_batch_get_state(rtmi_batch* b, double* state9, double* hist4, int32_t* istep, uint8_t* alive) {
     ARG_TRY(b, "rtmi_batch_get_state: null");
     DEVICE_TRY(b->field, "rtmi_batch_get_state");
     const size_t R = (size_t)b->R;
     void* stg = nullptr;
-    int rc = batch_staging(b, 13 * R * sizeof(double) + R * sizeof(int), &stg);
+    int rc = batch_staging(b, 13 * R * sizeof(double) + R * sizeof(int) + R, &stg);
     if (rc) return rc;
     double* d = (double*)stg;
     int* di = (int*)(d + 13 * R);
+    unsigned char* dl = (unsigned char*)(di + R);
     const dim3 g((unsigned)((R + 255) / 256)), blk(256);
-    if (b->p.dtype == RTMI_F64) hipLaunchKernelGGL(k_get_state<double>, g, blk, 0, b->stream, batch_dev<double>(b), d, di);
-    else hipLaunchKernelGGL(k_get_state<float>, g, blk, 0, b->stream, batch_dev<float>(b), d, di);
+    if (b->p.dtype == RTMI_F64) hipLaunchKernelGGL(k_get_state<double>, g, blk, 0, b->stream, batch_dev<double>(b), d, di, dl);
+    else hipLaunchKernelGGL(k_get_state<float>, g, blk, 0, b->stream, batch_dev<float>(b), d, di, dl);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess && state9) e = hipMemcpyAsync(state9, d, 9 * R * 8, hipMemcpyDeviceToHost, b->stream);
     if (e == hipSuccess && hist4) e = hipMemcpyAsync(hist4, d + 9 * R, 4 * R * 8, hipMemcpyDeviceToHost, b->stream);
     if (e == hipSuccess && istep) e = hipMemcpyAsync(istep, di, R * sizeof(int), hipMemcpyDeviceToHost, b->stream);
+    if (e == hipSuccess && alive) e = hipMemcpyAsync(alive, dl, R, hipMemcpyDeviceToHost, b->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
     if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_batch_get_state: ") + hipGetErrorString(e));
     return RTMI_OK;

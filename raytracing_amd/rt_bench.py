@@ -319,17 +319,20 @@ class Batch:
         check(lib().rtmi_batch_set_state(self._h, dptr(st), dptr(h), i.ctypes.data_as(_lib._ip) if i is not None else None))
 
     def get_state(self):
-        """(state9 [9,R], aux4 [4,R], istep [R]) -- rtmi_batch_get_state; restore_state(*get_state()) resumes bit for bit."""
+        """(state9 [9,R], aux4 [4,R], istep [R], alive [R]) -- rtmi_batch_get_state; restore_state(*get_state()) on a batch
+        with the same parameters resumes bit for bit."""
         st = np.empty((9, self.R)); h = np.empty((4, self.R)); i = np.empty(self.R, dtype=np.int32)
-        check(lib().rtmi_batch_get_state(self._h, dptr(st), dptr(h), i.ctypes.data_as(_lib._ip)))
-        return st, h, i
+        al = np.empty(self.R, dtype=np.uint8)
+        check(lib().rtmi_batch_get_state(self._h, dptr(st), dptr(h), i.ctypes.data_as(_lib._ip), al.ctypes.data))
+        return st, h, i, al
 
-    def restore_state(self, state9, aux4, istep):
+    def restore_state(self, state9, aux4, istep, alive):
         st = np.ascontiguousarray(state9, dtype=np.float64)
         h = np.ascontiguousarray(aux4, dtype=np.float64)
         i = np.ascontiguousarray(istep, dtype=np.int32)
-        assert st.shape == (9, self.R) and h.shape == (4, self.R) and i.shape == (self.R,)
-        check(lib().rtmi_batch_restore_state(self._h, dptr(st), dptr(h), i.ctypes.data_as(_lib._ip)))
+        al = np.ascontiguousarray(alive, dtype=np.uint8)
+        assert st.shape == (9, self.R) and h.shape == (4, self.R) and i.shape == (self.R,) and al.shape == (self.R,)
+        check(lib().rtmi_batch_restore_state(self._h, dptr(st), dptr(h), i.ctypes.data_as(_lib._ip), al.ctypes.data))
 
     def set_per_ray(self, step, max_size):
         """Per-ray DELTA_S and max_size ([R] each, caller's ray order): rtmi_batch_set_per_ray."""

@@ -52,14 +52,12 @@ def test_field_build_parity(scen, rb, gpu_fields, oracle_fields):
     x, y, Z, cdy, cdx = F.arrays()
     ox, oy, oZ, ocdy, ocdx = OF.arrays()
     assert np.array_equal(x, ox) and np.array_equal(y, oy)
-    assert np.abs(Z - oZ).max() <= 4e-16 * np.abs(oZ).max()          # device exp vs libm exp (interface)
-    gscale = max(np.abs(ocdy).max(), np.abs(ocdx).max())              # one component may be identically ~0
-    for a, b in ((cdy, ocdy), (cdx, ocdx)):
-        assert np.abs(a - b).max() <= 1e-13 * gscale
+    # samples (interface: numpy's SVML exp restated on both sides), np.gradient stencil, FITPACK's Givens QR: the same bits
+    assert np.array_equal(Z, oZ) and np.array_equal(cdy, ocdy) and np.array_equal(cdx, ocdx)
     g = golden(f"field_{scen}")                                        # and straight against the reference
     qy, qx = Z.shape
     for name, arr in (("Z", Z), ("cdy", cdy), ("cdx", cdx)):
-        assert np.abs(arr[qy // 2:qy // 2 + 8, qx // 2:qx // 2 + 8] - g[name + "_mid"]).max() <= 1e-13 * (np.abs(Z).max() if name == "Z" else gscale)
+        assert np.array_equal(arr[qy // 2:qy // 2 + 8, qx // 2:qx // 2 + 8], g[name + "_mid"])
 
 
 @pytest.mark.parametrize("scen", ["interface", "fisheye", "vert_heterogeneous"])
@@ -147,10 +145,11 @@ def test_trajectory_vs_reference(name, scen, m, rb, gpu_fields):
     b.close()
     assert s.shape == (int(t["max_size"]), 6, len(th))
     strided, last = sub_rows(s, d, int(t["stride"]))
-    # every ray of every method, golden-section ones included (north star: 1e-9 on every ray).  The one exception is
-    # the curvature advancement on the interface sigmoid, where the reference's own formula amplifies last-bit
-    # differences of the FIELD to ~1e-7 (tests/test_gpu_exact.py::test_interface_curvature_conditioning).
-    tol = 2e-6 if scen == "interface" and m in (3, 4, 5) else REL
+    # every ray of every method, golden-section and curvature ones included (north star: 1e-9 on every ray): the field is
+    # the reference's bits (numpy's SVML exp and FITPACK's Givens QR restated).  One exception: interface x op4, whose angle
+    # comes from atan2 (numpy's is SVML's, not restated; ocml's is within an ulp of it) and whose curvature advancement
+    # amplifies such last-bit differences to <= 2e-7 (tests/test_gpu_exact.py::test_interface_curvature_conditioning).
+    tol = 2e-6 if scen == "interface" and m == 4 else REL
     assert np.array_equal(d[2], t["d_ray"][2])
     assert relerr(strided, t["strided"]) < tol and relerr(last, t["last"]) < tol
     assert relerr(d[:2], t["d_ray"][:2]) < tol
@@ -417,15 +416,15 @@ def test_checkpoint_resume_is_bit_identical(scen, m, dtype, rb, gpu_fields):
     a.run()
     b = rb.Batch(F, m, step, ms, lim, 1, th, x0, y0, record_stride=1, rec_rows=3100)
     b.step(777)
-    st, hist, istep = b.get_state()
+    st, hist, istep, live = b.get_state()
     if m in (2, 6) and dtype == "f64":
         assert np.allclose(hist[0] ** 2 + hist[1] ** 2, 1.0, atol=1e-12) and not hist[2:].any()
     c = rb.Batch(F, m, step, ms, lim, 1, th, x0, y0, record_stride=1, rec_rows=3100)
-    c.restore_state(st, hist, istep)
+    c.restore_state(st, hist, istep, live)
     c.run()
     assert np.array_equal(c.d_ray(), a.d_ray()) and np.array_equal(c.final(), a.final())
     assert np.array_equal(c.rows(778, 2300), a.rows(778, 2300))      # the rows written after the resume
-    at = istep == 777                                         # rtmi_read_final's momenta are the last recorded row's
+    at = live == 1                                            # rtmi_read_final's momenta are the last recorded row's
     assert at.any() and np.array_equal(b.final()[6:8][:, at], b.rows(777, 1)[0, 2:4][:, at])
     a.close(); b.close(); c.close()
 
@@ -939,16 +938,14 @@ def test_random_rays_through_grid_ends_vs_oracle(scen, m, rb, gpu_fields, oracle
     assert same.mean() > 0.99                        # a ray grazing the rim may leave one step apart
     err = np.abs(fin[:, same] - o["final"][:, same]) / np.maximum(np.abs(o["final"][:, same]), 1.0)
     print(f"{scen} op{m}: {same.sum()}/{R} same step count, max rel err {err.max():.2e}")
-    if m in (3, 5, 9, 10, 11) and scen != "interface":
-        # reference-order methods on a field whose coefficients are the oracle's bits: every ray bit-identical
+    if m in (3, 5, 9, 10, 11):
+        # reference-order methods on a field whose coefficients are the oracle's bits (all scenarios): every ray bit-identical
         assert same.all() and np.array_equal(fin, o["final"])
         return
-    # op7 differentiates positions (roundoff / step).  On the interface the device samples the sigmoid with its own
-    # exp() (within 1 ulp of libm's), so field coefficients differ from the oracle's in last bits; the curvature
-    # advancement (op3/4/5/10, RT_bench.py:361-363) turns such a difference into ~1e-8 of position per step on the flat
-    # flanks of the sigmoid (tests/test_gpu_exact.py::test_interface_curvature_conditioning; with the oracle's samples
-    # the same rays are bit-identical, test_trajectories_are_the_oracles_bits).
-    tol = 1e-7 if m == 7 else (2e-5 if m in (3, 4, 5, 10) and scen == "interface" else REL)
+    # op7 differentiates positions (roundoff / step).  interface x op4: ocml's atan2 against libm's (within an ulp of each
+    # other) under the curvature advancement's amplification (RT_bench.py:361-363) -- random rays spend longer on the flat
+    # flanks of the sigmoid than the reference's fan does (tests/test_gpu_exact.py::test_interface_curvature_conditioning)
+    tol = 1e-7 if m == 7 else (2e-5 if m == 4 and scen == "interface" else REL)
     assert err.max() < tol
 
 

@@ -20,11 +20,47 @@ def test_field_build_matches_reference(scen, consts, oracle_fields):
     assert np.array_equal(g["tx"][4:-4], x[2:-2]) and np.array_equal(g["ty"][4:-4], y[2:-2])
     qy, qx = Z.shape
     for name, arr in (("Z", Z), ("cdy", cdy), ("cdx", cdx)):
-        scale = np.abs(arr).max()
         for tag, blk in (("c00", arr[:8, :8]), ("c11", arr[-8:, -8:]),
                          ("mid", arr[qy // 2:qy // 2 + 8, qx // 2:qx // 2 + 8])):
-            # Z: numpy's exp differs from libm's by <= 1 ulp (interface only); coefficients: Givens-QR vs LU
-            assert np.abs(blk - g[f"{name}_{tag}"]).max() <= 4e-15 * max(scale, 1e-300), (name, tag)
+            # the reference's BITS: numpy's array exp (SVML, np_exp in rt_oracle.c) for the interface samples, np.gradient's
+            # stencil, FITPACK regrid's Givens QR (regrid_interp) for the coefficients
+            assert np.array_equal(blk, g[f"{name}_{tag}"]), (name, tag)
+
+
+@pytest.mark.parametrize("scen", ["interface", "fisheye", "vert_heterogeneous"])
+def test_lu_solver_is_close_but_not_the_references_bits(scen, consts):
+    """What rounds 1-2 solved the collocation system with (banded LU): the same spline to 4e-15, not the same bits --
+    which is what moved interface x op3/4/5 by 2e-7 (test_trajectory_matches_reference now passes at 0 there)."""
+    g = golden(f"field_{scen}")
+    O.set_field_solver(1)
+    try:
+        F = O.Field(scen, LIMITS[scen], consts["DELTA"])
+    finally:
+        O.set_field_solver(0)
+    _, _, Z, cdy, cdx = F.arrays()
+    qy, qx = Z.shape
+    differs = False
+    for name, arr in (("cdy", cdy), ("cdx", cdx)):
+        blk = arr[qy // 2:qy // 2 + 8, qx // 2:qx // 2 + 8]
+        assert np.abs(blk - g[f"{name}_mid"]).max() <= 4e-15 * max(np.abs(arr).max(), 1e-300)
+        differs |= not np.array_equal(blk, g[f"{name}_mid"])
+    assert differs
+
+
+def test_np_exp_restatement_equals_numpy_here():
+    """np_exp (rt_oracle.c) against this host's np.exp -- only where numpy dispatches float64 exp to SVML (AVX512_SKX
+    builds, as in the container the fixtures were made in); elsewhere np.exp is another function and there is nothing to
+    compare (the fixtures above pin np_exp either way)."""
+    from numpy._core._multiarray_umath import __cpu_features__ as feat
+    if not feat.get("AVX512_SKX"):
+        pytest.skip("numpy does not use SVML's exp on this CPU")
+    rng = np.random.default_rng(11)
+    x = np.concatenate([rng.uniform(-707, 707, 2_000_000), rng.uniform(-2, 2, 500_000), np.arange(-700, 700, 1 / 16.0),
+                        -np.linspace(-5, 7, 681) / 0.005])
+    with np.errstate(over="ignore"):
+        ref = np.exp(x)
+    ok = np.abs(x) < 707.7                      # beyond: SVML's scalar fall-back, restated as libm exp (immaterial for n)
+    assert np.array_equal(O.np_exp(x)[ok], ref[ok])
 
 
 @pytest.mark.parametrize("scen", ["interface", "fisheye", "vert_heterogeneous"])
@@ -32,10 +68,8 @@ def test_n_gradient_matches_reference(scen, oracle_fields):
     g = golden(f"field_{scen}")
     F = oracle_fields(scen)
     n, gx, gy = F.n_gradient(g["px"], g["py"])
-    _, _, Z, cdy, cdx = F.arrays()
-    assert np.abs(n - g["n"]).max() <= 4e-16 * np.abs(Z).max()
-    assert np.abs(gx - g["gx"]).max() <= 2e-15 * max(np.abs(cdx).max(), 1e-12)
-    assert np.abs(gy - g["gy"]).max() <= 2e-15 * max(np.abs(cdy).max(), 1e-12)
+    # 1 024 random points per grid: the reference's bits (same coefficients, fpbisp/fpbspl operation by operation)
+    assert np.array_equal(n, g["n"]) and np.array_equal(gx, g["gx"]) and np.array_equal(gy, g["gy"])
 
 
 @pytest.mark.parametrize("m", range(1, 12))
@@ -46,27 +80,55 @@ def test_single_step_matches_reference(m, oracle_fields):
     ref = g[f"out{m}"]
     # np.arctan2 (op1/4/7/8) and numpy's pow differ from libm by <= 1 ulp; everything else is bit-exact
     assert np.max(np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)) < 2e-15
+    if m not in (1, 4, 7, 8):
+        with O.variant("pow"):
+            Fp = O.Field("vert_heterogeneous", LIMITS["vert_heterogeneous"], float(golden("constants")["DELTA"]))
+            outp = O.single_step(Fp, m, 3 if m >= 10 else 1, float(g["step"]), g[f"st{m}"], g[f"hist{m}"])
+        assert np.array_equal(outp, ref)          # the reference-faithful build: its bits
 
 
+ATAN2_METHODS = (1, 4, 7, 8)     # np.arctan2 is SVML's __svml_atan28 on the fixture host: not libm's atan2 in the last bit
+
+
+@pytest.fixture(scope="module")
+def pow_fields(consts):
+    """Fields of the reference-faithful build (SQ() = libm pow(x, 2.0), like numpy's scalar x**2)."""
+    cache = {}
+
+    def get(scen):
+        key = "vert_heterogeneous" if scen == "anisotropy" else scen
+        if key not in cache:
+            with O.variant("pow"):
+                cache[key] = O.Field(key, LIMITS[key], consts["DELTA"])
+        return cache[key]
+    return get
+
+
+@pytest.mark.parametrize("build", ["default", "pow"])
 @pytest.mark.parametrize("name,scen,m", traj_fixtures())
-def test_trajectory_matches_reference(name, scen, m, oracle_fields):
+def test_trajectory_matches_reference(name, scen, m, build, oracle_fields, pow_fields):
+    """Every trajectory fixture captured from the reference, with both builds of the oracle.
+    Methods without atan2 (op2/3/5/6/9/10/11), all four scenarios, interface x curvature included:
+      * "pow" build (squares like numpy's scalar x**2): the reference's BITS -- every recorded row, d_ray, step counts;
+      * "default" build (x*x, what the device reproduces): <= 1e-15 (measured: 0 on 16 of 18 fixtures, 2.8e-17 on the two
+        anisotropy ones) -- the whole cost of that deviation.
+    op1/4/7/8 call np.arctan2 = SVML's atan2 (not restated): 1e-12 (op7 differentiates positions: 1e-10); on the interface
+    sigmoid curvature_t (:361-363) amplifies op4's last-bit angle differences to 2e-7 (tolerance 2e-6)."""
     t = golden("traj_" + name)
-    F = oracle_fields(scen)
+    F = (pow_fields if build == "pow" else oracle_fields)(scen)
     x0, y0, th = traj_inputs(t, scen)
-    r = O.trazar(F, m, float(t["gamma"]), float(t["step"]), int(t["max_size"]), t["box"], x0, y0, th, record_stride=1)
+    r = O.trazar(F, m, float(t["gamma"]), float(t["step"]), int(t["max_size"]), t["box"], x0, y0, th, record_stride=1,
+                 nthreads=4)
     assert r["s_ray"].shape == (int(t["max_size"]), 6, len(th))
     assert np.array_equal(r["d_ray"][2], t["d_ray"][2]), "last written row per ray"
     strided, last = sub_rows(r["s_ray"], r["d_ray"], int(t["stride"]))
-    tol = 1e-10 if m == 7 else 1e-12      # op7 differentiates positions: roundoff amplified by 1/step
-    if scen == "interface" and m in (3, 4, 5):
-        # curvature_t (:361-363) divides a cancelled difference of sines by a curvature just above 1.5e-8 on the flat
-        # flanks of the sigmoid: last-bit differences of the field (numpy's exp and FITPACK's QR in the reference, libm
-        # exp and LU here) become ~1e-8 of position per such step.  Measured 2e-8 .. 2e-7 on these 16 rays; this is the
-        # reference's own conditioning (tests/test_gpu_exact.py::test_interface_curvature_conditioning).
-        tol = 2e-6
-    assert np.abs(strided - t["strided"]).max() < tol
-    assert np.abs(last - t["last"]).max() < tol
-    assert np.abs(r["d_ray"][:2] - t["d_ray"][:2]).max() < max(tol, 1e-12)
+    if m not in ATAN2_METHODS and build == "pow":
+        assert np.array_equal(strided, t["strided"]) and np.array_equal(last, t["last"]) and np.array_equal(r["d_ray"], t["d_ray"])
+    else:
+        tol = 1e-15 if m not in ATAN2_METHODS else (1e-10 if m == 7 else 2e-6 if (scen == "interface" and m == 4) else 1e-12)
+        assert np.abs(strided - t["strided"]).max() < tol
+        assert np.abs(last - t["last"]).max() < tol
+        assert np.abs(r["d_ray"][:2] - t["d_ray"][:2]).max() < max(tol, 1e-12)
     # rows after termination stay zero (Q7)
     k = int(np.argmin(r["d_ray"][2])); i = int(r["d_ray"][2, k])
     assert i + 1 >= r["s_ray"].shape[0] or not r["s_ray"][i + 1:, :, k].any()
