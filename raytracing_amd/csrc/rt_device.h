@@ -679,6 +679,9 @@ template <typename T> struct Consts {
     T gamma, g2m1;           // trazar's gamma, gamma**2-1 (:230)
     T gamma_s, g2m1_s;       // module-global gamma of op10/op11 (Q12)
     T box[4];
+    // op10/op11 (rt_exact.h, golden_filtered phase T): suprema over all angles of the k-th derivatives (k = 1..4) of the unit
+    // momentum curve (cos t, gamma_s^2 sin t)/a(t) -- [0..3], the larger of the two components -- and of a(t) -- [4..7]
+    T gold_sup[8];
 };
 
 // anisotropy(theta, gamma) (:118-119) from sin/cos.  ISO (gamma == 1): sqrt(s^2 + c^2), which is 1 +- ulp

@@ -166,44 +166,50 @@ __device__ __forceinline__ double ang_cost(const Ray<double>& r, double step, do
     return ::atan2(r.n * r.uy + impulse(r.gy, fgy, step), r.n * r.ux + impulse(r.gx, fgx, step));
 }
 
-// ---------------------------------------------------------------- golden() (:175-199), filtered
+// ---------------------------------------------------------------- golden() (:175-199), filtered  (anisotropic cost)
 // The reference evaluates func(c) and func(d) afresh in each of its 37 iterations and keeps [a, d] when
 // func(c) < func(d), else [c, b]; the returned midpoint depends only on that sequence of outcomes.  Here every
-// comparison is first attempted with FAST cost values that carry a bound on their distance from what the reference's
-// arithmetic gives at the current points; when the two fast values are further apart than the bounds allow, the
-// outcome is decided.  Otherwise (per lane, rare: the costs must agree to ~1e-14 of their terms) both costs are
-// recomputed at the current points in the reference's arithmetic (`exact`) and compared like the reference does.
-// Either way the outcome is the reference's, so a, b, c, d -- advanced with the reference's own unfused bracket
-// arithmetic -- are its bits, and so is the returned midpoint.
+// comparison is first attempted WITHOUT the reference's arithmetic, from values that carry a bound on their distance from
+// what the reference's arithmetic gives at the current points; when the bound allows, the outcome is decided.  Otherwise
+// (per lane, rare) both costs are recomputed at the current points in the reference's arithmetic (`exact`) and compared like
+// the reference does.  Either way the outcome is the reference's, so a, b, c, d -- advanced with the reference's own
+// unfused bracket arithmetic -- are its bits, and so is the returned midpoint.
 //
-// One new point per iteration: of the two points of the new bracket one is the previous iteration's better point
-// ("survivor"; equal up to a few ulps of t to the point the reference would evaluate again), the other is the
-// survivor moved by h_j = pi*GR^(j+4) towards the kept side.
-//   Phase A (the first kGoldRotIters iterations -- with the default, all 37 of a search that starts from width pi):
-//     sin/cos of the new point by rotating the survivor's sin/cos through h_j (table rt_golden_rot.h), no sincos
-//     evaluation at all.  The tracked angle drifts from the actual point by rounding (bounded by DPHI below), which
-//     only loosens the bound; measured on the BASELINE configurations the exact re-evaluation stays rare even in the
-//     last iterations (cfg5: 8.4e9 ray-steps/s with 24 rotation iterations, 9.5e9 with all of them).
-//   Phase B (whatever remains): sincos_k at the actual point, tight bound, the survivor's value reused with its actual
-//     distance |t - t_eval| priced in.
-//
-// FastSC(s, c, f, g): cost f and g = |e_x| + |e_y| of the residual vector from sin/cos of the evaluation angle.
-// Bound of one stored value: (g + l)*(K1 + l) + f*K2, l = LIP*|t - t_eval|, plus K3 once, where
-//   K1  = 2 x (absolute error bound of one residual component: reference arithmetic + fast arithmetic),
-//   LIP = 2 x (bound on |d e/dt|), K2 = relative error of squaring and adding, K3 = second-order terms.
+//   Phase A (the first kGoldTaylorFrom iterations, bracket width pi .. ~5e-3): one new FAST cost value per iteration.  Of
+//     the two points of the new bracket one is the previous iteration's better point ("survivor"; equal up to a few ulps of t
+//     to the point the reference would evaluate again), the other is the survivor moved by h_j = pi*GR^(j+4) towards the
+//     kept side; its sin/cos come from rotating the survivor's through h_j (table rt_golden_rot.h), no sincos evaluation.
+//     FastA(s, c, f, g): cost f and g = |e_x| + |e_y| of the residual vector from sin/cos of the evaluation angle.
+//     Bound of one stored value: g*K1 + f*K2 (+ K3 once), K1 = 2 x (absolute error bound of one residual component:
+//     reference arithmetic + fast arithmetic + LIP x the tracked angle's drift), K2 = relative error of squaring and adding.
+//   Phase T (the remaining ~23 iterations): no cost value at all.  The cost F = |e|^2 is expanded to third order about a
+//     centre t0 next to its minimiser (two evaluations of the residual e and of its first three derivatives in closed form:
+//     one at theta, a Newton step, one at the centre); with xi = t - t0
+//         F(c) - F(d) = (xi_c - xi_d) V + R4(c) - R4(d),   V = F1 + F2 (xi_c + xi_d)/2 + F3 (xi_c^2 + xi_c xi_d + xi_d^2)/6,
+//     and since xi_c < xi_d the reference's outcome F(c) < F(d) is V > 0 -- for certain when |V| (d - c) exceeds the remainder
+//     bound M4 rho^4/12 (rho = max |xi|, M4 >= |d4F/dt4| from suprema of the momentum curve's derivatives, Consts::gold_sup)
+//     plus the rounding error the reference's arithmetic can have made in its two values (the same g*K1 + f*K2 + K3 with
+//     g <= g0 + 2 E1 rho) plus the error of V's coefficients.  ~34 instructions per iteration against ~90 in phase A.  The
+//     minimiser stays inside every bracket, so rho shrinks with the bracket and the comparison is decided by the sign of V in
+//     all but ~4e-3 of the steps (the reference's own rounding noise in its last three iterations).
 struct GoldBounds { double K1, LIP, K2, K3; };
+// third-order expansion of the cost about one angle: |e_x| + |e_y| there, and the cost's first three derivatives
+struct GoldExpansion { double g0, F1, F2, F3; };
 
-#ifndef RTMI_GOLD_ROT_ITERS
-#define RTMI_GOLD_ROT_ITERS 48   // <= RT_GOLD_ROT_ENTRIES; from a bracket of width pi the search ends after 37 iterations
+#ifndef RTMI_GOLD_TAYLOR_FROM
+#define RTMI_GOLD_TAYLOR_FROM 14   // iterations of phase A; bracket width pi*GR^14 = 3.7e-3 when phase T takes over
 #endif
-constexpr int kGoldRotIters = RTMI_GOLD_ROT_ITERS;
+constexpr int kGoldTaylorFrom = RTMI_GOLD_TAYLOR_FROM;
+static_assert(kGoldTaylorFrom <= RT_GOLD_ROT_ENTRIES, "phase A rotates through rt_golden_rot.h");
 __device__ const double kGoldRot[2 * RT_GOLD_ROT_ENTRIES] = {RT_GOLD_ROT_VALUES};
 constexpr double kU = 1.1102230246251565e-16;   // 2^-53
 
-// fast_a: the phase-A evaluation (may be cheaper and looser than fast_sc by at most EA in one residual component)
-template <typename FastA, typename FastSC, typename Exact>
-__device__ __forceinline__ double golden_filtered(FastA fast_a, double EA, FastSC fast_sc, Exact exact, const GoldBounds& B,
-                                                  double th, double s0, double c0) {
+// fast_a: the phase-A evaluation (may be looser than the bound's K1 by at most EA in one residual component).
+// expand(s, c): GoldExpansion at the angle whose (sin, cos) are (s, c).  E[1..4]: bounds on |d^k e / dt^k| (one component);
+// e_abs: bound on the absolute error of one residual component as `expand` computes it.
+template <typename FastA, typename Expand, typename Exact>
+__device__ __forceinline__ double golden_filtered(FastA fast_a, double EA, Expand expand, Exact exact, const GoldBounds& B,
+                                                  const double E[5], double e_abs, double th, double s0, double c0) {
     const double GR = kGoldRatio, tol = M<double>::gold_tol;
     double a = th - kHalfPi, b = th + kHalfPi;
     double c = b - (b - a) * GR, d = a + (b - a) * GR;
@@ -211,7 +217,7 @@ __device__ __forceinline__ double golden_filtered(FastA fast_a, double EA, FastS
     {   // ---- phase A.  X: survivor, Y: the newer point; x_is_c: X is the lower point c
         // tracked angle vs actual point: rotation arithmetic (<= 6u each, table constants included) and the bracket
         // arithmetic's roundings (<= ulp(t) per update, t up to |theta| + pi/2)
-        const double dphi = kU * (8.0 + kGoldRotIters * (6.0 + 2.0 * (__builtin_fabs(th) + 2.0)));
+        const double dphi = kU * (8.0 + kGoldTaylorFrom * (6.0 + 2.0 * (__builtin_fabs(th) + 2.0)));
         const double lA = B.LIP * dphi;
         const double K1A = B.K1 + lA + 2.0 * EA, K3A = 4.0 * K1A * K1A;
         const double sk = RT_GOLD_KAPPA_SIN, ck = RT_GOLD_KAPPA_COS;
@@ -221,7 +227,7 @@ __device__ __forceinline__ double golden_filtered(FastA fast_a, double EA, FastS
         fast_a(sX, cX, fX, gX);
         fast_a(sY, cY, fY, gY);
         bool x_is_c = true;
-        for (; it < kGoldRotIters && __builtin_fabs(c - d) > tol; ++it) {
+        for (; it < kGoldTaylorFrom && __builtin_fabs(c - d) > tol; ++it) {
             const double bound = fma_(gX + gY, K1A, fma_(fX + fY, B.K2, K3A));
             bool xless = fX < fY;
             bool lt = xless == x_is_c;
@@ -241,32 +247,45 @@ __device__ __forceinline__ double golden_filtered(FastA fast_a, double EA, FastS
             x_is_c = !lt;
         }
     }
-    // ---- phase B (only if the search is still running)
-    double fc = 0, gc = 0, fd = 0, gd = 0, tc = c, td = d;
-    if (it < kGoldMaxIter && __builtin_fabs(c - d) > tol) {
-        double s, cs;
-        sincos_k(c, &s, &cs); fast_sc(s, cs, fc, gc);
-        sincos_k(d, &s, &cs); fast_sc(s, cs, fd, gd);
-    }
+    if (!(__builtin_fabs(c - d) > tol)) return (b + a) / 2.0;
+    // ---- phase T.  Centre: theta moved by one Newton step (with the cubic term) of the expansion at theta.
+    const GoldExpansion X0 = expand(s0, c0);
+    const double x0 = -X0.F1 / X0.F2;
+    const double xs = fma_(-0.5 * X0.F3 * x0, x0 / X0.F2, x0);
+    double s1, c1;
+    sincos_add_small(s0, c0, xs, &s1, &c1);                     // |xs| < 2^-5 is checked below
+    const GoldExpansion T = expand(s1, c1);
+    const double t0 = th + xs;
+    // the centre's angle is known to: the rounding of th + xs and of t - t0, the series of the rotation (angle error < 4u),
+    // and theta against its carried (sin, cos) -- a uniform shift eps0 of every xi, i.e. an error F2*eps0 of V
+    const double eps0 = kU * (16.0 + 4.0 * __builtin_fabs(th));
+    const double F2h = 0.5 * T.F2, F36 = T.F3 * (1.0 / 6.0);
+    // |d4F/dt4| <= 4 (E0 E4 + 4 E1 E3 + 3 E2^2), E0 = sup |e| <= g0 + E1 rho, for rho <= kRhoMax
+    constexpr double kRhoMax = 0.0078125;
+    const double M4c = (1.001 / 12.0) * 4.0 * fma_(T.g0 + E[1] * kRhoMax, E[4], fma_(4.0 * E[1], E[3], 3.0 * E[2] * E[2]));
+    // V's coefficients: F1 = 2 e.e1 inherits e's absolute error e_abs (e is a cancelled difference, its derivative is not);
+    // F2, F3 and the evaluation of V a relative 64u of their terms (|sigma| <= 2 rho, |pi2| <= 3 rho^2)
+    const double errV0 = fma_(8.0 * e_abs, E[1], fma_(__builtin_fabs(T.F2), eps0, 32.0 * kU * __builtin_fabs(T.F1)));
+    const double cF2 = 64.0 * kU * __builtin_fabs(T.F2), cF3 = 32.0 * kU * __builtin_fabs(T.F3);
+    const double E1x2 = 2.0 * E[1], K3x2 = 2.0 * B.K3;
+    // outside what the bounds were derived for (never on the path): every comparison goes to the reference's arithmetic
+    const bool ok = X0.F2 > 0.0 && T.F2 > 0.0 && __builtin_fabs(xs) < 0.03125 && __builtin_fabs(T.F3) < 1e300 && M4c < 1e300;
+    double invd = 1.002 / (d - c);                              // 1/(d - c): slack for the recurrence against the rounded widths
     for (; it < kGoldMaxIter && __builtin_fabs(c - d) > tol; ++it) {
-        const double lc = B.LIP * __builtin_fabs(c - tc), ld = B.LIP * __builtin_fabs(d - td);
-        const double bound = fma_(gc + lc, B.K1 + lc, fc * B.K2) + fma_(gd + ld, B.K1 + ld, fd * B.K2) + B.K3;
-        bool lt = fc < fd;
-        if (!(__builtin_fabs(fc - fd) > bound)) lt = exact(c) < exact(d);
-        double s, cs;
-        if (lt) {   // keep [a, d]: the new d is the old c (up to rounding), the new c is fresh
-            b = d;
-            c = b - (b - a) * GR;
-            d = a + (b - a) * GR;
-            fd = fc; gd = gc; td = tc;
-            sincos_k(c, &s, &cs); fast_sc(s, cs, fc, gc); tc = c;
-        } else {    // keep [c, b]
-            a = c;
-            c = b - (b - a) * GR;
-            d = a + (b - a) * GR;
-            fc = fd; gc = gd; tc = td;
-            sincos_k(d, &s, &cs); fast_sc(s, cs, fd, gd); td = d;
-        }
+        const double xc = c - t0, xd = d - t0;
+        const double sg = xc + xd, p2 = fma_(sg, sg, -(xc * xd));
+        const double V = fma_(F36, p2, fma_(F2h, sg, T.F1));
+        const double rho = __builtin_fmax(__builtin_fabs(xc), __builtin_fabs(xd));
+        const double Gb = fma_(E1x2, rho, T.g0);
+        const double noise = fma_(2.0 * Gb, fma_(B.K2, Gb, B.K1), K3x2);
+        const double r2 = rho * rho;
+        const double thr = fma_(fma_(M4c * r2, r2, noise), invd, fma_(rho, fma_(rho, cF3, cF2), errV0));
+        bool lt = V > 0.0;
+        if (!(ok && __builtin_fabs(V) > thr && rho < kRhoMax)) lt = exact(c) < exact(d);   // also when anything is NaN
+        if (lt) b = d; else a = c;
+        c = b - (b - a) * GR;
+        d = a + (b - a) * GR;
+        invd *= 1.618033988749895;
     }
     return (b + a) / 2.0;
 }
@@ -285,23 +304,66 @@ __device__ __attribute__((noinline)) double exact_cost_aniso(double t, double fn
 }
 
 // isotropic cost (:595, :697): (n' cos t - n u_x - I_x)^2 + (n' sin t - n u_y - I_y)^2
+//
+// golden() for this cost WITHOUT evaluating it.  With P = (n u_x + I_x, n u_y + I_y) the cost is
+//     F(t) = |n'(cos t, sin t) - P|^2 = (n' - |P|)^2 + 4 n'|P| sin^2((t - psi)/2),      psi = arg P,
+// symmetric about psi and increasing in |t - psi| < pi.  The reference keeps [a, d] when F(c) < F(d), c < d, i.e. when c is
+// the closer of the two to psi, i.e. when psi < (c + d)/2: each of its ~37 comparisons is the sign of
+//     x = (c + d)/2 - psi        --  two subtractions against one angle, psi - theta = atan2(P x u, P . u), per step.
+// What the reference actually compares are the ROUNDED values of F; the sign of x is its outcome for certain only when the
+// true difference |F(c) - F(d)| = 4 n'|P| |sin x| sin h (h = (d - c)/2) exceeds the rounding error its arithmetic can
+// have made in the two values, (g_c + g_d) K1 + (F_c + F_d) K2 + 2 K3 (GoldBounds, as in golden_filtered).  With
+// g <= sqrt(2 F), sqrt F <= |Delta| + sqrt(n'|P|) |t - psi|, Delta = n' - |P|, |t - psi| <= |x| + h <= 2.4 this is implied by
+//     |x| > Ca + Cb / h,    Ca = (2 sqrt2 K1 / sqrt(n'|P|) + 4.8 K2) / 1.776 + (the error of x itself, <= 16 u),
+//                           Cb = (2 sqrt2 K1 |Delta| + 2 K2 Delta^2 + 2 K3) / (1.776 n'|P|)
+// (1.776 = 4 x min sin x / x on [0, 2] x min sin h / h on [0, 0.371]).  Delta is O(step^2): Cb / h stays below 1e-12 even in
+// the last iteration (h = 7e-9) and the comparison is decided by the sign of x in all but ~1e-4 of the steps; otherwise --
+// per lane, for that one comparison -- both costs are evaluated in the reference's arithmetic (exact_cost_iso) and compared
+// like the reference does.  Either way the outcome is the reference's, and a, b, c, d, advanced with its own unfused bracket
+// arithmetic, are its bits.  (Round 2 evaluated a fast cost with an error bound at every new point: ~90 instructions per
+// iteration, ~20 now.)
 __device__ __forceinline__ double ang_golden_iso(const Ray<double>& r, double step, double fn, double fgx, double fgy) {
     const double px = r.n * r.ux, py = r.n * r.uy;
     const double ix = impulse(r.gx, fgx, step), iy = impulse(r.gy, fgy, step);
-    auto exact = [=](double t) { return exact_cost_iso(t, fn, px, py, ix, iy); };
-    auto fast_sc = [=](double s, double c, double& f, double& g) {
-        const double e0 = fma_(fn, c, -px) - ix, e1 = fma_(fn, s, -py) - iy;
-        f = fma_(e1, e1, e0 * e0);
-        g = __builtin_fabs(e0) + __builtin_fabs(e1);
-    };
-    // one residual component: |n' cos t| carries the sincos error (libm <= 0.55 ulp, sincos_k taken as <= 2 ulp) and a
-    // product rounding, the two subtractions round at most u * (|n'| + |p| + |I|) each -- in both arithmetics
-    const double afn = __builtin_fabs(fn);
+    const double Px = px + ix, Py = py + iy;
+    // P turned by -theta with the carried (cos theta, sin theta): its angle is phi = psi - theta, |phi| << 1
+    const double Pc = fma_(Py, r.uy, Px * r.ux), Ps = fma_(Py, r.ux, -(Px * r.uy));
+    const double phi = ::atan2(Ps, Pc);
+    const double P2 = fma_(Ps, Ps, Pc * Pc);
+    double rP = __builtin_amdgcn_rsq(P2);
+    rP = fma_(rP * 0.5, fma_(-P2 * rP, rP, 1.0), rP);
+    rP = fma_(rP * 0.5, fma_(-P2 * rP, rP, 1.0), rP);          // 1/|P| to ~2 ulp
+    const double aP = P2 * rP, afn = __builtin_fabs(fn);
+    // rounding error of one residual component in the reference's arithmetic (and the margin round 2's fast form needed): 12 u mag
     const double mag = afn + __builtin_fmax(__builtin_fabs(px), __builtin_fabs(py)) + __builtin_fmax(__builtin_fabs(ix), __builtin_fabs(iy));
     const double e1 = 12.0 * kU * mag;
-    GoldBounds B;
-    B.K1 = 2.0 * e1; B.LIP = 2.0 * afn; B.K2 = 8.0 * kU; B.K3 = 16.0 * e1 * e1;
-    return golden_filtered(fast_sc, 0.0, fast_sc, exact, B, r.th, r.uy, r.ux);
+    const double K1 = 2.0 * e1, K2 = 8.0 * kU, K3 = 16.0 * e1 * e1;
+    const double A = afn * aP;                                   // n'|P|
+    double rsA = __builtin_amdgcn_rsq(A);
+    rsA = fma_(rsA * 0.5, fma_(-A * rsA, rsA, 1.0), rsA) * 1.000001;   // >= 1/sqrt(A)
+    const double Delta = __builtin_fabs(afn - aP) + 16.0 * kU * (afn + aP);
+    const double beta = fma_(2.8284271247461903 * K1, Delta, fma_(2.0 * K2 * Delta, Delta, 2.0 * K3));
+    // slack 1.001: the tabulated-by-recurrence 1/h against the bracket's actual (rounded) width, the Newton reciprocals
+    double Ca = (1.001 / 1.776) * fma_(2.8284271247461903 * K1, rsA, 4.8 * K2) + 16.0 * kU;
+    const double Cb = (1.001 / 1.776) * beta * rsA * rsA;
+    // outside the geometry the bound was derived for (never on the path: psi within 1 rad of theta, |P| ~ n' > 0): every
+    // comparison goes to the reference's arithmetic
+    if (!(fn > 0.0 && aP > 0.25 * afn && __builtin_fabs(phi) < 1.0 && Cb < 1.0)) Ca = __builtin_inf();
+    const double GR = kGoldRatio, tol = M<double>::gold_tol, th = r.th, phi2 = 2.0 * phi;
+    double a = th - kHalfPi, b = th + kHalfPi;
+    double c = b - (b - a) * GR, d = a + (b - a) * GR;
+    double invh = 2.6967646315695153;                            // 1 / h_0, h_0 = (2 GR - 1) pi / 2; h_j = h_0 GR^j
+    for (int it = 0; it < kGoldMaxIter && __builtin_fabs(c - d) > tol; ++it) {
+        const double q2 = ((c - th) + (d - th)) - phi2;          // 2 x; both differences are exact or rounded at their own size
+        bool lt = q2 > 0.0;
+        if (!(__builtin_fabs(q2) > 2.0 * fma_(Cb, invh, Ca)))    // also taken when anything is NaN
+            lt = exact_cost_iso(c, fn, px, py, ix, iy) < exact_cost_iso(d, fn, px, py, ix, iy);
+        if (lt) b = d; else a = c;
+        c = b - (b - a) * GR;
+        d = a + (b - a) * GR;
+        invh *= 1.618033988749895;
+    }
+    return (b + a) / 2.0;
 }
 
 // anisotropic cost (:725-728 / :758-761); the step functions read the module-global gamma (quirk Q12)
@@ -328,7 +390,6 @@ __device__ __forceinline__ double ang_golden_aniso(const Ray<double>& r, const C
         f = fma_(e1, e1, e0 * e0);
         g = __builtin_fabs(e0) + __builtin_fabs(e1);
     };
-    auto fast_sc = [=](double s, double c, double& f, double& g) { fast_n(s, c, f, g, 2); };   // < 2 ulp in 1/a
     // phase A: one Newton step on the >= 20-bit hardware estimate leaves 1/a within 2^-38 (3.7e-12) relative
     auto fast_a = [=](double s, double c, double& f, double& g) { fast_n(s, c, f, g, 1); };
     // Error of one residual component (u = 2^-53, relative errors unless stated).  Reference arithmetic: s, c <= 1.1u
@@ -352,7 +413,45 @@ __device__ __forceinline__ double ang_golden_aniso(const Ray<double>& r, const C
     B.LIP = 3.0 * (afn * g2max * (1.0 / amin + g2a / (2.0 * amin * amin * amin)) + step * g2a / amin * gsum);
     B.K2 = 8.0 * kU; B.K3 = 16.0 * e1 * e1;
     const double EA = 4.0e-12 * (afn * g2max / amin + step * gmax * gsum);     // |m| * 3.7e-12, and the impulse's a(t)
-    return golden_filtered(fast_a, EA, fast_sc, exact, B, r.th, r.uy, r.ux);
+    // Phase T: e(t) = M(t) - m_i - (coef g + a(t) g1) step/2 (g1: the gradient at the new point) and its derivatives in
+    // closed form.  With A = 1/a, G = gamma^2 - 1, and D for d/dt:
+    //   M    = n1 (c A, gamma^2 s A)                        D M = n1 gamma^2 A^3 (-s, c)
+    //   D2 M = -n1 gamma^2 A^5 (c (1 - 2G s^2), s (1 + 3G - 2G s^2))
+    //   D3 M = n1 gamma^2 A^7 ( s [(1 - 2G s^2 + 4G c^2) a^2 + 5G c^2 (1 - 2G s^2)], -c [(1 + 3G - 6G s^2) a^2 - 5G s^2 (1 + 3G - 2G s^2)] )
+    //   D a = G s c A     D2 a = G A [(c^2 - s^2) - G s^2 c^2 A^2]     D3 a = G s c A [-4 - 3G (c^2 - s^2) A^2 + 3 G^2 s^2 c^2 A^4]
+    // (tools/check_aniso_derivatives.py compares them with mpmath's numerical derivatives.)
+    auto expand = [=](double s, double c) {
+        const double ss = s * s, cc = c * c, sc = s * c;
+        const double a2 = fma_(gam2, ss, cc);
+        double A = __builtin_amdgcn_rsq(a2);
+        A = fma_(A * 0.5, fma_(-a2 * A, A, 1.0), A);
+        A = fma_(A * 0.5, fma_(-a2 * A, A, 1.0), A);
+        const double a = a2 * A, A2 = A * A, A3 = A2 * A, A5 = A3 * A2, A7 = A5 * A2;
+        const double Gss = g2 * ss, Gcc = g2 * cc, kk = fn * gam2, dif = cc - ss;
+        const double u1 = fma_(-2.0, Gss, 1.0), u2 = fma_(3.0, g2, u1);            // 1 - 2G s^2, 1 + 3G - 2G s^2
+        const double hx = fgx * hstep, hy = fgy * hstep;                            // g1 step/2
+        const double a1 = g2 * sc * A, a2d = g2 * A * fma_(-Gss * cc, A2, dif);
+        const double a3 = a1 * fma_(3.0 * Gss * Gcc * A2, A2, fma_(-3.0 * g2 * dif, A2, -4.0));
+        const double e0x = fn * c * A - mix - fma_(a, fgx, cgx) * hstep, e0y = kk * s * A - miy - fma_(a, fgy, cgy) * hstep;
+        const double k3 = kk * A3, k5 = kk * A5, k7 = kk * A7;
+        const double e1x = fma_(-a1, hx, -(k3 * s)), e1y = fma_(-a1, hy, k3 * c);
+        const double e2x = fma_(-a2d, hx, -(k5 * c * u1)), e2y = fma_(-a2d, hy, -(k5 * s * u2));
+        const double m3x = k7 * s * fma_(fma_(4.0, Gcc, u1), a2, 5.0 * Gcc * u1);
+        const double m3y = -(k7 * c) * fma_(fma_(-4.0, Gss, u2), a2, -5.0 * Gss * u2);
+        const double e3x = fma_(-a3, hx, m3x), e3y = fma_(-a3, hy, m3y);
+        GoldExpansion X;
+        X.g0 = __builtin_fabs(e0x) + __builtin_fabs(e0y);
+        X.F1 = 2.0 * fma_(e0y, e1y, e0x * e1x);
+        X.F2 = 2.0 * (fma_(e1y, e1y, e1x * e1x) + fma_(e0y, e2y, e0x * e2x));
+        X.F3 = 2.0 * fma_(3.0, fma_(e1y, e2y, e1x * e2x), fma_(e0y, e3y, e0x * e3x));
+        return X;
+    };
+    // |D^k e| <= n1 D_k + (step/2) max|g1| A_k with D_k, A_k the suprema over all angles of the k-th derivatives of the unit
+    // momentum curve's components and of a(t) (host: gold_sup_derivatives, 10 % on top of an 8192-point sampling)
+    const double gmx = __builtin_fmax(__builtin_fabs(fgx), __builtin_fabs(fgy)) * hstep;
+    const double E[5] = {0.0, fma_(afn, k.gold_sup[0], gmx * k.gold_sup[4]), fma_(afn, k.gold_sup[1], gmx * k.gold_sup[5]),
+                         fma_(afn, k.gold_sup[2], gmx * k.gold_sup[6]), fma_(afn, k.gold_sup[3], gmx * k.gold_sup[7])};
+    return golden_filtered(fast_a, EA, expand, exact, B, E, e1 + EA, r.th, r.uy, r.ux);
 }
 
 // ---------------------------------------------------------------- opN around the field lookup

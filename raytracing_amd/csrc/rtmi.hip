@@ -37,6 +37,43 @@ static int fail(int code, const std::string& msg) {
         if (!(cond)) return fail(RTMI_ERR_ARG, (msg));  \
     } while (0)
 
+// Suprema over t of |d^k/dt^k| (k = 1..4) of the unit momentum curve's components c/a, gamma^2 s/a and of a(t) =
+// sqrt(gamma^2 s^2 + c^2), by truncated Taylor arithmetic (order 4) at 8192 equally spaced angles, with 10 % on top for what
+// lies between the samples (neighbouring samples differ by a fraction of that).  Bounds for the remainder of the
+// golden-section search's third-order expansion (rt_exact.h, phase T); gamma is a property of the batch, so once per batch.
+static void gold_sup_derivatives(double gamma, double out[8]) {
+    constexpr int K = 4, N = 8192;
+    typedef double Jet[K + 1];
+    auto mul = [](const Jet a, const Jet b, Jet o) {
+        for (int i = 0; i <= K; i++) { double v = 0; for (int j = 0; j <= i; j++) v += a[j] * b[i - j]; o[i] = v; }
+    };
+    const double fact[K + 1] = {1, 1, 2, 6, 24};
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    for (int q = 0; q < N; q++) {
+        const double t = 2.0 * M_PI * q / N;
+        Jet s, c, ss, cc, a2, A, a, mx, my, t1, t2;
+        for (int k = 0; k <= K; k++) { s[k] = std::sin(t + k * M_PI / 2) / fact[k]; c[k] = std::cos(t + k * M_PI / 2) / fact[k]; }
+        mul(s, s, ss); mul(c, c, cc);
+        for (int k = 0; k <= K; k++) a2[k] = gamma * gamma * ss[k] + cc[k];
+        for (int k = 0; k <= K; k++) A[k] = 0;
+        A[0] = 1.0 / std::sqrt(a2[0]);
+        for (int it = 0; it < 5; it++) {          // A <- A (1.5 - 0.5 a2 A^2): one more exact series coefficient per pass
+            mul(A, A, t1); mul(a2, t1, t2);
+            for (int k = 0; k <= K; k++) t2[k] = -0.5 * t2[k];
+            t2[0] += 1.5;
+            mul(A, t2, t1);
+            for (int k = 0; k <= K; k++) A[k] = t1[k];
+        }
+        mul(a2, A, a); mul(c, A, mx); mul(s, A, my);
+        for (int k = 1; k <= K; k++) {
+            const double m = std::max(std::fabs(mx[k]), gamma * gamma * std::fabs(my[k])) * fact[k];
+            out[k - 1] = std::max(out[k - 1], m);
+            out[3 + k] = std::max(out[3 + k], std::fabs(a[k]) * fact[k]);
+        }
+    }
+    for (int i = 0; i < 8; i++) out[i] *= 1.1;
+}
+
 // numpy's scalar x**2 calls libm pow(x, 2.0), which is not always the rounded product x*x (it differs by one ulp for
 // ~0.1 % of arguments on glibc 2.35); the exponent is volatile so that no compiler folds the call into a multiply.
 static double libm_square(double x) {
@@ -1094,6 +1131,7 @@ struct rtmi_batch {
     // ([0] sliced, [1] plain; < 0: not measured yet), and what the last rtmi_run used
     double auto_ms[2] = {-1.0, -1.0};
     int auto_n[2] = {0, 0};      // timed runs per schedule so far
+    double gold_sup[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // gold_sup_derivatives(gamma_step) for op10/op11
     int mode_used = RTMI_LAUNCH_PLAIN;
     void* staging = nullptr;     // device scratch of the read / metric / set_state paths, grown on demand, freed with the batch
     size_t staging_bytes = 0;
@@ -1123,6 +1161,7 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     a.K.gamma = (T)p.gamma; a.K.g2m1 = (T)(p.gamma * p.gamma - 1.0);
     a.K.gamma_s = (T)p.gamma_step; a.K.g2m1_s = (T)(p.gamma_step * p.gamma_step - 1.0);
     for (int i = 0; i < 4; i++) a.K.box[i] = (T)p.box[i];
+    for (int i = 0; i < 8; i++) a.K.gold_sup[i] = (T)b->gold_sup[i];
     a.R = b->R; a.max_size = p.max_size; a.stride = p.record_stride; a.rec_rows = p.rec_rows;
     const size_t R = (size_t)b->R;
     a.st = (double*)b->state; a.has_hist = p.method == 7;
@@ -1290,6 +1329,7 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     rtmi_batch* b = new (std::nothrow) rtmi_batch();
     if (!b) return fail(RTMI_ERR_ALLOC, "rtmi_batch_create: host allocation failed");
     b->field = f; b->p = *p; b->R = R; b->esz = p->dtype == RTMI_F64 ? 8 : 4; b->stream = (hipStream_t)stream;
+    if (p->method >= 10) gold_sup_derivatives(p->gamma_step, b->gold_sup);
     if (b->p.record_stride > 0 && b->p.rec_rows <= 0)
         b->p.rec_rows = ((int64_t)p->max_size + p->record_stride - 1) / p->record_stride;
     if (b->p.record_stride == 0) b->p.rec_rows = 0;
