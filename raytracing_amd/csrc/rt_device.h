@@ -488,7 +488,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // reads global memory for that lookup -- the coefficient VALUES are the same bits either way, so results do not
 // depend on the policy.  No block barrier: the tile is private to one wave and LDS executes a wave's DS
 // instructions in order; fetch() must be reached in wave-uniform control flow (it votes and shuffles).
-template <typename T> struct LdsGather {
+template <typename T, int PHASES = RTMI_TILE_PHASES> struct LdsGather {
     static constexpr int TILE = 16;                 // coefficient rows/cols held
     static constexpr int GPITCH = TILE + 1;         // pairs per g row (one pad pair against bank aliasing)
     static constexpr int ZPITCH = TILE + 2;         // elements per zn row
@@ -593,14 +593,14 @@ template <typename T> struct LdsGather {
         int cx, cy;
         const bool fits = place(F, c, active, cx, cy);
         if (__ballot(!fits) == 0ull || fits) {   // every lane in the tile (the common, wave-uniform case), or this one is
-#if RTMI_TILE_PHASES > 1
+            if constexpr (PHASES > 1) {
             const RT_LDS Pair<T>* gw = gt + cy * GPITCH + cx;
             const RT_LDS T* zw = zt + (cy + 1) * ZPITCH + (cx + 1);
             const T z0 = zw[0], z1 = zw[1], z2 = zw[ZPITCH], z3 = zw[ZPITCH + 1];
-            constexpr int ROWS = 4 / RTMI_TILE_PHASES;
+            constexpr int ROWS = 4 / PHASES;
             T sx = 0, sy = 0;
 #pragma unroll
-            for (int ph = 0; ph < RTMI_TILE_PHASES; ph++) {
+            for (int ph = 0; ph < PHASES; ph++) {
                 Pair<T> a[ROWS][4];
 #pragma unroll
                 for (int r = 0; r < ROWS; r++) {
@@ -623,12 +623,12 @@ template <typename T> struct LdsGather {
             }
             n = bilinear(c, z0, z1, z2, z3);
             gx = sx; gy = sy;
-#else
+            } else {   // PHASES == 1: the whole window in flight at once (the latency build: registers to spare, nothing to hide behind)
             T z[4];
             Pair<T> g[4][4];
             read_tile(cx, cy, z, g);
             field_combine(c, z, g, n, gx, gy);
-#endif
+            }
         } else {
             // this lane's window is outside the tile (or at a grid end): row by row from global memory, so that this rare
             // branch does not set the kernel's register count (36 coefficients + 18 addresses in flight did)

@@ -678,11 +678,11 @@ template <typename T> __device__ __forceinline__ void idle_ray(const BatchDev<T>
     r.hx0 = r.hx1 = r.x; r.hy0 = r.hy1 = r.y;
 }
 
-template <typename T, bool LDS> struct GatherOf { using type = rt::GlobalGather<T>; };
-template <typename T> struct GatherOf<T, true> { using type = rt::LdsGather<T>; };
+template <typename T, bool LDS, int PH = RTMI_TILE_PHASES> struct GatherOf { using type = rt::GlobalGather<T>; };
+template <typename T, int PH> struct GatherOf<T, true, PH> { using type = rt::LdsGather<T, PH>; };
 template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::GlobalGather<T>&, T*) {}
-template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::LdsGather<T>& g, T* lds) {
-    g.init(lds + (threadIdx.x >> 6) * rt::LdsGather<T>::ELEMS);
+template <typename T, bool LDS, int PH> __device__ __forceinline__ void gather_init(rt::LdsGather<T, PH>& g, T* lds) {
+    g.init(lds + (threadIdx.x >> 6) * rt::LdsGather<T, PH>::ELEMS);
 }
 
 // A ray's state is stored once, when it terminates: the batch members that needs (state slab, istep, alive) are re-read
@@ -841,7 +841,7 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
     }
 }
 
-template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool COH = false>
+template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool COH = false, int PH = RTMI_TILE_PHASES>
 __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, long blk, int nsteps);
 
 // The loop at :866-879: one lane per ray, state in registers for up to nsteps DELTA_S steps.
@@ -857,9 +857,18 @@ void k_advance(BatchDev<T> a, int nsteps) {
     __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
     advance_bundle<T, METHOD, ISO, LDS, VAR>(a, lds, (long)blockIdx.x * blockDim.x, nsteps);
 }
-template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool COH>
+// The tile kernel built for FEW waves: a batch of <= 2 waves per SIMD (cfg2's 65 536 rays: one) has nothing to hide a step's
+// dependent chain behind -- 2 060 cycles per step at one wave per SIMD against 705 of issue -- so this build may use the whole
+// register file (launch bound: one wave per SIMD) and reads the 4x4 window from the tile in one go; the scheduler then
+// overlaps the two axes, the two gradient components and the LDS round trips.  Same arithmetic, same order of every sum: same bits.
+template <typename T, int METHOD, bool ISO>
+__global__ __launch_bounds__(256, 1) void k_advance_lat(BatchDev<T> a, int nsteps) {
+    __shared__ __attribute__((aligned(16))) T lds[4 * rt::LdsGather<T, 1>::ELEMS];
+    advance_bundle<T, METHOD, ISO, true, false, false, 1>(a, lds, (long)blockIdx.x * blockDim.x, nsteps);
+}
+template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool COH, int PH>
 __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, long blk, int nsteps) {
-    typename GatherOf<T, LDS>::type gather;
+    typename GatherOf<T, LDS, PH>::type gather;
     gather_init<T, LDS>(gather, lds);
     const long k = blk + threadIdx.x;
     rt::Ray<T> r;
@@ -1132,6 +1141,7 @@ struct rtmi_batch {
     double auto_ms[2] = {-1.0, -1.0};
     int auto_n[2] = {0, 0};      // timed runs per schedule so far
     double gold_sup[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // gold_sup_derivatives(gamma_step) for op10/op11
+    int lat_simds = 0, lat_waves_per_simd = 0;       // SIMDs of the device (CUs x 4); > 0 once known (pick_advance's latency rule)
     int mode_used = RTMI_LAUNCH_PLAIN;
     void* staging = nullptr;     // device scratch of the read / metric / set_state paths, grown on demand, freed with the batch
     size_t staging_bytes = 0;
@@ -1233,8 +1243,18 @@ static bool use_lds_tile(const rtmi_batch* b) {
 static bool uniform_rows_ok(const rtmi_batch* b) {
     return b->p.record_stride == 0 || (!b->dirty_state && (double)b->R * (double)b->esz * 6.0 < 2147483647.0);
 }
+// op2/op6 fp64 tile builds for few waves (k_advance_lat): [method 2 | 6][iso]
+static const void* advance_lat_fn(int m, bool iso) {
+    static const void* const tab[2][2] = {{(const void*)k_advance_lat<double, 2, false>, (const void*)k_advance_lat<double, 2, true>},
+                                          {(const void*)k_advance_lat<double, 6, false>, (const void*)k_advance_lat<double, 6, true>}};
+    return tab[m == 6 ? 1 : 0][iso ? 1 : 0];
+}
 static const void* pick_advance(const rtmi_batch* b) {
     const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
+    // at most two waves per SIMD's worth of rays: the latency build (env RTMI_NO_LAT=1 keeps the throughput build, for A/B)
+    if (lds && b->p.dtype == RTMI_F64 && (b->p.method == 2 || b->p.method == 6) && !b->vstep && uniform_rows_ok(b) &&
+        b->lat_waves_per_simd > 0 && (b->R + 63) / 64 <= (int64_t)2 * b->lat_simds && !getenv("RTMI_NO_LAT"))
+        return advance_lat_fn(b->p.method, iso);
     // the VAR build: per-ray DELTA_S / max_size when set, and per-lane row bookkeeping always
     if (b->vstep || !uniform_rows_ok(b))
         return b->p.dtype == RTMI_F64 ? advance_var_fn<double>(b->p.method, iso) : advance_var_fn<float>(b->p.method, iso);
@@ -1385,11 +1405,12 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
             HIP_TRY(hipMemcpyAsync(b->launch + 2 * Rz, theta0, Rz * 8, hipMemcpyHostToDevice, b->stream));
         }
         HIP_TRY(hipStreamSynchronize(b->stream));  // caller's host buffers may go away
-        b->kfn = pick_advance(b);
-        b->kfn_refill = pick_refill(b);
         int dev = 0, cus = 0, per_cu = 0;
         HIP_TRY(hipGetDevice(&dev));
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        b->lat_simds = cus * 4; b->lat_waves_per_simd = 1;
+        b->kfn = pick_advance(b);
+        b->kfn_refill = pick_refill(b);
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, b->kfn_refill, 256, 0));
         b->persistent_blocks = cus * (per_cu > 0 ? per_cu : 1);
         if (b->p.launch_mode == RTMI_LAUNCH_SLICED || b->p.launch_mode == RTMI_LAUNCH_AUTO) {

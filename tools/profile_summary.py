@@ -92,8 +92,9 @@ def main():
         with open(os.path.join(ROOT, "profiles", f"{tag}_bench.json"), "w") as f:
             f.write(json.dumps(bench) + "\n")
         key = f"{cfg['workload'].split(',')[0]}:{cfg['rays_rank0']}:{cfg['record']}{'+n_ray' if cfg.get('n_ray_rows') else ''}:{bench['dtype']}:{cfg['method']}"
-        if cfg.get("launch_mode", "lane") != "lane":          # bench.py looks up lane-mode entries only; keep the others apart
-            key += ":" + cfg["launch_mode"]
+        mode = cfg.get("launch_mode_used", cfg.get("launch_mode", "plain"))
+        if mode not in ("lane", "plain"):                     # bench.py looks plain-launch entries up without a suffix
+            key += ":" + mode
         tj[key] = entry
         print("\n".join(lines))
     tj["_note"] = ("HBM bytes and instruction counts per advance-kernel launch from rocprofv3 --pmc (separate passes; FETCH_SIZE/WRITE_SIZE "
