@@ -243,7 +243,7 @@ def main():
         from scipy.interpolate import PchipInterpolator
         for scen, m in (("vert_heterogeneous", 6), ("anisotropy", 11)):
             if scen == "anisotropy":
-                continue   # 90 s of reference time for the same code path; vert covers it
+                continue   # the per-ray stage is the same code; the across-ray stage has its anisotropy fixture below
             d, s_ray = run_traj(R, scen, m, R.DELTA_S, 91)
             times = np.arange(0.05, 0.6, 0.05)
             out = np.full((len(times), 3, s_ray.shape[2]), np.nan)
@@ -256,14 +256,19 @@ def main():
                             out[it, q, i] = PchipInterpolator(t_ray, s_ray[:n, col, i])(travel_time)
             save("isochrones_vert_op6", dict(times=times, points=out, theta=d["theta"], step=d["step"],
                                              max_size=d["max_size"], box=d["box"]))
-    if want("wavefronts"):
-        # across-ray stage of the wavefront extraction (RT_bench.py:1005-1026, 1043-1044), with the reference's own calls,
-        # on the reference's own trajectories (vert op6, 31 rays; anisotropy op11 takes 90 s of reference time for the same code)
+    for key, scen, m, gam in (("wavefronts", "vert_heterogeneous", 6, 1), ("wavefronts_aniso", "anisotropy", 11, 3)):
+        if not want(key):
+            continue
+        # across-ray stage of the wavefront extraction (RT_bench.py:1005-1026, 1043-1044), with the reference's own calls, on
+        # the reference's own trajectories: vert op6 and -- where the ray angle is NOT the wavefront normal -- anisotropy
+        # (gamma = 3) op11, 31 rays each (the latter takes ~90 s of reference time)
         from scipy.interpolate import PchipInterpolator
-        d, s_ray = run_traj(R, "vert_heterogeneous", 6, R.DELTA_S, 91)
+        if scen == "anisotropy":
+            R.gamma = gam           # module-global read by op10/op11 (Q12); run_traj sets it too
+        d, s_ray = run_traj(R, scen, m, R.DELTA_S, 91)
         times = np.arange(0.05, 0.6, 0.05)
         RC = s_ray.shape[2]
-        res = dict(times=times, theta=d["theta"], step=d["step"], max_size=d["max_size"], box=d["box"])
+        res = dict(times=times, theta=d["theta"], step=d["step"], max_size=d["max_size"], box=d["box"], gamma=gam, method=m)
         for it, travel_time in enumerate(times):
             valid_ray_coord, angle_vector, rays = [], [], []
             for i in range(RC):
@@ -288,7 +293,7 @@ def main():
                             f"angle_rayorder{it}": angle_vector, f"dxdy{it}": dy_dx_original, f"normal{it}": normal_angles,
                             f"angle_diff_ref{it}": np.absolute(angle_vector - normal_angles),    # (:1032) as the reference zips it
                             f"x_fine{it}": pchip_interpolator(y_fine), f"y_fine{it}": y_fine})
-        save("wavefronts_vert_op6", res)
+        save("wavefronts_vert_op6" if scen != "anisotropy" else "wavefronts_aniso_op11", res)
     if want("consts"):
         save("constants", consts)
 

@@ -1156,12 +1156,14 @@ def test_cfg4_fp32_full_8m_rays(rb, gpu_fields):
 
 
 # ------------------------------------------------------------------ SURVEY 8f rank 4, second stage: wavefronts across rays
-def test_wavefronts_vs_scipy_on_reference_trajectories(rb, gpu_fields):
+@pytest.mark.parametrize("fixture,m,gam", [("wavefronts_vert_op6", 6, 1), ("wavefronts_aniso_op11", 11, 3)])
+def test_wavefronts_vs_scipy_on_reference_trajectories(fixture, m, gam, rb, gpu_fields):
     """rtmi_wavefronts (device: sort by y, PCHIP across rays, derivative, normal angles, 100-point curve) against the
     reference's own code path (RT_bench.py:1005-1026, 1043-1044: np.argsort + scipy PchipInterpolator + .derivative())
-    applied to the reference's trajectories -- fixture wavefronts_vert_op6, 11 traveltimes x 31 rays."""
-    g = golden("wavefronts_vert_op6")
-    b = rb.Batch(gpu_fields("vert_heterogeneous"), 6, float(g["step"]), int(g["max_size"]), g["box"], 1, g["theta"], -2.0,
+    applied to the reference's trajectories -- 11 traveltimes x 31 rays of vert_heterogeneous op6 and of the anisotropy
+    scenario (gamma = 3, op11), where the ray direction is NOT the wavefront normal (the reference draws both, :1016-1039)."""
+    g = golden(fixture)
+    b = rb.Batch(gpu_fields("vert_heterogeneous"), m, float(g["step"]), int(g["max_size"]), g["box"], gam, g["theta"], -2.0,
                  -2.0, record_stride=1)
     b.run()
     wf = b.wavefronts(g["times"])
@@ -1185,7 +1187,10 @@ def test_wavefronts_vs_scipy_on_reference_trajectories(rb, gpu_fields):
         assert np.abs(w["angle"] - iso[it, 2, w["ray"]]).max() == 0
         assert np.abs(w["angle_diff"] - np.abs(w["angle"] - w["normal"])).max() < 1e-15
         assert np.abs(w["angle_diff"] - g[f"angle_diff_ref{it}"]).max() < 1e-10
-        assert w["angle_diff"].max() < 0.05                           # rays are normal to wavefronts (31 coarse points)
+        if gam == 1:
+            assert w["angle_diff"].max() < 0.05                       # isotropic: rays are normal to wavefronts (31 coarse points)
+        else:
+            assert w["angle_diff"].max() > 0.1                        # anisotropic: group and phase directions differ
     assert seen >= 8
 
 
