@@ -24,7 +24,7 @@
 // entries by a few units of 2^-105 relative, which can change a result only when the exact value lies within
 // 1e-32 relative of a rounding boundary.
 // Checked bit for bit against the libm of the build image on 2e9 arguments (tools/check_libm_sincos.c; every range
-// above, both functions) and in tests/test_libm_sincos.py; |x| >= 105414350 (glibc's __branred) is outside what
+// above, both functions) and on the device in tests/test_gpu_exact.py::test_device_sincos_is_libm_bit_for_bit; |x| >= 105414350 (glibc's __branred) is outside what
 // the path produces and returns the library's ordinary sincos there.
 //
 // Host/device: the same source compiles under gcc for the CPU-side checker (tools/, tests/) and under hipcc for
