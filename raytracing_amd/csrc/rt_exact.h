@@ -451,7 +451,7 @@ __device__ __forceinline__ double ang_golden_aniso(const Ray<double>& r, const C
     const double gmx = __builtin_fmax(__builtin_fabs(fgx), __builtin_fabs(fgy)) * hstep;
     const double E[5] = {0.0, fma_(afn, k.gold_sup[0], gmx * k.gold_sup[4]), fma_(afn, k.gold_sup[1], gmx * k.gold_sup[5]),
                          fma_(afn, k.gold_sup[2], gmx * k.gold_sup[6]), fma_(afn, k.gold_sup[3], gmx * k.gold_sup[7])};
-    return golden_filtered(fast_a, EA, expand, exact, B, E, e1 + EA, r.th, r.uy, r.ux);
+    return golden_filtered(fast_a, EA, expand, exact, B, E, e1, r.th, r.uy, r.ux);   // expand refines 1/a twice: e1 covers it
 }
 
 // ---------------------------------------------------------------- opN around the field lookup
