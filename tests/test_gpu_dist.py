@@ -1,0 +1,61 @@
+"""GPU, two processes on one MI355X (gloo for the rendezvous and the gather; RCCL needs one GPU per rank and runs on the
+driver's multi-GPU node): raytracing_amd.dist.trazar_sharded -- one trazar() call's rays split over the ranks -- gives the
+unsharded call's arrays bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.init()                                   # torch's HIP runtime first (raytracing_amd/_lib.py)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from raytracing_amd import dist as rd
+        from raytracing_amd import rt_bench as rb
+        cases = [("vert_heterogeneous", "3", rb.op6, np.linspace(0, np.pi / 2, 1001), 16, 1),      # ragged: 501 + 500
+                 ("anisotropy", "4", rb.op11, np.linspace(0, np.pi / 2, 64), None, 3),
+                 ("interface", "1", rb.op6, None, "full", 1)]                                         # the 42-ray preset
+        for scen, choice, op, th, record, gam in cases:
+            rb.gamma = gam
+            res = rd.trazar_sharded(op, scen, False, rb.DELTA_S, 91, choice, thetas=th, record=record, device=0)
+            if rank == 0:
+                fld = rb.Field.build(scen)
+                z, grd = rb.FieldSpline(fld, "n"), (rb.FieldSpline(fld, "dy"), rb.FieldSpline(fld, "dx"))
+                ref = rb.trazar(op, z, grd, False, rb.DELTA_S, 91, choice, thetas=th, record=record)
+                fld.close()
+                assert np.array_equal(res[1], ref[1]), scen                       # d_ray
+                assert np.array_equal(res[3], ref[3]), scen                       # errors (interface: the 42 exit-angle errors)
+                if record is not None:
+                    assert res[0].shape == ref[0].shape and np.array_equal(res[0], ref[0]), scen
+                else:
+                    assert res[0] is None
+            else:
+                assert res is None
+        if rank == 0:
+            open(os.path.join(tmp, "ok"), "w").write("ok")
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_trazar_sharded_two_ranks_one_gpu(tmp_path):
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert (tmp_path / "ok").exists()
