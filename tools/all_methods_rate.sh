@@ -1,0 +1,10 @@
+#!/bin/bash
+# ray-steps/s of every step method on the scenarios it applies to, 1 048 576 rays (524 288 for the golden-section methods), fp64,
+# no record, default schedule: one line per case through tools/bench_line.py
+for scen in vert_heterogeneous fisheye interface; do
+  for m in 1 2 3 4 5 6 7 8 9; do
+    rays=1048576; case $m in 5|9) rays=524288;; esac
+    echo -n "$scen : "; python3 tools/bench_line.py --scenario $scen --method $m --rays $rays --record none --steps 3
+  done
+done
+for m in 10 11; do echo -n "anisotropy : "; python3 tools/bench_line.py --scenario anisotropy --method $m --rays 524288 --record none --steps 3; done

@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Parity sweep on the GPU box: every step method on every scenario it applies to, device (librtmi through the C ABI) against
+the CPU oracle, on two batches each -- a fan of 4 096 rays from the scenario's launch point and 2 048 rays with random launch
+points and directions anywhere in the box.  One line per case: rays with identical step counts, largest relative difference
+of the final state and of every 64th recorded row (|a-b| / max(|b|, 1)), and for the reference-order methods whether the
+whole result is the oracle's bits.  The oracle itself is pinned to the reference by tests/test_oracle_golden.py (bit-identical
+wherever atan2 is not involved).  This is a checker run (tests/ material), not product code.
+
+  python3 tools/parity_sweep.py > profiles/r03_parity_sweep.txt
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from raytracing_amd import rt_bench as rb          # noqa: E402
+from oracle import rt_oracle as O                   # noqa: E402
+
+LIM = {"interface": (-2, 20, -2, 4), "fisheye": (-1.5, 1.5, -1.5, 1.5), "vert_heterogeneous": (-2, 5, -2.5, 1),
+       "anisotropy": (-2, 5, -2.5, 1)}
+EXACT = (3, 5, 9, 10, 11)
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0))) if a.size else 0.0
+
+
+def main():
+    threads = min(O.max_threads(), os.cpu_count() or 1)
+    rng = np.random.default_rng(2026)
+    print(f"# device vs oracle ({threads} host threads); tolerance of the north star: 1e-9 relative, step counts exactly")
+    print(f"{'scenario':19s} {'op':>3s} {'batch':7s} {'rays':>5s} {'ray-steps':>10s} {'same steps':>10s} {'final':>9s} {'rows/64':>9s} {'bits':>5s}")
+    worst = 0.0
+    t0 = time.time()
+    for scen in ("vert_heterogeneous", "fisheye", "interface", "anisotropy"):
+        key = "vert_heterogeneous" if scen == "anisotropy" else scen
+        F = rb.Field.build(key, LIM[key], rb.DELTA)
+        OF = O.Field(key, LIM[key], rb.DELTA)
+        gam = 3 if scen == "anisotropy" else 1
+        methods = (10, 11) if scen == "anisotropy" else range(1, 10)
+        if scen == "fisheye":
+            step, ms, x0f, y0f, thf = 2 * np.pi / 303, 3040, 1.0, 0.0, np.linspace(np.pi / 4, 3 * np.pi / 4, 4096)
+        elif scen == "interface":
+            step, ms, x0f, y0f, thf = rb.DELTA_S, 30228, -2.0, -2.0, np.linspace(2 * np.pi / 60, np.pi / 2, 4097)[:4096]
+        else:
+            step, ms, x0f, y0f, thf = rb.DELTA_S, 30228, -2.0, -2.0, np.linspace(0, np.pi / 2, 4096)
+        lim = LIM[scen]
+        xr = rng.uniform(lim[0] + 0.05, lim[1] - 0.05, 2048); yr = rng.uniform(lim[2] + 0.05, lim[3] - 0.05, 2048)
+        thr = rng.uniform(-np.pi, np.pi, 2048)
+        for m in methods:
+            for tag, x0, y0, th, msz in (("fan", x0f, y0f, thf, ms), ("random", xr, yr, thr, 3000)):
+                R = len(th)
+                if m in (5, 9, 10, 11) and scen == "interface" and tag == "fan":
+                    th, R = th[::4], len(th[::4])          # the golden-section methods on 30 000-row rays: keep the oracle's share short
+                b = rb.Batch(F, m, step, msz, lim, gam, th, x0, y0, record_stride=64)
+                b.run()
+                d, fin, rows = b.d_ray(), b.final(), b.rows()
+                b.close()
+                o = O.trazar(OF, m, gam, step, msz, lim, x0, y0, th, record_stride=64, nthreads=threads)
+                same = d[2] == o["d_ray"][2]
+                ef = rel(fin[:, same], o["final"][:, same])
+                er = rel(rows[:, :, same], o["s_ray"][:, :, same])
+                bits = bool(np.array_equal(fin, o["final"]) and np.array_equal(rows, o["s_ray"]) and np.array_equal(d, o["d_ray"]))
+                print(f"{scen:19s} {m:3d} {tag:7s} {R:5d} {int(d[2].sum()):10d} {int(same.sum()):10d} {ef:9.1e} {er:9.1e} {'yes' if bits else ('NO' if m in EXACT else '-'):>5s}",
+                      flush=True)
+                if not (scen == "interface" and m == 4):
+                    worst = max(worst, ef, er)
+        F.close()
+    print(f"# largest difference outside interface x op4 (atan2 under the curvature formula's amplification): {worst:.1e}; {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
