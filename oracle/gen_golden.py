@@ -182,6 +182,12 @@ def main():
         for m in (3, 4, 5):
             d, s_ray = run_traj(R, "interface", m, R.DELTA_S, 91, rays=(th, np.ones(16) * -2))
             save(f"traj_interface_op{m}_16", d)
+    if want("traj_interface_rest"):
+        # the remaining isotropic methods on the same 16-ray interface fan (round 3): with these every scenario has every method
+        th = np.linspace(2 * (np.pi / 60), np.pi / 2, 17)[:16]
+        for m in (1, 2, 7, 8, 9):
+            d, s_ray = run_traj(R, "interface", m, R.DELTA_S, 91, rays=(th, np.ones(16) * -2))
+            save(f"traj_interface_op{m}_16", d)
     if want("traj_fisheye_fan"):
         # the 9-ray fisheye fan (both terminations) for every isotropic method (round 2)
         th = np.linspace(np.pi / 4, 3 * np.pi / 4, 9)
