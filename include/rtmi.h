@@ -119,6 +119,10 @@ typedef struct {
                                 reference's call surface never sees it; dropping it saves 1/7 of the recorded bytes */
     int32_t slice_steps;     /* time-sliced schedule: DELTA_S steps per time slice of a bundle (0 -> 512); a bundle's first two
                                 slices are 4 and 2 times as long */
+    int32_t reference_order; /* 0 (default): op1/2/6/7/8 step in fused forms (~1e-13 from the reference per trajectory; op7, which
+                                differentiates positions, up to ~1e-9 on the interface scenario); 1 (fp64 only): they too run in the
+                                reference's own operation order, like op3/4/5/9/10/11 always do -- op2/op6 then give the reference's
+                                bits, op1/7/8 differ from it by their atan2 alone (numpy's is SVML's) -- at about a third of the speed */
 } rtmi_params;
 
 /* Upload R launch conditions (host pointers; x0/y0 per ray -- pos_x[k], -2 or the fisheye start, :809-813),

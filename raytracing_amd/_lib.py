@@ -29,7 +29,8 @@ class Params(C.Structure):
                 ("box", C.c_double * 4), ("launch_mode", C.c_int32), ("block_size", C.c_int32),
                 ("refill_min", C.c_int32), ("exact_basis", C.c_int32),
                 ("field_path", C.c_int32), ("sort_rays", C.c_int32),
-                ("ext_s_ray", C.c_void_p), ("ext_n_ray", C.c_void_p), ("lazy_clear", C.c_int32), ("no_n_ray", C.c_int32), ("slice_steps", C.c_int32)]
+                ("ext_s_ray", C.c_void_p), ("ext_n_ray", C.c_void_p), ("lazy_clear", C.c_int32), ("no_n_ray", C.c_int32), ("slice_steps", C.c_int32),
+                ("reference_order", C.c_int32)]
 
 
 class DeviceView(C.Structure):

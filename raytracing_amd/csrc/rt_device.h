@@ -873,9 +873,14 @@ namespace rt {
 
 // Methods that run in the reference's own operation order (rt_exact.h): curvature advancement and/or golden-section
 // angle search, fp64 only (the reference has no fp32).
+// The kernels' METHOD template value is the step method 1..11, plus kRefOrder for op1/2/6/7/8 when the batch asks for the
+// reference's operation order throughout (rtmi_params.reference_order, fp64): those five then take rt_exact.h's path too --
+// op2/op6 become the oracle's (= the reference's) bits, op1/7/8 differ from it by their atan2 alone.
+constexpr int kRefOrder = 16;
+constexpr int base_method(int m) { return m & 15; }
 template <typename T, int METHOD> struct IsExact { static constexpr bool value = false; };
 template <int METHOD> struct IsExact<double, METHOD> {
-    static constexpr bool value = METHOD == 3 || METHOD == 4 || METHOD == 5 || METHOD == 9 || METHOD == 10 || METHOD == 11;
+    static constexpr bool value = (METHOD & kRefOrder) != 0 || METHOD == 3 || METHOD == 4 || METHOD == 5 || METHOD == 9 || METHOD == 10 || METHOD == 11;
 };
 inline bool is_exact_method(int method) { return method == 3 || method == 4 || method == 5 || method >= 9; }
 
@@ -912,7 +917,7 @@ inline bool rotates_unit(int method, bool f64) { return (f64 || RTMI_UNIT_REFRES
 template <typename T, int METHOD, bool ISO, typename G>
 __device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& k, G& gather, bool active, Ray<T>& r, int i) {
     if constexpr (IsExact<T, METHOD>::value) {
-        return ex::ray_step<METHOD>(F, k, gather, active, r);
+        return ex::ray_step<base_method(METHOD)>(F, k, gather, active, r, i);
     } else {
     Acc fx, fy, fth;
     T fn, fgx, fgy;

@@ -455,15 +455,30 @@ __device__ __forceinline__ double ang_golden_aniso(const Ray<double>& r, const C
 }
 
 // ---------------------------------------------------------------- opN around the field lookup
+// METHOD here is the step method itself, 1..11: op1/2/6/7/8 take this path only when the batch asks for the reference's
+// operation order throughout (rtmi_params.reference_order); op3/4/5/9/10/11 always do.
 template <int METHOD>
 __device__ __forceinline__ bool op_advance(const Consts<double>& k, const Ray<double>& r, double& fx, double& fy) {
-    if constexpr (METHOD == 3 || METHOD == 4 || METHOD == 5 || METHOD == 10) return ex::adv_curv(r, k, fx, fy);
+    if constexpr (METHOD == 1 || METHOD == 2) { ex::adv_first(r, k.step, fx, fy); return true; }
+    else if constexpr (METHOD == 3 || METHOD == 4 || METHOD == 5 || METHOD == 10) return ex::adv_curv(r, k, fx, fy);
     else { ex::adv_second(r, k, fx, fy); return true; }
 }
+// i: the row being produced (op7's bootstrap rows 1 and 2, :833-864)
 template <int METHOD>
-__device__ __forceinline__ double op_angle(const Consts<double>& k, const Ray<double>& r, bool flag, double fn, double fgx,
-                                           double fgy) {
-    if constexpr (METHOD == 3) return flag ? ex::ang_rk2(r, k.step, fn, fgx, fgy) : r.th;
+__device__ __forceinline__ double op_angle(const Consts<double>& k, const Ray<double>& r, bool flag, double fx, double fy,
+                                           double fn, double fgx, double fgy, int i) {
+    if constexpr (METHOD == 1 || METHOD == 8) return ex::ang_cost(r, k.step, fgx, fgy);
+    else if constexpr (METHOD == 2 || METHOD == 6) return ex::ang_rk2(r, k.step, fn, fgx, fgy);
+    else if constexpr (METHOD == 7) {
+        // finite_diff (:370-372) over [P0, P1, P2, P3] = [h0, h1, (x, y), f], left to right like the reference; rows 1 and 2
+        // use the first- and second-order backward differences (:843, :856)
+        double vx, vy;
+        if (i == 1) { vx = fx - r.x; vy = fy - r.y; }
+        else if (i == 2) { vx = 3.0 * fx - 4.0 * r.x + r.hx1; vy = 3.0 * fy - 4.0 * r.y + r.hy1; }
+        else { vx = 11.0 * fx - 18.0 * r.x + 9.0 * r.hx1 - 2.0 * r.hx0; vy = 11.0 * fy - 18.0 * r.y + 9.0 * r.hy1 - 2.0 * r.hy0; }
+        return ::atan2(vy, vx);
+    }
+    else if constexpr (METHOD == 3) return flag ? ex::ang_rk2(r, k.step, fn, fgx, fgy) : r.th;
     else if constexpr (METHOD == 4) return flag ? ex::ang_cost(r, k.step, fgx, fgy) : r.th;
     else if constexpr (METHOD == 5) return flag ? ex::ang_golden_iso(r, k.step, fn, fgx, fgy) : r.th;
     else if constexpr (METHOD == 9) return ex::ang_golden_iso(r, k.step, fn, fgx, fgy);
@@ -501,13 +516,13 @@ __device__ __forceinline__ void derive(const Consts<double>& k, Ray<double>& r) 
 
 template <int METHOD, typename G>
 __device__ __forceinline__ bool ray_step(const FieldDev<double>& F, const Consts<double>& k, G& gather, bool active,
-                                         Ray<double>& r) {
+                                         Ray<double>& r, int i) {
     double fx, fy, fn, fgx, fgy;
     const bool flag = ex::op_advance<METHOD>(k, r, fx, fy);
     ex::n_gradient(F, gather, active, fx, fy, fn, fgx, fgy);
-    const double fth = ex::op_angle<METHOD>(k, r, flag, fn, fgx, fgy);
+    const double fth = ex::op_angle<METHOD>(k, r, flag, fx, fy, fn, fgx, fgy, i);
     ex::store_update(k, r, fx, fy, fth, fn, fgx, fgy);
-    return !outside(k, r);
+    return (METHOD == 7 && i <= 2) || !outside(k, r);     // no boundary test in op7's bootstrap rows
 }
 
 }  // namespace ex

@@ -645,7 +645,7 @@ __device__ __forceinline__ void load_ray(const BatchDev<T>& a, long k, rt::Ray<T
     r.x = ld_state<COH>(a.acc(0) + k); r.y = ld_state<COH>(a.acc(1) + k); r.th = ld_state<COH>(a.acc(2) + k);
     r.n = ld_state<COH>(a.aux(0) + k); r.gx = ld_state<COH>(a.aux(1) + k); r.gy = ld_state<COH>(a.aux(2) + k);
     r.dsim = ld_state<COH>(a.acc(3) + k); r.dreal = ld_state<COH>(a.acc(4) + k); r.tt = ld_state<COH>(a.acc(5) + k);
-    if (METHOD == 7) {
+    if (rt::base_method(METHOD) == 7) {
         r.hx0 = ld_state<COH>(a.aux(3) + k); r.hy0 = ld_state<COH>(a.aux(4) + k);
         r.hx1 = ld_state<COH>(a.aux(5) + k); r.hy1 = ld_state<COH>(a.aux(6) + k);
     } else { r.hx0 = r.hy0 = r.hx1 = r.hy1 = 0; }
@@ -661,7 +661,7 @@ __device__ __forceinline__ void store_ray(const BatchDev<T>& a, long k, const rt
     st_state<COH>(a.acc(0) + k, r.x); st_state<COH>(a.acc(1) + k, r.y); st_state<COH>(a.acc(2) + k, r.th);
     st_state<COH>(a.aux(0) + k, r.n); st_state<COH>(a.aux(1) + k, r.gx); st_state<COH>(a.aux(2) + k, r.gy);
     st_state<COH>(a.acc(3) + k, r.dsim); st_state<COH>(a.acc(4) + k, r.dreal); st_state<COH>(a.acc(5) + k, r.tt);
-    if (METHOD == 7) {
+    if (rt::base_method(METHOD) == 7) {
         st_state<COH>(a.aux(3) + k, r.hx0); st_state<COH>(a.aux(4) + k, r.hy0);
         st_state<COH>(a.aux(5) + k, r.hx1); st_state<COH>(a.aux(6) + k, r.hy1);
     }
@@ -1175,9 +1175,9 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     a.R = b->R; a.max_size = p.max_size; a.stride = p.record_stride; a.rec_rows = p.rec_rows;
     const size_t R = (size_t)b->R;
     a.st = (double*)b->state; a.has_hist = p.method == 7;
-    a.exact = p.dtype == RTMI_F64 && rt::is_exact_method(p.method);
+    a.exact = p.dtype == RTMI_F64 && (rt::is_exact_method(p.method) || p.reference_order);
     a.iso = p.gamma == 1.0 && p.method < 10 && !a.exact;
-    a.rot = rt::rotates_unit(p.method, p.dtype == RTMI_F64);
+    a.rot = rt::rotates_unit(p.method, p.dtype == RTMI_F64) && !a.exact;
     a.istep = b->istep; a.alive = b->alive;
     a.s_ray = (T*)b->s_ray; a.n_ray = (T*)b->n_ray;
     a.counters = b->counters;
@@ -1187,47 +1187,54 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     return a;
 }
 
-// kernel variant tables: [method][iso][lds].  Anisotropic-only methods (op10/op11) have no ISO build.
-#define RTMI_ADV_(T, M) \
-    {{(const void*)k_advance<T, M, false, false, false>, (const void*)k_advance<T, M, false, true, false>}, \
-     {(const void*)k_advance<T, (M < 10 ? M : 1), (M < 10), false, false>, (const void*)k_advance<T, (M < 10 ? M : 1), (M < 10), true, false>}}
-#define RTMI_ADVVAR_(T, M) \
-    {(const void*)k_advance<T, M, false, false, true>, (const void*)k_advance<T, (M < 10 ? M : 1), (M < 10), false, true>}
-#define RTMI_REFILL_(T, M) \
-    {{(const void*)k_trace_refill<T, M, false, false>, (const void*)k_trace_refill<T, M, false, true>}, \
-     {(const void*)k_trace_refill<T, (M < 10 ? M : 1), (M < 10), false>, (const void*)k_trace_refill<T, (M < 10 ? M : 1), (M < 10), true>}}
-#define RTMI_SLICED_(T, M) \
-    {{(const void*)k_advance_sliced<T, M, false, false>, (const void*)k_advance_sliced<T, M, false, true>}, \
-     {(const void*)k_advance_sliced<T, (M < 10 ? M : 1), (M < 10), false>, (const void*)k_advance_sliced<T, (M < 10 ? M : 1), (M < 10), true>}}
-template <typename T> static const void* sliced_fn(int m, bool iso, bool lds) {
-    static const void* const tab[11][2][2] = {RTMI_SLICED_(T, 1), RTMI_SLICED_(T, 2), RTMI_SLICED_(T, 3), RTMI_SLICED_(T, 4),
-                                              RTMI_SLICED_(T, 5), RTMI_SLICED_(T, 6), RTMI_SLICED_(T, 7), RTMI_SLICED_(T, 8),
-                                              RTMI_SLICED_(T, 9), RTMI_SLICED_(T, 10), RTMI_SLICED_(T, 11)};
-    return tab[m - 1][iso ? 1 : 0][lds ? 1 : 0];
+// kernel variant tables: [kernel method][iso][lds].  Kernel methods: the step methods 1..11, then op1/2/6/7/8 in the reference's
+// operation order (METHOD = method | rt::kRefOrder, fp64 only: the fp32 tables alias the ordinary builds there).
+// Anisotropic-only methods (op10/op11) have no ISO build.
+constexpr int kKernelMethods = 16;
+constexpr int kmethod_of(int idx) { return idx < 11 ? idx + 1 : (idx == 11 ? 1 : idx == 12 ? 2 : idx == 13 ? 6 : idx == 14 ? 7 : 8) | rt::kRefOrder; }
+static int kernel_index(int method, bool ref_order) {
+    if (!ref_order || rt::is_exact_method(method)) return method - 1;
+    return method == 1 ? 11 : method == 2 ? 12 : method == 6 ? 13 : method == 7 ? 14 : 15;
+}
+template <typename T> constexpr int km(int idx) { return sizeof(T) == 4 ? rt::base_method(kmethod_of(idx)) : kmethod_of(idx); }
+constexpr bool iso_ok(int m) { return rt::base_method(m) < 10; }
+#define RTMI_ADV_(T, I) \
+    {{(const void*)k_advance<T, km<T>(I), false, false, false>, (const void*)k_advance<T, km<T>(I), false, true, false>}, \
+     {(const void*)k_advance<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), false, false>, (const void*)k_advance<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), true, false>}}
+#define RTMI_ADVVAR_(T, I) \
+    {(const void*)k_advance<T, km<T>(I), false, false, true>, (const void*)k_advance<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), false, true>}
+#define RTMI_REFILL_(T, I) \
+    {{(const void*)k_trace_refill<T, km<T>(I), false, false>, (const void*)k_trace_refill<T, km<T>(I), false, true>}, \
+     {(const void*)k_trace_refill<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), false>, (const void*)k_trace_refill<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), true>}}
+#define RTMI_SLICED_(T, I) \
+    {{(const void*)k_advance_sliced<T, km<T>(I), false, false>, (const void*)k_advance_sliced<T, km<T>(I), false, true>}, \
+     {(const void*)k_advance_sliced<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), false>, (const void*)k_advance_sliced<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), true>}}
+#define RTMI_ALL16_(X, T) X(T, 0), X(T, 1), X(T, 2), X(T, 3), X(T, 4), X(T, 5), X(T, 6), X(T, 7), X(T, 8), X(T, 9), X(T, 10), X(T, 11), X(T, 12), X(T, 13), X(T, 14), X(T, 15)
+template <typename T> static const void* sliced_fn(int ki, bool iso, bool lds) {
+    static const void* const tab[kKernelMethods][2][2] = {RTMI_ALL16_(RTMI_SLICED_, T)};
+    return tab[ki][iso ? 1 : 0][lds ? 1 : 0];
+}
+template <typename T> static const void* advance_fn(int ki, bool iso, bool lds) {
+    static const void* const tab[kKernelMethods][2][2] = {RTMI_ALL16_(RTMI_ADV_, T)};
+    return tab[ki][iso ? 1 : 0][lds ? 1 : 0];
+}
+// per-ray DELTA_S / max_size builds (global gather only): [kernel method][iso]
+template <typename T> static const void* advance_var_fn(int ki, bool iso) {
+    static const void* const tab[kKernelMethods][2] = {RTMI_ALL16_(RTMI_ADVVAR_, T)};
+    return tab[ki][iso ? 1 : 0];
+}
+template <typename T> static const void* refill_fn(int ki, bool iso, bool lds) {
+    static const void* const tab[kKernelMethods][2][2] = {RTMI_ALL16_(RTMI_REFILL_, T)};
+    return tab[ki][iso ? 1 : 0][lds ? 1 : 0];
 }
 #undef RTMI_SLICED_
-template <typename T> static const void* advance_fn(int m, bool iso, bool lds) {
-    static const void* const tab[11][2][2] = {RTMI_ADV_(T, 1), RTMI_ADV_(T, 2), RTMI_ADV_(T, 3), RTMI_ADV_(T, 4),
-                                              RTMI_ADV_(T, 5), RTMI_ADV_(T, 6), RTMI_ADV_(T, 7), RTMI_ADV_(T, 8),
-                                              RTMI_ADV_(T, 9), RTMI_ADV_(T, 10), RTMI_ADV_(T, 11)};
-    return tab[m - 1][iso ? 1 : 0][lds ? 1 : 0];
-}
-// per-ray DELTA_S / max_size builds (global gather only): [method][iso]
-template <typename T> static const void* advance_var_fn(int m, bool iso) {
-    static const void* const tab[11][2] = {RTMI_ADVVAR_(T, 1), RTMI_ADVVAR_(T, 2), RTMI_ADVVAR_(T, 3), RTMI_ADVVAR_(T, 4),
-                                           RTMI_ADVVAR_(T, 5), RTMI_ADVVAR_(T, 6), RTMI_ADVVAR_(T, 7), RTMI_ADVVAR_(T, 8),
-                                           RTMI_ADVVAR_(T, 9), RTMI_ADVVAR_(T, 10), RTMI_ADVVAR_(T, 11)};
-    return tab[m - 1][iso ? 1 : 0];
-}
-template <typename T> static const void* refill_fn(int m, bool iso, bool lds) {
-    static const void* const tab[11][2][2] = {RTMI_REFILL_(T, 1), RTMI_REFILL_(T, 2), RTMI_REFILL_(T, 3), RTMI_REFILL_(T, 4),
-                                              RTMI_REFILL_(T, 5), RTMI_REFILL_(T, 6), RTMI_REFILL_(T, 7), RTMI_REFILL_(T, 8),
-                                              RTMI_REFILL_(T, 9), RTMI_REFILL_(T, 10), RTMI_REFILL_(T, 11)};
-    return tab[m - 1][iso ? 1 : 0][lds ? 1 : 0];
-}
 #undef RTMI_ADV_
 #undef RTMI_ADVVAR_
 #undef RTMI_REFILL_
+#undef RTMI_ALL16_
+// the fp64 batch runs rt_exact.h's arithmetic: always for op3/4/5/9/10/11, for the others when reference_order is set
+static bool batch_exact(const rtmi_batch* b) { return b->p.dtype == RTMI_F64 && (rt::is_exact_method(b->p.method) || b->p.reference_order); }
+static int batch_kernel_index(const rtmi_batch* b) { return kernel_index(b->p.method, b->p.dtype == RTMI_F64 && b->p.reference_order); }
 // field_path 0 (auto): which gather policy the step kernels are built with.
 static bool use_lds_tile(const rtmi_batch* b) {
     if (b->p.field_path == 1) return false;
@@ -1236,7 +1243,7 @@ static bool use_lds_tile(const rtmi_batch* b) {
     // per SIMD 12.5 vs 15.0 ms without recording and 19 vs 24 ms with the full record, op1/7/8 and fp32 by 0-2 %, a
     // shuffled fan 44 vs 50 ms; the reference-order fp64 methods (op3/4/5/9/10/11: 2-74 cost evaluations per step, more
     // live state) are 2-15 % faster on global gathers.
-    return !(b->p.dtype == RTMI_F64 && rt::is_exact_method(b->p.method));
+    return !batch_exact(b);
 }
 // rows can go out through the wave-uniform descriptor path: rays in lockstep (no rtmi_batch_set_state since the last
 // reset) and 6 quantities x R values within 31-bit byte offsets
@@ -1253,12 +1260,12 @@ static const void* pick_advance(const rtmi_batch* b) {
     const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
     // at most two waves per SIMD's worth of rays: the latency build (env RTMI_NO_LAT=1 keeps the throughput build, for A/B)
     if (lds && b->p.dtype == RTMI_F64 && (b->p.method == 2 || b->p.method == 6) && !b->vstep && uniform_rows_ok(b) &&
-        b->lat_waves_per_simd > 0 && (b->R + 63) / 64 <= (int64_t)2 * b->lat_simds && !getenv("RTMI_NO_LAT"))
+        !b->p.reference_order && b->lat_waves_per_simd > 0 && (b->R + 63) / 64 <= (int64_t)2 * b->lat_simds && !getenv("RTMI_NO_LAT"))
         return advance_lat_fn(b->p.method, iso);
     // the VAR build: per-ray DELTA_S / max_size when set, and per-lane row bookkeeping always
     if (b->vstep || !uniform_rows_ok(b))
-        return b->p.dtype == RTMI_F64 ? advance_var_fn<double>(b->p.method, iso) : advance_var_fn<float>(b->p.method, iso);
-    return b->p.dtype == RTMI_F64 ? advance_fn<double>(b->p.method, iso, lds) : advance_fn<float>(b->p.method, iso, lds);
+        return b->p.dtype == RTMI_F64 ? advance_var_fn<double>(batch_kernel_index(b), iso) : advance_var_fn<float>(batch_kernel_index(b), iso);
+    return b->p.dtype == RTMI_F64 ? advance_fn<double>(batch_kernel_index(b), iso, lds) : advance_fn<float>(batch_kernel_index(b), iso, lds);
 }
 // queue entries beyond the implicit first NB: every bundle is pushed back once per slice it survives
 static unsigned long long sliced_capacity(const rtmi_batch* b, int slice) {
@@ -1285,11 +1292,11 @@ static unsigned long long sliced_timeout_ticks(const rtmi_batch* b, int slice) {
 static bool sliced_feasible(const rtmi_batch* b) { return sliced_capacity(b, sliced_steps(b)) <= (1ull << 25); }
 static const void* pick_sliced(const rtmi_batch* b) {
     const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
-    return b->p.dtype == RTMI_F64 ? sliced_fn<double>(b->p.method, iso, lds) : sliced_fn<float>(b->p.method, iso, lds);
+    return b->p.dtype == RTMI_F64 ? sliced_fn<double>(batch_kernel_index(b), iso, lds) : sliced_fn<float>(batch_kernel_index(b), iso, lds);
 }
 static const void* pick_refill(const rtmi_batch* b) {
     const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
-    return b->p.dtype == RTMI_F64 ? refill_fn<double>(b->p.method, iso, lds) : refill_fn<float>(b->p.method, iso, lds);
+    return b->p.dtype == RTMI_F64 ? refill_fn<double>(batch_kernel_index(b), iso, lds) : refill_fn<float>(batch_kernel_index(b), iso, lds);
 }
 
 // clear_traj: zero the trajectory arrays (np.zeros, :802-803).  A reset with unchanged launch conditions rewrites
@@ -1345,6 +1352,8 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     ARG_TRY(p->lazy_clear == 0 || p->lazy_clear == 1, "rtmi_batch_create: lazy_clear must be 0 or 1");
     ARG_TRY(p->no_n_ray == 0 || p->no_n_ray == 1, "rtmi_batch_create: no_n_ray must be 0 or 1");
     ARG_TRY(!(p->no_n_ray && p->ext_n_ray), "rtmi_batch_create: no_n_ray set together with ext_n_ray");
+    ARG_TRY(p->reference_order == 0 || p->reference_order == 1, "rtmi_batch_create: reference_order must be 0 or 1");
+    ARG_TRY(!(p->reference_order && p->dtype != RTMI_F64), "rtmi_batch_create: reference_order needs an fp64 batch (the reference has no fp32)");
     DEVICE_TRY(f, "rtmi_batch_create");
     rtmi_batch* b = new (std::nothrow) rtmi_batch();
     if (!b) return fail(RTMI_ERR_ALLOC, "rtmi_batch_create: host allocation failed");
@@ -1356,7 +1365,7 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     int rc = RTMI_OK;
     auto body = [&]() -> int {
         const size_t Rz = (size_t)R;
-        const int naux = p->method == 7 ? 7 : rt::rotates_unit(p->method, p->dtype == RTMI_F64) ? 5 : 3;   // n gx gy + history | unit vector
+        const int naux = p->method == 7 ? 7 : (rt::rotates_unit(p->method, p->dtype == RTMI_F64) && !p->reference_order) ? 5 : 3;   // n gx gy + history | unit vector
         HIP_TRY(hipMalloc(&b->state, 6 * Rz * sizeof(double) + naux * Rz * b->esz));
         HIP_TRY(hipMalloc(&b->istep, Rz * sizeof(int)));
         HIP_TRY(hipMalloc(&b->alive, Rz));

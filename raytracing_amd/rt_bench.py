@@ -275,7 +275,8 @@ class Batch:
 
     def __init__(self, field, method, step, max_size, box, gamma, thetas, x0, y0, record_stride=1, rec_rows=0,
                  gamma_step=None, stream=None, ext_s_ray=None, ext_n_ray=None, block_size=0, launch_mode="auto",
-                 refill_min=0, exact_basis=0, field_path=0, sort_rays=False, lazy_clear=False, keep_n_ray=True, slice_steps=0):
+                 refill_min=0, exact_basis=0, field_path=0, sort_rays=False, lazy_clear=False, keep_n_ray=True, slice_steps=0,
+                 reference_order=False):
         self.field = field
         th = np.ascontiguousarray(thetas, dtype=np.float64)
         self.R = len(th)
@@ -302,6 +303,8 @@ class Batch:
         p.lazy_clear = int(bool(lazy_clear))
         p.no_n_ray = int(not keep_n_ray)
         p.slice_steps = int(slice_steps)
+        # reference_order: op1/2/6/7/8 too in the reference's own operation order (fp64): op2/op6 give its bits, slower
+        p.reference_order = int(bool(reference_order))
         self.params = p
         self._h = C.c_void_p()
         check(lib().rtmi_batch_create(field._h, C.byref(p), self.R, dptr(x0), dptr(y0), dptr(th), stream,
@@ -548,7 +551,7 @@ def moment_cv(s_ray, ray_count=None):
 
 
 def trazar(selected_func, z, grd, show, step, divisor, user_choice, *, thetas=None, starts=None, box=None,
-           gamma=None, max_size=None, record="full", return_batch=False, launch_mode="auto"):
+           gamma=None, max_size=None, record="full", return_batch=False, launch_mode="auto", reference_order=False):
     """RT_bench.py:766-948 on the GPU.  Positional arguments and the returned
     (s_ray[max_size,6,R], d_ray[3,R], compute_times[R], errors[R]) are the reference's.
 
@@ -556,7 +559,9 @@ def trazar(selected_func, z, grd, show, step, divisor, user_choice, *, thetas=No
     the preset of `user_choice`; record = "full" (reference layout), an int stride, or None (s_ray is None).
     compute_times holds the device propagation time split evenly over rays, so np.sum(compute_times) is the
     quantity the reference's benchmark reads (:1526).  launch_mode: "auto" (rtmi_params' default: the library picks the
-    schedule), "plain", "refill", "sliced" or the rtmi_launch_mode integer -- same bits in all of them.
+    schedule), "plain", "refill", "sliced" or the rtmi_launch_mode integer -- same bits in all of them.  reference_order=True:
+    op1/2/6/7/8 too step in the reference's own operation order (rtmi_params.reference_order): op2/op6 then return the
+    reference's bits, at about a third of the speed.
     """
     g, ray_count, theta_v, pos_x, s, limx_i, limx_s, limy_i, limy_s, op_if, op_fish, _, _ = constants(user_choice)
     fld = _field_of(z, grd)
@@ -581,7 +586,7 @@ def trazar(selected_func, z, grd, show, step, divisor, user_choice, *, thetas=No
     stride = 0 if record is None else (1 if record == "full" else int(record))
     b = Batch(fld, selected_func, step, max_size, box, gamma, theta_v[:ray_count], x0, y0, record_stride=stride,
               sort_rays="auto", keep_n_ray=False,          # n_ray is internal to the reference's trazar (:803), never returned
-              launch_mode=launch_mode)
+              launch_mode=launch_mode, reference_order=reference_order)
     t1 = time.perf_counter()
     b.run()
     b.sync()

@@ -148,6 +148,53 @@ def test_trajectories_are_the_oracles_bits(scen, m, R, rb, fields):
         assert _bits_equal(s, o["s_ray"]) and _bits_equal(n, o["n_ray"])
 
 
+REF_ORDER_CASES = [(scen, m) for scen in ("vert_heterogeneous", "fisheye", "interface") for m in (1, 2, 6, 7, 8)]
+
+
+@pytest.mark.parametrize("scen,m", REF_ORDER_CASES)
+def test_reference_order_mode(scen, m, rb, fields):
+    """rtmi_params.reference_order = 1: op1/2/6/7/8 too step in the reference's own operation order (rt_exact.h).
+      * op2, op6 (no atan2): the oracle's bits -- every recorded row, d_ray, final state -- through the plain, the refill and
+        the time-sliced kernel, and the REFERENCE's bits on its own fixture of the same fan (vert 31 rays, fisheye 9-ray fan,
+        interface 16 rays);
+      * op1, op7, op8: what remains is their atan2 (ocml's here, libm's in the oracle, SVML's in the reference: within an ulp
+        of each other): <= 1e-10 of the reference on every ray (op7, which differentiates positions: 1e-9; the fused default
+        is at 1.2e-9 on interface x op7)."""
+    from oracle import rt_oracle as O
+    F, OF = fields(scen)
+    name = {"vert_heterogeneous": f"traj_vert_op{m}", "fisheye": f"traj_fisheye_op{m}_fan9" if m != 6 else "traj_fisheye_op6_fan9",
+            "interface": f"traj_interface_op{m}_16"}[scen]
+    t = golden(name)
+    x0, y0, th = traj_inputs(t, scen)
+    step, ms, lim = float(t["step"]), int(t["max_size"]), t["box"]
+    o = O.trazar(OF, m, 1, step, ms, lim, x0, y0, th, record_stride=1, nthreads=8)
+    for mode in ("plain", "refill", "sliced"):
+        b = rb.Batch(F, m, step, ms, lim, 1, th, x0, y0, record_stride=1, reference_order=True, launch_mode=mode, slice_steps=300)
+        b.run()
+        d, fin, s = b.d_ray(), b.final(), b.rows()
+        b.close()
+        assert np.array_equal(d[2], t["d_ray"][2])
+        strided, last = sub_rows(s, d, int(t["stride"]))
+        if m in (2, 6):
+            assert _bits_equal(d, o["d_ray"]) and _bits_equal(fin, o["final"]) and _bits_equal(s, o["s_ray"]), mode
+            assert np.array_equal(strided, t["strided"]) and np.array_equal(last, t["last"]), mode     # the reference's bits
+        else:
+            tol = 1e-9 if m == 7 else 1e-10
+            err = max(np.max(np.abs(strided - t["strided"]) / np.maximum(np.abs(t["strided"]), 1.0)),
+                      np.max(np.abs(last - t["last"]) / np.maximum(np.abs(t["last"]), 1.0)))
+            if mode == "plain":
+                print(f"{name} reference_order: {err:.2e} from the reference")
+            assert err < tol, (mode, err)
+
+
+def test_reference_order_needs_fp64(rb):
+    from raytracing_amd._lib import RtmiError
+    F = rb.Field.build("vert_heterogeneous", LIMITS["vert_heterogeneous"], rb.DELTA, rb.F32)
+    with pytest.raises(RtmiError, match="fp64"):
+        rb.Batch(F, 6, rb.DELTA_S, 100, LIMITS["vert_heterogeneous"], 1, [0.3], -2.0, -2.0, reference_order=True)
+    F.close()
+
+
 @pytest.mark.parametrize("scen,m", [("vert_heterogeneous", 9), ("anisotropy", 11), ("fisheye", 5), ("vert_heterogeneous", 3),
                                     ("anisotropy", 10), ("fisheye", 9)])
 def test_random_rays_are_the_oracles_bits(scen, m, rb, fields):

