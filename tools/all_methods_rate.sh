@@ -8,3 +8,5 @@ for scen in vert_heterogeneous fisheye interface; do
   done
 done
 for m in 10 11; do echo -n "anisotropy : "; python3 tools/bench_line.py --scenario anisotropy --method $m --rays 524288 --record none --steps 3; done
+# rtmi_params.reference_order: op1/2/6/7/8 in the reference's operation order
+for m in 1 2 6 7 8; do echo -n "vert_heterogeneous reference_order : "; python3 tools/bench_line.py --scenario vert_heterogeneous --method $m --rays 1048576 --record none --steps 3 --reference-order; done

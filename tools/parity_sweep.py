@@ -31,7 +31,8 @@ def main():
     threads = min(O.max_threads(), os.cpu_count() or 1)
     rng = np.random.default_rng(2026)
     print(f"# device vs oracle ({threads} host threads); tolerance of the north star: 1e-9 relative, step counts exactly")
-    print(f"{'scenario':19s} {'op':>3s} {'batch':7s} {'rays':>5s} {'ray-steps':>10s} {'same steps':>10s} {'final':>9s} {'rows/64':>9s} {'bits':>5s}")
+    print("# op column: R = rtmi_params.reference_order (op1/2/6/7/8 in the reference's operation order too)")
+    print(f"{'scenario':19s} {'op':>4s} {'batch':7s} {'rays':>5s} {'ray-steps':>10s} {'same steps':>10s} {'final':>9s} {'rows/64':>9s} {'bits':>5s}")
     worst = 0.0
     t0 = time.time()
     for scen in ("vert_heterogeneous", "fisheye", "interface", "anisotropy"):
@@ -54,21 +55,24 @@ def main():
                 R = len(th)
                 if m in (5, 9, 10, 11) and scen == "interface" and tag == "fan":
                     th, R = th[::4], len(th[::4])          # the golden-section methods on 30 000-row rays: keep the oracle's share short
-                b = rb.Batch(F, m, step, msz, lim, gam, th, x0, y0, record_stride=64)
-                b.run()
-                d, fin, rows = b.d_ray(), b.final(), b.rows()
-                b.close()
                 o = O.trazar(OF, m, gam, step, msz, lim, x0, y0, th, record_stride=64, nthreads=threads)
-                same = d[2] == o["d_ray"][2]
-                ef = rel(fin[:, same], o["final"][:, same])
-                er = rel(rows[:, :, same], o["s_ray"][:, :, same])
-                bits = bool(np.array_equal(fin, o["final"]) and np.array_equal(rows, o["s_ray"]) and np.array_equal(d, o["d_ray"]))
-                print(f"{scen:19s} {m:3d} {tag:7s} {R:5d} {int(d[2].sum()):10d} {int(same.sum()):10d} {ef:9.1e} {er:9.1e} {'yes' if bits else ('NO' if m in EXACT else '-'):>5s}",
-                      flush=True)
-                if not (scen == "interface" and m == 4):
-                    worst = max(worst, ef, er)
+                for ref_order in ((False, True) if m in (1, 2, 6, 7, 8) else (False,)):
+                    b = rb.Batch(F, m, step, msz, lim, gam, th, x0, y0, record_stride=64, reference_order=ref_order)
+                    b.run()
+                    d, fin, rows = b.d_ray(), b.final(), b.rows()
+                    b.close()
+                    same = d[2] == o["d_ray"][2]
+                    ef = rel(fin[:, same], o["final"][:, same])
+                    er = rel(rows[:, :, same], o["s_ray"][:, :, same])
+                    bits = bool(np.array_equal(fin, o["final"]) and np.array_equal(rows, o["s_ray"]) and np.array_equal(d, o["d_ray"]))
+                    want_bits = m in EXACT or (ref_order and m in (2, 6))
+                    print(f"{scen:19s} {m:3d}{'R' if ref_order else ' '} {tag:7s} {R:5d} {int(d[2].sum()):10d} {int(same.sum()):10d} {ef:9.1e} {er:9.1e} "
+                          f"{'yes' if bits else ('NO' if want_bits else '-'):>5s}", flush=True)
+                    if not (scen == "interface" and m == 4) and (ref_order or m not in (1, 7, 8)):
+                        worst = max(worst, ef, er)
         F.close()
-    print(f"# largest difference outside interface x op4 (atan2 under the curvature formula's amplification): {worst:.1e}; {time.time() - t0:.0f} s")
+    print(f"# largest difference outside interface x op4 (atan2 under the curvature formula's amplification) and outside the fused "
+          f"default of the atan2 methods op1/7/8 (listed above; their reference_order rows count): {worst:.1e}; {time.time() - t0:.0f} s")
 
 
 if __name__ == "__main__":
