@@ -105,6 +105,72 @@ static double np_exp(double x) {
     return ldexp(t, (int)floor(N));
 }
 
+/* np.arctan2 on float64 as numpy 2.2.6 evaluates it on an AVX512_SKX machine: Intel SVML's __svml_atan28_ha (differs from
+ * libm's atan2 in the last bit for 7 % of arguments).  Main path restated: the ratio |y|/|x| against 0.4375, 0.6875, 1.1875,
+ * 2.4375 picks a base point c in {0, 0.5, 1, 1.5, inf}; q = (|y| - c|x|) / (|x| + c|y|) (inf: -|x|/|y|) by a reciprocal -- the
+ * VRCP14PD instruction's 14-bit estimate and two Newton steps -- as a hi + lo pair; an odd polynomial of degree 21 in two
+ * interleaved chains of q^4; atan(c) hi/lo, pi hi/lo and the signs put back.  VRCP14PD itself is a table
+ * (raytracing_amd/csrc/rt_rcp14_table.h, captured from the instruction by tools/gen_rcp14_table.c).  tools/check_np_atan2.py:
+ * 0 mismatches against np.arctan2 on 1.6e7 argument pairs.  Operands with exponents below 2^-1020 or above 2^993 (zeros and
+ * infinities among them) take SVML's scalar fall-back, restated as libm atan2. */
+#include "../raytracing_amd/csrc/rt_rcp14_table.h"
+static uint16_t g_rcp14[65536];
+static int g_rcp14_ready = 0;
+static void rcp14_init(void) {
+    static const uint64_t words[RT_RCP14_WORDS] = {RT_RCP14_DELTAS};
+    uint16_t v = RT_RCP14_T0;
+    for (int k = 0; k < 65536; k++) { v = (uint16_t)(v - ((words[k >> 5] >> (2 * (k & 31))) & 3)); g_rcp14[k] = v; }
+    g_rcp14_ready = 1;
+}
+static double vrcp14pd(double x) {
+    uint64_t xb, rb;
+    memcpy(&xb, &x, 8);
+    const uint64_t e = (xb >> 52) & 0x7ff, m = xb & 0xfffffffffffffull;
+    rb = m == 0 ? (0x7fe - e) << 52 : ((0x7fd - e) << 52) | ((uint64_t)g_rcp14[m >> 36] << 36);
+    double r;
+    memcpy(&r, &rb, 8);
+    return r;
+}
+static double np_arctan2(double y, double x) {
+    const double ax = fabs(x), ay = fabs(y);
+    uint64_t b;
+    memcpy(&b, &ax, 8); const int32_t ix = (int32_t)((uint32_t)(b >> 32) - 0x80300000u);
+    memcpy(&b, &ay, 8); const int32_t iy = (int32_t)((uint32_t)(b >> 32) - 0x80300000u);
+    if (ix >= (int32_t)0xfdd00000u || iy >= (int32_t)0xfdd00000u) return atan2(y, x);
+    const int k5 = 0.4375 * ax < ay, k1 = 0.6875 * ax < ay, k2 = 1.1875 * ax < ay, k3 = 2.4375 * ax < ay;
+    const double c = k2 ? (k3 ? 1.0 : 1.5) : (k1 ? 1.0 : 0.5);
+    const double ahi = k2 ? (k3 ? 0x1.921fb54442d18p+0 : 0x1.f730bd281f69bp-1) : (k1 ? 0x1.921fb54442d18p-1 : 0x1.dac670561bb4fp-2);
+    const double alo = k2 ? (k3 ? 0x1.1a62633145c07p-54 : 0x1.007887af0cbbdp-56) : (k1 ? 0x1.1a62633145c07p-55 : 0x1.a2b7f222f65e2p-56);
+    double den = k3 ? 0.0 : ax, num = k3 ? 0.0 : ay;
+    if (k5) { den = fma(c, ay, den); num = fma(-c, ax, num); }
+    double r = vrcp14pd(den);
+    double e = fma(-r, den, 1.0);
+    r = fma(e, r, r);
+    e = fma(-r, den, 1.0);
+    r = fma(e, r, r);
+    const double q = num * r, q2 = q * q;
+    const double res = fma(-q, den, num);
+    const double q4 = q2 * q2;
+    double ql = res * r;
+    if (k5) ql = ql + alo;
+    double A = fma(0x1.be4fbe6733718p-7, q4, 0x1.6ad5558fe19c9p-5), B = fma(-0x1.04cd71f92185ep-5, q4, -0x1.a9e755ca13d23p-5);
+    A = fma(q4, A, 0x1.e12f1edf7c393p-5);  B = fma(q4, B, -0x1.1108d326c68edp-4);
+    A = fma(q4, A, 0x1.3b132b731e73ap-4);  B = fma(q4, B, -0x1.745d119677a4fp-4);
+    A = fma(q4, A, 0x1.c71c719f99f96p-4);  B = fma(q4, B, -0x1.2492492441a21p-3);
+    A = fma(q4, A, 0x1.9999999998f43p-3);  B = fma(q4, B, -0x1.5555555555552p-2);
+    double t = fma(q2, A, B) * q2;
+    const int xneg = x < 0.0;
+    if (xneg) ql = ql - 0x1.1a64000000000p-53;                  /* pi's low part, with the sign the final flip undoes */
+    t = fma(q, t, ql);
+    double s = q + t;
+    if (k5) s = s + ahi;
+    if (xneg) s = -s + 0x1.921fb54442d18p+1;
+    return copysign(s, y);                                       /* s >= 0 here; SVML ORs y's sign bit in */
+}
+RTO_API void rto_np_arctan2_many(const double *y, const double *x, double *o, long n) {
+    if (!g_rcp14_ready) rcp14_init();
+    for (long i = 0; i < n; i++) o[i] = np_arctan2(y[i], x[i]);
+}
 RTO_API void rto_np_exp_many(const double *x, double *y, long n) { for (long i = 0; i < n; i++) y[i] = np_exp(x[i]); }
 
 /* ---- scenario fields: RT_bench.py:106-116 -------------------------------- */
@@ -335,6 +401,7 @@ RTO_API void rto_field_free(rto_field *f) {
 /* interpolacion(): RT_bench.py:435-464 (Hessian splines :459-462 are never read -> skipped) */
 RTO_API rto_field *rto_field_from_samples(const double *x, int qx, const double *y, int qy,
                                           const double *Z, double delta) {
+    if (!g_rcp14_ready) rcp14_init();           /* np_arctan2's table, before any (threaded) trace */
     rto_field *f = calloc(1, sizeof *f);
     size_t nz = (size_t)qx * qy;
     f->qx = qx; f->qy = qy;
@@ -501,8 +568,8 @@ static double ang_rk2(const rto_state *s, double step, double fn, double fgx, do
     return s->theta + (k1 + k2) / 2.0;
 }
 static double ang_cost(const rto_state *s, double step, double fgx, double fgy) { /* :407 */
-    return atan2(s->n * sin(s->theta) + impulse_t(s->gy, fgy, step),
-                 s->n * cos(s->theta) + impulse_t(s->gx, fgx, step));
+    return np_arctan2(s->n * sin(s->theta) + impulse_t(s->gy, fgy, step),
+                      s->n * cos(s->theta) + impulse_t(s->gx, fgx, step));
 }
 static double ang_golden_iso(const rto_state *s, double step, double fn, double fgx, double fgy) {
     iso_env e = { fn, s->n, s->ux, s->uy, impulse_t(s->gx, fgx, step), impulse_t(s->gy, fgy, step) };
@@ -540,7 +607,7 @@ static void op_step(const rto_ctx *c, const rto_state *s, double *fx, double *fy
     case 7: { /* :646-648 finite_diff :370-372 */
         double vx = 11 * *fx - 18 * s->hx[2] + 9 * s->hx[1] - 2 * s->hx[0];
         double vy = 11 * *fy - 18 * s->hy[2] + 9 * s->hy[1] - 2 * s->hy[0];
-        *fth = atan2(vy, vx);
+        *fth = np_arctan2(vy, vx);
         break;
     }
     }
@@ -634,7 +701,7 @@ RTO_API long rto_trazar(const rto_field *f, const rto_params *p, int R, const do
                 double vx, vy;
                 if (i == 1) { vx = fx - s.hx[2]; vy = fy - s.hy[2]; }               /* :843 */
                 else { vx = 3 * fx - 4 * s.hx[2] + s.hx[1]; vy = 3 * fy - 4 * s.hy[2] + s.hy[1]; } /* :856 */
-                fth = atan2(vy, vx);
+                fth = np_arctan2(vy, vx);
                 store_update(&c, &s, fx, fy, fth, fn, fgx, fgy);
                 write_row(p, s_ray, n_ray, R, k, i, &s);
             }

@@ -71,6 +71,7 @@ def lib(which=None):
         L.rto_max_threads.restype = C.c_int
         L.rto_set_field_solver.argtypes = [C.c_int]
         L.rto_np_exp_many.argtypes = [_dp, _dp, C.c_long]
+        L.rto_np_arctan2_many.argtypes = [_dp, _dp, _dp, C.c_long]
         _libs[which] = L
     return _libs[which]
 
@@ -93,6 +94,13 @@ def _p(a):
 
 def _f64(a):
     return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def np_arctan2(y, x):
+    """The oracle's restatement of numpy's float64 arctan2 (SVML __svml_atan28_ha), for tools/check_np_atan2.py."""
+    y = _f64(y); x = _f64(x); o = np.empty_like(x)
+    lib().rto_np_arctan2_many(_p(y), _p(x), _p(o), x.size)
+    return o
 
 
 class Field:

@@ -5,14 +5,15 @@
 // intermediate value can move a trajectory by 1e-8 .. 1e-6, so those methods do not use the
 // fused / reciprocal / uniform-knot forms of rt_device.h.  Everything here is written operation by operation like
 // the reference's scalar numpy code as restated in oracle/rt_oracle.c (same association, no contraction, IEEE
-// division and square root, libm-identical sin/cos from rt_libm.h), so that a ray's state is the SAME BITS as the
-// oracle's after every step (atan2, used by op4 only, is ocml's and within 1 ulp).  Reference lines are RT_bench.py.
+// division and square root, libm-identical sin/cos from rt_libm.h, numpy's SVML arctan2 restated in atan2_ below), so that
+// a ray's state is the SAME BITS as the oracle's after every step.  Reference lines are RT_bench.py.
 //
 // The golden-section search keeps the reference's comparison sequence without paying for 74 such cost evaluations
 // per step: see golden_filtered below.
 #pragma once
 #include "rt_libm.h"
 #include "rt_golden_rot.h"
+#include "rt_rcp14_table.h"
 
 namespace rt {
 namespace ex {
@@ -33,6 +34,53 @@ __device__ __attribute__((noinline)) double cos_(double x) {
     double s, c;
     sincos_k(x, &s, &c);
     return c;
+}
+// np.arctan2 as the reference's numpy evaluates it (AVX512_SKX builds: Intel SVML's __svml_atan28_ha; not libm's atan2 in the
+// last bit for 7 % of arguments) -- same text as oracle/rt_oracle.c np_arctan2, see there; tools/check_np_atan2.py: 0
+// mismatches against np.arctan2 on 1.6e7 argument pairs.  Its reciprocal starts from the VRCP14PD instruction, which is a
+// table of the operand's top 16 mantissa bits (rt_rcp14_table.h; decoded into g_rcp14 once per device by k_rcp14_init).
+__device__ unsigned short g_rcp14[65536];
+__device__ const unsigned long long kRcp14Words[RT_RCP14_WORDS] = {RT_RCP14_DELTAS};
+__device__ __forceinline__ double vrcp14pd(double x) {
+    const unsigned long long xb = __builtin_bit_cast(unsigned long long, x);
+    const unsigned long long e = (xb >> 52) & 0x7ffull, m = xb & 0xfffffffffffffull;
+    const unsigned long long rb = m == 0ull ? (0x7feull - e) << 52 : ((0x7fdull - e) << 52) | ((unsigned long long)g_rcp14[m >> 36] << 36);
+    return __builtin_bit_cast(double, rb);
+}
+__device__ __attribute__((noinline)) double atan2_(double y, double x) {
+    const double ax = __builtin_fabs(x), ay = __builtin_fabs(y);
+    const int ix = (int)((unsigned)(__builtin_bit_cast(unsigned long long, ax) >> 32) - 0x80300000u);
+    const int iy = (int)((unsigned)(__builtin_bit_cast(unsigned long long, ay) >> 32) - 0x80300000u);
+    if (ix >= (int)0xfdd00000u || iy >= (int)0xfdd00000u) return ::atan2(y, x);   // zeros, infinities, 2^-1020 > |.| or |.| >= 2^993
+    const bool k5 = 0.4375 * ax < ay, k1 = 0.6875 * ax < ay, k2 = 1.1875 * ax < ay, k3 = 2.4375 * ax < ay;
+    const double c = k2 ? (k3 ? 1.0 : 1.5) : (k1 ? 1.0 : 0.5);
+    const double ahi = k2 ? (k3 ? 0x1.921fb54442d18p+0 : 0x1.f730bd281f69bp-1) : (k1 ? 0x1.921fb54442d18p-1 : 0x1.dac670561bb4fp-2);
+    const double alo = k2 ? (k3 ? 0x1.1a62633145c07p-54 : 0x1.007887af0cbbdp-56) : (k1 ? 0x1.1a62633145c07p-55 : 0x1.a2b7f222f65e2p-56);
+    double den = k3 ? 0.0 : ax, num = k3 ? 0.0 : ay;
+    if (k5) { den = __builtin_fma(c, ay, den); num = __builtin_fma(-c, ax, num); }
+    double r = vrcp14pd(den);
+    double e = __builtin_fma(-r, den, 1.0);
+    r = __builtin_fma(e, r, r);
+    e = __builtin_fma(-r, den, 1.0);
+    r = __builtin_fma(e, r, r);
+    const double q = num * r, q2 = q * q;
+    const double res = __builtin_fma(-q, den, num);
+    const double q4 = q2 * q2;
+    double ql = res * r;
+    if (k5) ql = ql + alo;
+    double A = __builtin_fma(0x1.be4fbe6733718p-7, q4, 0x1.6ad5558fe19c9p-5), B = __builtin_fma(-0x1.04cd71f92185ep-5, q4, -0x1.a9e755ca13d23p-5);
+    A = __builtin_fma(q4, A, 0x1.e12f1edf7c393p-5);  B = __builtin_fma(q4, B, -0x1.1108d326c68edp-4);
+    A = __builtin_fma(q4, A, 0x1.3b132b731e73ap-4);  B = __builtin_fma(q4, B, -0x1.745d119677a4fp-4);
+    A = __builtin_fma(q4, A, 0x1.c71c719f99f96p-4);  B = __builtin_fma(q4, B, -0x1.2492492441a21p-3);
+    A = __builtin_fma(q4, A, 0x1.9999999998f43p-3);  B = __builtin_fma(q4, B, -0x1.5555555555552p-2);
+    double t = __builtin_fma(q2, A, B) * q2;
+    const bool xneg = x < 0.0;
+    if (xneg) ql = ql - 0x1.1a64000000000p-53;
+    t = __builtin_fma(q, t, ql);
+    double s = q + t;
+    if (k5) s = s + ahi;
+    if (xneg) s = -s + 0x1.921fb54442d18p+1;
+    return __builtin_copysign(s, y);
 }
 __device__ __forceinline__ double sqrt_(double x) { return __dsqrt_rn(x); }            // correctly rounded
 __device__ __forceinline__ double sq(double x) { return x * x; }                        // oracle SQ()
@@ -163,7 +211,7 @@ __device__ __forceinline__ double ang_rk2(const Ray<double>& r, double step, dou
     return r.th + (k1 + k2) / 2.0;
 }
 __device__ __forceinline__ double ang_cost(const Ray<double>& r, double step, double fgx, double fgy) {
-    return ::atan2(r.n * r.uy + impulse(r.gy, fgy, step), r.n * r.ux + impulse(r.gx, fgx, step));
+    return atan2_(r.n * r.uy + impulse(r.gy, fgy, step), r.n * r.ux + impulse(r.gx, fgx, step));
 }
 
 // ---------------------------------------------------------------- golden() (:175-199), filtered  (anisotropic cost)
@@ -476,7 +524,7 @@ __device__ __forceinline__ double op_angle(const Consts<double>& k, const Ray<do
         if (i == 1) { vx = fx - r.x; vy = fy - r.y; }
         else if (i == 2) { vx = 3.0 * fx - 4.0 * r.x + r.hx1; vy = 3.0 * fy - 4.0 * r.y + r.hy1; }
         else { vx = 11.0 * fx - 18.0 * r.x + 9.0 * r.hx1 - 2.0 * r.hx0; vy = 11.0 * fy - 18.0 * r.y + 9.0 * r.hy1 - 2.0 * r.hy0; }
-        return ::atan2(vy, vx);
+        return atan2_(vy, vx);
     }
     else if constexpr (METHOD == 3) return flag ? ex::ang_rk2(r, k.step, fn, fgx, fgy) : r.th;
     else if constexpr (METHOD == 4) return flag ? ex::ang_cost(r, k.step, fgx, fgy) : r.th;

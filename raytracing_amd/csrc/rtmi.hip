@@ -1232,6 +1232,25 @@ template <typename T> static const void* refill_fn(int ki, bool iso, bool lds) {
 #undef RTMI_ADVVAR_
 #undef RTMI_REFILL_
 #undef RTMI_ALL16_
+// VRCP14PD's table (rt_rcp14_table.h) decoded once per device, for rt::ex::atan2_
+__global__ void k_rcp14_init() {
+    unsigned short v = RT_RCP14_T0;
+    for (int k = 0; k < 65536; k++) {
+        v = (unsigned short)(v - (unsigned short)((rt::ex::kRcp14Words[k >> 5] >> (2 * (k & 31))) & 3ull));
+        rt::ex::g_rcp14[k] = v;
+    }
+}
+static int ensure_rcp14_table(hipStream_t st) {
+    static bool done[64] = {false};
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && done[dev]) return RTMI_OK;
+    hipLaunchKernelGGL(k_rcp14_init, dim3(1), dim3(1), 0, st);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    if (dev >= 0 && dev < 64) done[dev] = true;
+    return RTMI_OK;
+}
 // the fp64 batch runs rt_exact.h's arithmetic: always for op3/4/5/9/10/11, for the others when reference_order is set
 static bool batch_exact(const rtmi_batch* b) { return b->p.dtype == RTMI_F64 && (rt::is_exact_method(b->p.method) || b->p.reference_order); }
 static int batch_kernel_index(const rtmi_batch* b) { return kernel_index(b->p.method, b->p.dtype == RTMI_F64 && b->p.reference_order); }
@@ -1359,6 +1378,10 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     if (!b) return fail(RTMI_ERR_ALLOC, "rtmi_batch_create: host allocation failed");
     b->field = f; b->p = *p; b->R = R; b->esz = p->dtype == RTMI_F64 ? 8 : 4; b->stream = (hipStream_t)stream;
     if (p->method >= 10) gold_sup_derivatives(p->gamma_step, b->gold_sup);
+    if (batch_exact(b) && (p->method == 1 || p->method == 4 || p->method == 7 || p->method == 8)) {   // they call rt::ex::atan2_
+        const int rct = ensure_rcp14_table(b->stream);
+        if (rct) { delete b; return rct; }
+    }
     if (b->p.record_stride > 0 && b->p.rec_rows <= 0)
         b->p.rec_rows = ((int64_t)p->max_size + p->record_stride - 1) / p->record_stride;
     if (b->p.record_stride == 0) b->p.rec_rows = 0;

@@ -145,11 +145,9 @@ def test_trajectory_vs_reference(name, scen, m, rb, gpu_fields):
     b.close()
     assert s.shape == (int(t["max_size"]), 6, len(th))
     strided, last = sub_rows(s, d, int(t["stride"]))
-    # every ray of every method, golden-section and curvature ones included (north star: 1e-9 on every ray): the field is
-    # the reference's bits (numpy's SVML exp and FITPACK's Givens QR restated).  One exception: interface x op4, whose angle
-    # comes from atan2 (numpy's is SVML's, not restated; ocml's is within an ulp of it) and whose curvature advancement
-    # amplifies such last-bit differences to <= 2e-7 (tests/test_gpu_exact.py::test_interface_curvature_conditioning).
-    tol = 2e-6 if scen == "interface" and m == 4 else REL
+    # every ray of every method (north star: 1e-9 on every ray): the field is the reference's bits, op3/4/5/9/10/11 run in its
+    # operation order with numpy's own exp / arctan2 / sin / cos restated (<= 3e-17 here); op1/2/6/7/8 in fused forms (~1e-13)
+    tol = REL
     if scen == "interface" and m == 7:
         # op7's angle is the atan2 of a 4-point difference of POSITIONS: their last bits, divided by 6*DELTA_S, enter the angle
         # (2e-12 per step), and the interface amplifies the random walk of 4 000 such steps to ~1e-9.  The fused default lands
@@ -944,14 +942,12 @@ def test_random_rays_through_grid_ends_vs_oracle(scen, m, rb, gpu_fields, oracle
     assert same.mean() > 0.99                        # a ray grazing the rim may leave one step apart
     err = np.abs(fin[:, same] - o["final"][:, same]) / np.maximum(np.abs(o["final"][:, same]), 1.0)
     print(f"{scen} op{m}: {same.sum()}/{R} same step count, max rel err {err.max():.2e}")
-    if m in (3, 5, 9, 10, 11):
+    if m in (3, 4, 5, 9, 10, 11):
         # reference-order methods on a field whose coefficients are the oracle's bits (all scenarios): every ray bit-identical
         assert same.all() and np.array_equal(fin, o["final"])
         return
-    # op7 differentiates positions (roundoff / step).  interface x op4: ocml's atan2 against libm's (within an ulp of each
-    # other) under the curvature advancement's amplification (RT_bench.py:361-363) -- random rays spend longer on the flat
-    # flanks of the sigmoid than the reference's fan does (tests/test_gpu_exact.py::test_interface_curvature_conditioning)
-    tol = 1e-7 if m == 7 else (2e-5 if m == 4 and scen == "interface" else REL)
+    # op7 differentiates positions (roundoff / step)
+    tol = 1e-7 if m == 7 else REL
     assert err.max() < tol
 
 

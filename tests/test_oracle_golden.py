@@ -78,16 +78,13 @@ def test_single_step_matches_reference(m, oracle_fields):
     F = oracle_fields("vert_heterogeneous")
     out = O.single_step(F, m, 3 if m >= 10 else 1, float(g["step"]), g[f"st{m}"], g[f"hist{m}"])
     ref = g[f"out{m}"]
-    # np.arctan2 (op1/4/7/8) and numpy's pow differ from libm by <= 1 ulp; everything else is bit-exact
+    # numpy's scalar pow differs from x*x by <= 1 ulp; everything else is bit-exact
     assert np.max(np.abs(out - ref) / np.maximum(np.abs(ref), 1e-3)) < 2e-15
-    if m not in (1, 4, 7, 8):
+    if True:
         with O.variant("pow"):
             Fp = O.Field("vert_heterogeneous", LIMITS["vert_heterogeneous"], float(golden("constants")["DELTA"]))
             outp = O.single_step(Fp, m, 3 if m >= 10 else 1, float(g["step"]), g[f"st{m}"], g[f"hist{m}"])
         assert np.array_equal(outp, ref)          # the reference-faithful build: its bits
-
-
-ATAN2_METHODS = (1, 4, 7, 8)     # np.arctan2 is SVML's __svml_atan28 on the fixture host: not libm's atan2 in the last bit
 
 
 @pytest.fixture(scope="module")
@@ -107,13 +104,12 @@ def pow_fields(consts):
 @pytest.mark.parametrize("build", ["default", "pow"])
 @pytest.mark.parametrize("name,scen,m", traj_fixtures())
 def test_trajectory_matches_reference(name, scen, m, build, oracle_fields, pow_fields):
-    """Every trajectory fixture captured from the reference, with both builds of the oracle.
-    Methods without atan2 (op2/3/5/6/9/10/11), all four scenarios, interface x curvature included:
-      * "pow" build (squares like numpy's scalar x**2): the reference's BITS -- every recorded row, d_ray, step counts;
-      * "default" build (x*x, what the device reproduces): <= 1e-15 (measured: 0 on 16 of 18 fixtures, 2.8e-17 on the two
-        anisotropy ones) -- the whole cost of that deviation.
-    op1/4/7/8 call np.arctan2 = SVML's atan2 (not restated): 1e-12 (op7 differentiates positions: 1e-10); on the interface
-    sigmoid curvature_t (:361-363) amplifies op4's last-bit angle differences to 2e-7 (tolerance 2e-6)."""
+    """Every trajectory fixture captured from the reference -- all 11 methods, all four scenarios, 31 fixtures -- with both
+    builds of the oracle:
+      * "pow" build (squares like numpy's scalar x**2): the reference's BITS -- every recorded row, d_ray, step counts -- on
+        every fixture (numpy's SVML exp and arctan2, FITPACK's Givens QR, glibc's sin/cos are all restated);
+      * "default" build (x*x, what the device reproduces): <= 1e-15 (measured: 0 on 27 fixtures, <= 2.2e-16 on four) -- the
+        whole cost of that one deviation."""
     t = golden("traj_" + name)
     F = (pow_fields if build == "pow" else oracle_fields)(scen)
     x0, y0, th = traj_inputs(t, scen)
@@ -122,16 +118,29 @@ def test_trajectory_matches_reference(name, scen, m, build, oracle_fields, pow_f
     assert r["s_ray"].shape == (int(t["max_size"]), 6, len(th))
     assert np.array_equal(r["d_ray"][2], t["d_ray"][2]), "last written row per ray"
     strided, last = sub_rows(r["s_ray"], r["d_ray"], int(t["stride"]))
-    if m not in ATAN2_METHODS and build == "pow":
+    if build == "pow":
         assert np.array_equal(strided, t["strided"]) and np.array_equal(last, t["last"]) and np.array_equal(r["d_ray"], t["d_ray"])
     else:
-        tol = 1e-15 if m not in ATAN2_METHODS else (1e-10 if m == 7 else 2e-6 if (scen == "interface" and m == 4) else 1e-12)
-        assert np.abs(strided - t["strided"]).max() < tol
-        assert np.abs(last - t["last"]).max() < tol
-        assert np.abs(r["d_ray"][:2] - t["d_ray"][:2]).max() < max(tol, 1e-12)
+        assert np.abs(strided - t["strided"]).max() < 1e-15 and np.abs(last - t["last"]).max() < 1e-15
+        assert np.abs(r["d_ray"][:2] - t["d_ray"][:2]).max() < 1e-12
     # rows after termination stay zero (Q7)
     k = int(np.argmin(r["d_ray"][2])); i = int(r["d_ray"][2, k])
     assert i + 1 >= r["s_ray"].shape[0] or not r["s_ray"][i + 1:, :, k].any()
+
+
+def test_np_arctan2_restatement_equals_numpy_here():
+    """np_arctan2 (rt_oracle.c: SVML __svml_atan28_ha with VRCP14PD as a table) against this host's np.arctan2, bit for bit --
+    where numpy dispatches to SVML (AVX512_SKX, as in the container the fixtures were made in)."""
+    from numpy._core._multiarray_umath import __cpu_features__ as feat
+    if not feat.get("AVX512_SKX"):
+        pytest.skip("numpy does not use SVML's arctan2 on this CPU")
+    rng = np.random.default_rng(12)
+    N = 500_000
+    y = np.concatenate([rng.normal(0, 1, N), rng.uniform(-0.1, 0.1, N), rng.normal(0, 1, N) * 10.0 ** rng.uniform(-30, 30, N),
+                        [0.0, -0.0, 1.0, -1.0, 0.0, np.inf]])
+    x = np.concatenate([rng.normal(0, 1, N), rng.normal(0, 1, N), rng.normal(0, 1, N) * 10.0 ** rng.uniform(-30, 30, N),
+                        [1.0, -1.0, 0.0, 0.0, 0.0, -np.inf]])
+    assert np.array_equal(O.np_arctan2(y, x).view(np.uint64), np.arctan2(y, x).view(np.uint64))
 
 
 def test_reference_anchor_values(oracle_fields):
