@@ -121,8 +121,8 @@ typedef struct {
                                 slices are 4 and 2 times as long */
     int32_t reference_order; /* 0 (default): op1/2/6/7/8 step in fused forms (~1e-13 from the reference per trajectory; op7, which
                                 differentiates positions, up to ~1e-9 on the interface scenario); 1 (fp64 only): they too run in the
-                                reference's own operation order, like op3/4/5/9/10/11 always do -- op2/op6 then give the reference's
-                                bits, op1/7/8 differ from it by their atan2 alone (numpy's is SVML's) -- at about a third of the speed */
+                                reference's own operation order, like op3/4/5/9/10/11 always do -- all five then give the
+                                reference's bits (numpy's arctan2 = SVML's is restated for op1/7/8) -- at about a quarter of the speed */
 } rtmi_params;
 
 /* Upload R launch conditions (host pointers; x0/y0 per ray -- pos_x[k], -2 or the fisheye start, :809-813),
