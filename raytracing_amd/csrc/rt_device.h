@@ -4,6 +4,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "rt_polytab.h"
+
+#ifndef RTMI_POLY
+#define RTMI_POLY 1     // 1: the fast-form step methods look the field up as one polynomial per cell (PolyGather); 0: B-spline sums
+#endif
+
 namespace rt {
 
 // The library is compiled with -ffp-contract=off: every fusion below is an explicit fma(), so a value is
@@ -172,6 +178,10 @@ template <typename T> struct FieldDev {
     T ax, hx, bx, inv_hx;
     T ay, hy, by, inv_hy;
     int exact;   // 1: FITPACK's arithmetic with true knots in every cell (see axis_eval)
+    // poly: [(qy-1)*(qx-1)][kPolyStride] the same three splines as one polynomial per grid cell (rt_polytab.h) -- what the
+    // fast-form step methods evaluate (PolyGather below); zn / g serve the reference-order methods and rtmi_field_eval
+    const T* poly;
+    int ncx;     // cells per grid row, qx - 1
 };
 
 // Rare branches of the step loop (a lookup near the grid's rim, re-staging the LDS tile, a lane falling back to a global
@@ -640,11 +650,18 @@ template <typename T, int PHASES = RTMI_TILE_PHASES> struct LdsGather {
 
 // n_gradient(vector, grd, z) (:141-156): bilinear n, bicubic dn/dx and dn/dy at (x, y) -> (n, [gx, gy]).
 // `active` tells the gather policy whether this lane's lookup matters (idle lanes still execute it).
+template <typename G> struct IsPoly { static constexpr bool value = false; };
+template <typename T, bool S> struct PolyGather;
+template <typename T, bool S> struct IsPoly<PolyGather<T, S>> { static constexpr bool value = true; };
 template <typename T, typename G>
 __device__ __forceinline__ void n_gradient(const FieldDev<T>& F, G& gather, bool active, T x, T y, T& n, T& gx, T& gy) {
-    Cell<T> c;
-    field_locate(F, x, y, c);
-    gather.lookup(F, c, active, n, gx, gy);
+    if constexpr (IsPoly<G>::value) {
+        gather.lookup_xy(F, active, x, y, n, gx, gy);
+    } else {
+        Cell<T> c;
+        field_locate(F, x, y, c);
+        gather.lookup(F, c, active, n, gx, gy);
+    }
 }
 template <typename T>
 __device__ __forceinline__ void GlobalGather<T>::lookup(const FieldDev<T>& F, const Cell<T>& c, bool active, T& n, T& gx, T& gy) {
@@ -655,6 +672,165 @@ __device__ __forceinline__ void GlobalGather<T>::lookup(const FieldDev<T>& F, co
     cc.jx = active ? c.jx : 0; cc.jy = active ? c.jy : 0; cc.lx = active ? c.lx : 3; cc.ly = active ? c.ly : 3;
     lookup_global_rows<T, RTMI_GLOBAL_PHASES>(F, cc, n, gx, gy);
 }
+
+// ---------------------------------------------------------------- the field as one polynomial per cell (rt_polytab.h)
+// Where a lookup lands: the cell and the position in it.  u = (x - a)*inv_h - j with the product taken EXACTLY (fma): the
+// table's polynomials are written in precisely this coordinate (poly_axis_build inverts the same map), so u carries one
+// rounding and the lookup agrees with FITPACK's evaluation to < 1e-15 of the field's scale in every cell of the grid, the
+// not-a-knot end cells included (tests/test_polytab_host.py) -- there is no rim case.  What is left of the old one is
+// FITPACK's argument clamp (quirk Q4) for a point outside the grid: per lane, behind a wave vote that only picks the layout.
+template <typename T> struct PolyCell { int cell; T u, v; };
+template <typename T> __device__ __forceinline__ void poly_axis(T x, T a, T b, T inv_h, int ncell, bool& in, T& xa, T& jf, int& j) {
+    xa = x - a;
+    jf = floor_(xa * inv_h);
+    j = (int)jf;
+    in = (unsigned)j < (unsigned)ncell;           // NaN converts to 0: "in", and the NaN flows through u
+}
+template <typename T> __device__ __forceinline__ void poly_axis_clamped(T x, T a, T b, T inv_h, int ncell, T& xa, T& jf, int& j) {
+    x = x < a ? a : x;
+    x = x > b ? b : x;
+    xa = x - a;
+    jf = floor_(xa * inv_h);
+    jf = jf < T(0) ? T(0) : (jf > (T)(ncell - 1) ? (T)(ncell - 1) : jf);
+    j = (int)jf;
+}
+template <typename T> __device__ __forceinline__ void poly_locate(const FieldDev<T>& F, T x, T y, bool active, PolyCell<T>& c) {
+    bool inx, iny;
+    T xa, ya, jfx, jfy;
+    int jx, jy;
+    poly_axis(x, F.ax, F.bx, F.inv_hx, F.ncx, inx, xa, jfx, jx);
+    poly_axis(y, F.ay, F.by, F.inv_hy, F.qy - 1, iny, ya, jfy, jy);
+    // an idle lane (a terminated ray's stale state drifts out of the grid) never addresses the table with its cell: no clamp
+    inx = inx || !active; iny = iny || !active;
+    if (__ballot(!(inx && iny)) != 0ull) {
+        const FieldDev<T> G = rare_field(F);
+        if (!inx) poly_axis_clamped(x, G.ax, G.bx, G.inv_hx, G.ncx, xa, jfx, jx);
+        if (!iny) poly_axis_clamped(y, G.ay, G.by, G.inv_hy, G.qy - 1, ya, jfy, jy);
+    }
+    c.u = fma_(xa, F.inv_hx, -jfx);
+    c.v = fma_(ya, F.inv_hy, -jfy);
+    c.cell = jy * F.ncx + jx;                     // < 2^31 cells (field_alloc)
+}
+
+// Horner in u for the four rows, then in v.  ROW(k) yields row k's four coefficients; with a wave-uniform cell they sit in
+// scalar registers and every fma below reads one of them as its scalar operand.
+template <typename T> using Quad = T __attribute__((ext_vector_type(4)));
+// a*u + c with a and c in SCALAR registers (a wave-uniform cell's coefficients), u per lane.  A vector instruction reads at
+// most one scalar operand on gfx9, so c is copied to a vector register first; left to the compiler every scalar addend of
+// the Horner chain is copied (it selects the two-address v_fmac, 26 copies per lookup) -- hence the explicit forms.
+__device__ __forceinline__ double fma_sus(double a, double u, double c) {
+    double t, d;
+    asm("v_mov_b64 %0, %1" : "=v"(t) : "s"(c));
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "s"(a), "v"(u), "v"(t));
+    return d;
+}
+__device__ __forceinline__ float fma_sus(float a, float u, float c) {
+    float t, d;
+    asm("v_mov_b32 %0, %1" : "=v"(t) : "s"(c));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "s"(a), "v"(u), "v"(t));
+    return d;
+}
+// a*u + c with only the addend c in scalar registers: the three-address form, no copy
+__device__ __forceinline__ double fma_vus(double a, double u, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(u), "s"(c));
+    return d;
+}
+__device__ __forceinline__ float fma_vus(float a, float u, float c) {
+    float d;
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(u), "s"(c));
+    return d;
+}
+// Horner in u for one row.  SC: the coefficients are scalar-register values.  Same operations either way: same bits.
+template <typename T, bool SC> __device__ __forceinline__ T poly_row(Quad<T> a, T u) {
+    if constexpr (SC) return fma_vus(fma_vus(fma_sus(a.w, u, a.z), u, a.y), u, a.x);
+    else return fma_(fma_(fma_(a.w, u, a.z), u, a.y), u, a.x);
+}
+template <typename T, bool SC, typename ROW> __device__ __forceinline__ T poly_bicubic(ROW row, int base, T u, T v) {
+    const T r3 = poly_row<T, SC>(row(base + 3), u), r2 = poly_row<T, SC>(row(base + 2), u);
+    const T r1 = poly_row<T, SC>(row(base + 1), u), r0 = poly_row<T, SC>(row(base), u);
+    return fma_(fma_(fma_(r3, v, r2), v, r1), v, r0);
+}
+template <typename T, bool SC> __device__ __forceinline__ T poly_bilinear(Quad<T> b, T u, T v) {
+    if constexpr (SC) return fma_(fma_sus(b.w, u, b.z), v, fma_sus(b.y, u, b.x));
+    else return fma_(fma_(b.w, u, b.z), v, fma_(b.y, u, b.x));
+}
+
+// Gather policy 3 (the fast-form step methods): the cell's polynomial.
+//   SCALAR: the wave's live lanes are asked for their cell; the lanes in the first live lane's cell evaluate with that cell's
+//   36 coefficients read through the scalar cache into SGPRs (5 s_load per lookup, no vector register, no LDS), the rest go
+//   round once more, and whoever is still left after two rounds -- an incoherent wave: shuffled or random rays -- reads its
+//   own cell with vector loads.  A fan's wave sits in ONE cell on 98 % of its steps (64 neighbouring rays of 1 M span 4 % of
+//   a cell) and in two on the rest.
+//   !SCALAR: every lane reads its own cell with vector loads (two rows in flight): the per-ray-DELTA_S sweep, field_path 1.
+// The arithmetic is poly_bicubic / poly_bilinear on the same numbers either way: the result does not depend on the policy,
+// on the wave mates or on which round served the lane.
+template <typename T, bool SCALAR> struct PolyGather {
+    static constexpr bool kPoly = true;
+    typedef const Quad<T> __attribute__((address_space(4)))* ScalarRows;
+    static __device__ __forceinline__ void eval_scalar(ScalarRows p, T u, T v, T& n, T& gx, T& gy) {
+        auto row = [&](int k) -> Quad<T> { return p[k]; };
+        gx = poly_bicubic<T, true>(row, 0, u, v);
+        gy = poly_bicubic<T, true>(row, 4, u, v);
+        n = poly_bilinear<T, true>(p[8], u, v);
+    }
+    static __device__ __forceinline__ void eval_lane(const FieldDev<T>& F, int cell, T u, T v, T& n, T& gx, T& gy) {
+        const Quad<T>* p = reinterpret_cast<const Quad<T>*>(F.poly + (size_t)cell * kPolyStride);
+        T g[2];
+#pragma unroll
+        for (int s = 0; s < 2; s++) {
+            // two rows in flight (16 VGPRs in fp64), the next two behind their sums: this path must not set the register count
+            Quad<T> a3 = p[4 * s + 3], a2 = p[4 * s + 2];
+            T r3 = poly_row<T, false>(a3, u), r2 = poly_row<T, false>(a2, u);
+            asm volatile("" : "+v"(r3), "+v"(r2) : : "memory");
+            Quad<T> a1 = p[4 * s + 1], a0 = p[4 * s];
+            T r1 = poly_row<T, false>(a1, u), r0 = poly_row<T, false>(a0, u);
+            g[s] = fma_(fma_(fma_(r3, v, r2), v, r1), v, r0);
+            asm volatile("" : "+v"(g[s]) : : "memory");
+        }
+        gx = g[0]; gy = g[1];
+        n = poly_bilinear<T, false>(p[8], u, v);
+    }
+    __device__ __forceinline__ void lookup_xy(const FieldDev<T>& F, bool active, T x, T y, T& n, T& gx, T& gy) {
+        PolyCell<T> c;
+        poly_locate(F, x, y, active, c);
+        if constexpr (SCALAR) {
+            // the first live lane's cell; when every live lane is in it (98 % of a fan's wave-steps) all lanes evaluate its
+            // polynomial in straight-line code -- an idle lane too, at its own (u, v) in [0, 1)^2: finite, and nobody reads it
+            const unsigned long long live = __ballot(active);
+            const int first = live ? __builtin_ctzll(live) : 0;
+            int cu = __builtin_amdgcn_readlane(c.cell, first);
+            // the entry's address is formed from the scalar and pinned to scalar registers BEFORE any comparison with the
+            // per-lane cell: inside "cell == cu" the compiler would otherwise substitute the lane's value and load per lane
+            ScalarRows p = (ScalarRows)(F.poly + (size_t)cu * kPolyStride);
+            asm volatile("" : "+s"(p));
+            if (__ballot(active && c.cell != cu) == 0ull) {
+                eval_scalar(p, c.u, c.v, n, gx, gy);
+                return;
+            }
+            // a wave in several cells: two rounds of "the first waiting lane's cell", then per-lane loads for whoever is left
+            n = T(1); gx = T(0); gy = T(0);
+            bool todo = active;
+#pragma nounroll
+            for (int round = 0; round < 2; ++round) {
+                if (__ballot(todo) == 0ull) break;
+                if (todo) {
+                    cu = __builtin_amdgcn_readfirstlane(c.cell);
+                    p = (ScalarRows)(F.poly + (size_t)cu * kPolyStride);
+                    asm volatile("" : "+s"(p));
+                    if (c.cell == cu) {
+                        eval_scalar(p, c.u, c.v, n, gx, gy);
+                        todo = false;
+                    }
+                }
+            }
+            if (todo) eval_lane(F, c.cell, c.u, c.v, n, gx, gy);
+        } else {
+            n = T(1); gx = T(0); gy = T(0);          // what an idle lane steps on with (finite; nobody reads its state)
+            if (active) eval_lane(F, c.cell, c.u, c.v, n, gx, gy);
+        }
+    }
+};
 
 // ---------------------------------------------------------------- per-ray state
 // The six quantities a ray ACCUMULATES over thousands of steps -- position, angle, the two arclengths, traveltime --

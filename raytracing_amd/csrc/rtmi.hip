@@ -91,6 +91,7 @@ struct rtmi_field {
     double *dZ = nullptr, *dCdy = nullptr, *dCdx = nullptr;
     // packed, dtype-typed arrays the trace kernels gather from
     void *zn = nullptr, *g = nullptr;
+    void* poly = nullptr;        // [(qy-1)*(qx-1)][rt::kPolyStride] of dtype: one polynomial per cell (rt_polytab.h)
     hipStream_t stream = nullptr;
 };
 
@@ -123,6 +124,8 @@ template <typename T> static rt::FieldDev<T> field_dev(const rtmi_field* f, int 
     F.inv_hx = (T)(1.0 / f->hx);
     F.ay = (T)f->ay; F.hy = (T)f->hy; F.by = (T)f->by;
     F.inv_hy = (T)(1.0 / f->hy);
+    F.poly = (const T*)f->poly;
+    F.ncx = f->qx - 1;
     return F;
 }
 
@@ -265,6 +268,19 @@ template <typename T> __global__ void k_pack(const double* Z, const double* cdy,
     g[2 * i + 1] = (T)cdy[i];  // d/dy spline = grd[0] (:155)
 }
 
+// The per-cell polynomial table (rt_polytab.h): one thread per cell, fp64 conversion, stored in the field's dtype.
+template <typename T>
+__global__ void k_polytab(const double* Z, const double* cdx, const double* cdy, int qx, int qy, const double* Cx, const double* Lx,
+                          const double* Cy, const double* Ly, T* out) {
+    const int jx = blockIdx.x * blockDim.x + threadIdx.x, jy = blockIdx.y;
+    if (jx >= qx - 1 || jy >= qy - 1) return;
+    double c[36];
+    rt::poly_cell_convert(Z, cdx, cdy, qx, qy, jx, jy, Cx, Lx, Cy, Ly, c);
+    T* o = out + ((size_t)jy * (qx - 1) + jx) * rt::kPolyStride;
+    for (int i = 0; i < 36; i++) o[i] = (T)c[i];
+    for (int i = 36; i < rt::kPolyStride; i++) o[i] = T(0);
+}
+
 template <typename T>
 __global__ void k_field_eval(rt::FieldDev<T> F, long npts, const double* x, const double* y, double* n, double* gx,
                              double* gy) {
@@ -354,6 +370,7 @@ static int field_finish_impl(rtmi_field* f, double delta) {
     const FpAxis AY = fp_axis_build(linspace(f->ay, f->by, qy));
     double* dlux = nullptr;     // rotations + triangles of both axes, then the work matrix g
     double* dluy = nullptr;
+    double* dpoly = nullptr;    // per-axis tables of the cell polynomials
     auto solve_and_pack = [&]() -> int {   // dlux/dluy are released below whatever this returns
         const size_t nax = (size_t)qx * 12, nay = (size_t)qy * 12;                 // cs [m][8] + a [m][4]
         HIP_TRY(hipMalloc(&dlux, (nax + nay) * sizeof(double) + (size_t)(qx + qy) * sizeof(int)));
@@ -386,6 +403,30 @@ static int field_finish_impl(rtmi_field* f, double delta) {
             hipLaunchKernelGGL(k_pack<float>, dim3((nz + 255) / 256), dim3(256), 0, st, f->dZ, f->dCdy, f->dCdx,
                                (float*)f->zn, (float*)f->g, nz);
         HIP_TRY(hipGetLastError());
+        // one polynomial per cell for the fast-form lookups: per-axis basis tables on the host (long double), cells on the device
+        {
+            const double ihx = (double)(f->dtype == RTMI_F64 ? 1.0 / f->hx : (double)(float)(1.0 / f->hx));
+            const double ihy = (double)(f->dtype == RTMI_F64 ? 1.0 / f->hy : (double)(float)(1.0 / f->hy));
+            const bool f64 = f->dtype == RTMI_F64;
+            const rt::PolyAxis PX = rt::poly_axis_build(linspace(f->ax, f->bx, qx), f64 ? f->ax : (double)(float)f->ax, ihx);
+            const rt::PolyAxis PY = rt::poly_axis_build(linspace(f->ay, f->by, qy), f64 ? f->ay : (double)(float)f->ay, ihy);
+            const size_t ncell = (size_t)(qx - 1) * (qy - 1);
+            const size_t nax2 = (size_t)(qx - 1) * 20, nay2 = (size_t)(qy - 1) * 20;
+            HIP_TRY(hipMalloc(&dpoly, (nax2 + nay2) * sizeof(double)));
+            double *dCx = dpoly, *dLx = dpoly + (size_t)(qx - 1) * 16, *dCy = dpoly + nax2, *dLy = dCy + (size_t)(qy - 1) * 16;
+            HIP_TRY(hipMemcpyAsync(dCx, PX.C.data(), PX.C.size() * sizeof(double), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(dLx, PX.L.data(), PX.L.size() * sizeof(double), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(dCy, PY.C.data(), PY.C.size() * sizeof(double), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(dLy, PY.L.data(), PY.L.size() * sizeof(double), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMalloc(&f->poly, ncell * rt::kPolyStride * esz));
+            const dim3 pg((qx - 1 + 63) / 64, qy - 1), pb(64);
+            if (f->dtype == RTMI_F64)
+                hipLaunchKernelGGL(k_polytab<double>, pg, pb, 0, st, f->dZ, f->dCdx, f->dCdy, qx, qy, dCx, dLx, dCy, dLy, (double*)f->poly);
+            else
+                hipLaunchKernelGGL(k_polytab<float>, pg, pb, 0, st, f->dZ, f->dCdx, f->dCdy, qx, qy, dCx, dLx, dCy, dLy, (float*)f->poly);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(st));  // the host tables go out of scope
+        }
         HIP_TRY(hipStreamSynchronize(st));  // host vectors / LU buffers go out of scope
         return RTMI_OK;
     };
@@ -393,6 +434,7 @@ static int field_finish_impl(rtmi_field* f, double delta) {
     if (rc) (void)hipStreamSynchronize(st);   // nothing may still read the LU buffers
     (void)hipFree(dlux);
     (void)hipFree(dluy);
+    (void)hipFree(dpoly);
     return rc;
 }
 
@@ -419,6 +461,7 @@ RTMI_EXPORT int rtmi_device_count(int* count) {
 RTMI_EXPORT void rtmi_field_destroy(rtmi_field* f) {
     if (!f) return;
     (void)hipFree(f->dZ); (void)hipFree(f->dCdy); (void)hipFree(f->dCdx); (void)hipFree(f->zn); (void)hipFree(f->g);
+    (void)hipFree(f->poly);
     delete f;
 }
 
@@ -578,13 +621,18 @@ template <> __device__ __forceinline__ void derive_rt<double>(const BatchDev<dou
     else if (a.iso) rt::derive<double, true>(a.K, r);
     else rt::derive<double, false>(a.K, r);
 }
+#if RTMI_POLY
+template <typename T> using InitGather = rt::PolyGather<T, false>;     // the fast forms' lookup, one lane per ray
+#else
+template <typename T> using InitGather = rt::GlobalGather<T>;
+#endif
 template <typename T> __device__ __forceinline__ void n_gradient_rt(const BatchDev<T>& a, T x, T y, T& n, T& gx, T& gy) {
-    rt::GlobalGather<T> gg;
+    InitGather<T> gg;
     rt::n_gradient(a.F, gg, true, x, y, n, gx, gy);
 }
 template <> __device__ __forceinline__ void n_gradient_rt<double>(const BatchDev<double>& a, double x, double y, double& n, double& gx, double& gy) {
-    rt::GlobalGather<double> gg;
-    if (a.exact) rt::ex::n_gradient(a.F, gg, true, x, y, n, gx, gy); else rt::n_gradient(a.F, gg, true, x, y, n, gx, gy);
+    if (a.exact) { rt::GlobalGather<double> gg; rt::ex::n_gradient(a.F, gg, true, x, y, n, gx, gy); }
+    else { InitGather<double> gg; rt::n_gradient(a.F, gg, true, x, y, n, gx, gy); }
 }
 
 // initial conditions (:809-826): one lane per ray
@@ -678,9 +726,16 @@ template <typename T> __device__ __forceinline__ void idle_ray(const BatchDev<T>
     r.hx0 = r.hx1 = r.x; r.hy0 = r.hy1 = r.y;
 }
 
-template <typename T, bool LDS, int PH = RTMI_TILE_PHASES> struct GatherOf { using type = rt::GlobalGather<T>; };
-template <typename T, int PH> struct GatherOf<T, true, PH> { using type = rt::LdsGather<T, PH>; };
+// Gather policy of a step kernel.  Reference-order methods (rt_exact.h: FITPACK's sums on the B-spline window): the LDS tile
+// (LDS) or global gathers.  Fast-form methods and every fp32 batch: the cell's polynomial (rt::PolyGather), through the scalar
+// cache for a coherent wave (LDS) or with per-lane loads.  RTMI_POLY 0 builds the fast forms on the B-spline window as well.
+template <typename T, int METHOD> constexpr bool uses_poly() { return RTMI_POLY && !rt::IsExact<T, METHOD>::value; }
+template <typename T, int METHOD, bool LDS> constexpr bool uses_tile() { return LDS && !uses_poly<T, METHOD>(); }
+template <typename T, int METHOD, bool LDS, int PH = RTMI_TILE_PHASES, bool POLY = uses_poly<T, METHOD>()> struct GatherOf { using type = rt::GlobalGather<T>; };
+template <typename T, int METHOD, int PH> struct GatherOf<T, METHOD, true, PH, false> { using type = rt::LdsGather<T, PH>; };
+template <typename T, int METHOD, bool LDS, int PH> struct GatherOf<T, METHOD, LDS, PH, true> { using type = rt::PolyGather<T, LDS>; };
 template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::GlobalGather<T>&, T*) {}
+template <typename T, bool LDS, bool S> __device__ __forceinline__ void gather_init(rt::PolyGather<T, S>&, T*) {}
 template <typename T, bool LDS, int PH> __device__ __forceinline__ void gather_init(rt::LdsGather<T, PH>& g, T* lds) {
     g.init(lds + (threadIdx.x >> 6) * rt::LdsGather<T, PH>::ELEMS);
 }
@@ -854,7 +909,7 @@ __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, lon
 template <typename T, int METHOD, bool ISO, bool LDS, bool VAR>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? RTMI_F32_WAVES : LDS ? (light_method(METHOD) ? RTMI_TILE_WAVES : heavy_method(METHOD) ? 2 : 3) : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES))
 void k_advance(BatchDev<T> a, int nsteps) {
-    __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
+    __shared__ __attribute__((aligned(16))) T lds[uses_tile<T, METHOD, LDS>() ? 4 * rt::LdsGather<T>::ELEMS : 2];
     advance_bundle<T, METHOD, ISO, LDS, VAR>(a, lds, (long)blockIdx.x * blockDim.x, nsteps);
 }
 // The tile kernel built for FEW waves: a batch of <= 2 waves per SIMD (cfg2's 65 536 rays: one) has nothing to hide a step's
@@ -863,12 +918,12 @@ void k_advance(BatchDev<T> a, int nsteps) {
 // overlaps the two axes, the two gradient components and the LDS round trips.  Same arithmetic, same order of every sum: same bits.
 template <typename T, int METHOD, bool ISO>
 __global__ __launch_bounds__(256, 1) void k_advance_lat(BatchDev<T> a, int nsteps) {
-    __shared__ __attribute__((aligned(16))) T lds[4 * rt::LdsGather<T, 1>::ELEMS];
+    __shared__ __attribute__((aligned(16))) T lds[uses_tile<T, METHOD, true>() ? 4 * rt::LdsGather<T, 1>::ELEMS : 2];
     advance_bundle<T, METHOD, ISO, true, false, false, 1>(a, lds, (long)blockIdx.x * blockDim.x, nsteps);
 }
 template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool COH, int PH>
 __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, long blk, int nsteps) {
-    typename GatherOf<T, LDS, PH>::type gather;
+    typename GatherOf<T, METHOD, LDS, PH>::type gather;
     gather_init<T, LDS>(gather, lds);
     const long k = blk + threadIdx.x;
     rt::Ray<T> r;
@@ -925,7 +980,7 @@ __device__ __forceinline__ void compiler_fence() { __atomic_signal_fence(__ATOMI
 template <typename T, int METHOD, bool ISO, bool LDS>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? RTMI_F32_SLICED_WAVES : LDS ? (light_method(METHOD) ? RTMI_TILE_WAVES : heavy_method(METHOD) ? 2 : 3) : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES))
 void k_advance_sliced(BatchDev<T> a, int slice, unsigned long long capacity, unsigned long long* ctl, unsigned long long timeout_ticks) {
-    __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
+    __shared__ __attribute__((aligned(16))) T lds[uses_tile<T, METHOD, LDS>() ? 4 * rt::LdsGather<T>::ELEMS : 2];
     __shared__ unsigned long long s_entry;
     const unsigned long long NB = (unsigned long long)((a.R + 255) / 256);
     unsigned long long* head = ctl;
@@ -1017,8 +1072,8 @@ void k_advance_sliced(BatchDev<T> a, int slice, unsigned long long capacity, uns
 #endif
 template <typename T, int METHOD, bool ISO, bool LDS>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : light_method(METHOD) ? RTMI_REFILL_WAVES : 2) void k_trace_refill(BatchDev<T> a, int refill_min, int chunk) {
-    __shared__ __attribute__((aligned(16))) T lds[LDS ? 4 * rt::LdsGather<T>::ELEMS : 2];
-    typename GatherOf<T, LDS>::type gather;
+    __shared__ __attribute__((aligned(16))) T lds[uses_tile<T, METHOD, LDS>() ? 4 * rt::LdsGather<T>::ELEMS : 2];
+    typename GatherOf<T, METHOD, LDS>::type gather;
     gather_init<T, LDS>(gather, lds);
     const bool RECORD = a.stride != 0;
     const unsigned lane = threadIdx.x & 63;

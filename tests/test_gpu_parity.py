@@ -496,9 +496,10 @@ def test_uniform_basis_vs_exact_basis(scen, m, rb, gpu_fields, oracle_fields):
                                                  ("interface", 6, False, "plain"), ("fisheye", 6, False, "plain"),
                                                  ("vert_heterogeneous", 7, True, "refill"), ("anisotropy", 11, False, "plain")])
 def test_lds_tile_equals_global_gather(scen, m, shuffle, mode, rb, gpu_fields):
-    """field_path 2 (wave-private LDS tile of the field, re-staged as the wave moves; lanes outside the tile fall
-    back to global loads) must give the same bits as field_path 1 (every lookup gathers from global memory):
-    coherent fans, a shuffled batch (tile rarely fits), the refill kernel, rays that run to the grid's edge."""
+    """field_path 2 -- the wave-shared lookup: for the fast-form methods the cell's polynomial through the scalar cache
+    (wave-uniform cell, per-lane loads for lanes elsewhere), for the reference-order methods the wave-private LDS tile
+    (re-staged as the wave moves; lanes outside fall back to global loads) -- must give the same bits as field_path 1
+    (every lane reads for itself): coherent fans, a shuffled batch, the refill kernel, rays that run to the grid's edge."""
     R = 2000 if m != 11 else 200
     lim = LIMITS[scen]
     if scen == "fisheye":
@@ -516,7 +517,8 @@ def test_lds_tile_equals_global_gather(scen, m, shuffle, mode, rb, gpu_fields):
         b.run()
         out.append((b.d_ray(), b.final(), b.rows(), b.stats()["lds_bytes"]))
         b.close()
-    assert out[0][3] > 4096 and out[1][3] <= 512        # the tile variant really carries the LDS tile
+    if m == 11:
+        assert out[0][3] > 4096 and out[1][3] <= 512    # the tile variant really carries the LDS tile
     for u, v in zip(out[0][:3], out[1][:3]):
         assert np.array_equal(u, v)
 
