@@ -100,10 +100,15 @@ typedef struct {
                                 keeps the faster (rtmi_stats.launch_mode_used tells which ran) */
     int32_t block_size;      /* 0 -> default */
     int32_t refill_min;      /* RTMI_LAUNCH_REFILL: compact when this many lanes of a wave are idle (0 -> 32) */
-    int32_t exact_basis;     /* 0: uniform-knot cubic basis in interior cells (<= 4e-14 from FITPACK's weights);
-                                1: FITPACK's fpbspl arithmetic on the true knots in every cell (slower) */
-    int32_t field_path;      /* where lookups read the field: 0 auto (wave-private LDS tile, except global memory for fp64
-                                op3/4/5/9/10/11), 1 global memory (L1/L2), 2 wave-private LDS tile; identical results */
+    int32_t exact_basis;     /* kept for ABI compatibility (0 or 1; it used to select fpbspl on the true knots), no effect now: the fast-form methods evaluate the
+                                field as one polynomial per grid cell, converted from FITPACK's splines on the TRUE knots of
+                                every cell (< 1e-15 of the field's scale from FITPACK's own evaluation, rim cells included);
+                                rtmi_field_eval and the reference-order methods use FITPACK's arithmetic itself */
+    int32_t field_path;      /* how a wave gets at the field; identical results.  0 auto; 1 every lane reads for itself
+                                (L1/L2); 2 wave-shared: the fast-form methods read a wave-uniform cell's polynomial through
+                                the scalar cache into scalar registers (lanes in other cells fall back to 1), the
+                                reference-order methods stage a wave-private LDS tile of B-spline coefficients.  Auto: 2 for
+                                the fast-form methods and fp32, 1 for fp64 op3/4/5/9/10/11 and reference_order */
     int32_t sort_rays;       /* 1: reorder rays inside the batch by launch cell block and angle so that lanes of a wave stay
                                 coherent; every read call still answers in the caller's ray order (see rtmi_device_view.perm) */
     /* optional caller-owned DEVICE buffers (e.g. torch tensors); NULL -> the library allocates */

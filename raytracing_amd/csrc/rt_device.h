@@ -6,6 +6,9 @@
 
 #include "rt_polytab.h"
 
+#ifndef RTMI_POLY_BATCH
+#define RTMI_POLY_BATCH 1     // scalar loads of a lookup: 0 row by row, 1 one spline + n then the other (measured best), 2 all at once (spills SGPRs)
+#endif
 #ifndef RTMI_POLY
 #define RTMI_POLY 1     // 1: the fast-form step methods look the field up as one polynomial per cell (PolyGather); 0: B-spline sums
 #endif
@@ -651,8 +654,8 @@ template <typename T, int PHASES = RTMI_TILE_PHASES> struct LdsGather {
 // n_gradient(vector, grd, z) (:141-156): bilinear n, bicubic dn/dx and dn/dy at (x, y) -> (n, [gx, gy]).
 // `active` tells the gather policy whether this lane's lookup matters (idle lanes still execute it).
 template <typename G> struct IsPoly { static constexpr bool value = false; };
-template <typename T, bool S> struct PolyGather;
-template <typename T, bool S> struct IsPoly<PolyGather<T, S>> { static constexpr bool value = true; };
+template <typename T, int MODE> struct PolyGather;
+template <typename T, int MODE> struct IsPoly<PolyGather<T, MODE>> { static constexpr bool value = true; };
 template <typename T, typename G>
 __device__ __forceinline__ void n_gradient(const FieldDev<T>& F, G& gather, bool active, T x, T y, T& n, T& gx, T& gy) {
     if constexpr (IsPoly<G>::value) {
@@ -741,18 +744,22 @@ __device__ __forceinline__ float fma_vus(float a, float u, float c) {
     asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(u), "s"(c));
     return d;
 }
-// Horner in u for one row.  SC: the coefficients are scalar-register values.  Same operations either way: same bits.
-template <typename T, bool SC> __device__ __forceinline__ T poly_row(Quad<T> a, T u) {
-    if constexpr (SC) return fma_vus(fma_vus(fma_sus(a.w, u, a.z), u, a.y), u, a.x);
+// Horner in u for one row.  SC 1: the coefficients are scalar-register values; SC 2: they are vector registers that must
+// survive the lookup (the kept cell of PolyGather's CACHED mode): three-address fma, or the compiler copies each addend for
+// its two-address v_fmac.  Same operations in every form: same bits.
+template <typename T, int SC> __device__ __forceinline__ T poly_row(Quad<T> a, T u) {
+    if constexpr (SC == 1) return fma_vus(fma_vus(fma_sus(a.w, u, a.z), u, a.y), u, a.x);
+    else if constexpr (SC == 2) return fma_const(fma_const(fma_const(a.w, u, a.z), u, a.y), u, a.x);
     else return fma_(fma_(fma_(a.w, u, a.z), u, a.y), u, a.x);
 }
-template <typename T, bool SC, typename ROW> __device__ __forceinline__ T poly_bicubic(ROW row, int base, T u, T v) {
+template <typename T, int SC, typename ROW> __device__ __forceinline__ T poly_bicubic(ROW row, int base, T u, T v) {
     const T r3 = poly_row<T, SC>(row(base + 3), u), r2 = poly_row<T, SC>(row(base + 2), u);
     const T r1 = poly_row<T, SC>(row(base + 1), u), r0 = poly_row<T, SC>(row(base), u);
     return fma_(fma_(fma_(r3, v, r2), v, r1), v, r0);
 }
-template <typename T, bool SC> __device__ __forceinline__ T poly_bilinear(Quad<T> b, T u, T v) {
-    if constexpr (SC) return fma_(fma_sus(b.w, u, b.z), v, fma_sus(b.y, u, b.x));
+template <typename T, int SC> __device__ __forceinline__ T poly_bilinear(Quad<T> b, T u, T v) {
+    if constexpr (SC == 1) return fma_(fma_sus(b.w, u, b.z), v, fma_sus(b.y, u, b.x));
+    else if constexpr (SC == 2) return fma_(fma_const(b.w, u, b.z), v, fma_const(b.y, u, b.x));
     else return fma_(fma_(b.w, u, b.z), v, fma_(b.y, u, b.x));
 }
 
@@ -763,38 +770,113 @@ template <typename T, bool SC> __device__ __forceinline__ T poly_bilinear(Quad<T
 //   own cell with vector loads.  A fan's wave sits in ONE cell on 98 % of its steps (64 neighbouring rays of 1 M span 4 % of
 //   a cell) and in two on the rest.
 //   !SCALAR: every lane reads its own cell with vector loads (two rows in flight): the per-ray-DELTA_S sweep, field_path 1.
+//   CACHED (the build for at most two waves per SIMD, k_advance_lat): nothing hides a scalar load's latency there (six waits
+//   of ~130 clocks per step measured: cfg2 3.3 ms against 2.3 with the LDS tile), and registers are plentiful, so the wave
+//   KEEPS its cell's 36 coefficients in vector registers (every lane the same values) and reloads them only when the first
+//   live lane's cell changes -- every seventh step on the vert fan; a lookup in the kept cell is 33 fma and no memory access.
 // The arithmetic is poly_bicubic / poly_bilinear on the same numbers either way: the result does not depend on the policy,
 // on the wave mates or on which round served the lane.
-template <typename T, bool SCALAR> struct PolyGather {
+constexpr int kPolyLane = 0, kPolyScalar = 1, kPolyCached = 2;
+template <typename T, int MODE> struct PolyGather {
+    static constexpr bool SCALAR = MODE == kPolyScalar;
     static constexpr bool kPoly = true;
     typedef const Quad<T> __attribute__((address_space(4)))* ScalarRows;
     static __device__ __forceinline__ void eval_scalar(ScalarRows p, T u, T v, T& n, T& gx, T& gy) {
+#if RTMI_POLY_BATCH == 0
         auto row = [&](int k) -> Quad<T> { return p[k]; };
-        gx = poly_bicubic<T, true>(row, 0, u, v);
-        gy = poly_bicubic<T, true>(row, 4, u, v);
-        n = poly_bilinear<T, true>(p[8], u, v);
+        gx = poly_bicubic<T, 1>(row, 0, u, v);
+        gy = poly_bicubic<T, 1>(row, 4, u, v);
+        n = poly_bilinear<T, 1>(p[8], u, v);
+#else
+        // scalar loads return out of order, so every wait is for all of them: ask for as many rows at once as the scalar
+        // registers hold (RTMI_POLY_BATCH 1: one spline + n, then the other; 2: everything) instead of row by row
+        Quad<T> a[9];
+#pragma unroll
+        for (int k = 0; k < 4; k++) a[k] = p[k];
+        a[8] = p[8];
+#if RTMI_POLY_BATCH == 2
+#pragma unroll
+        for (int k = 4; k < 8; k++) a[k] = p[k];
+#endif
+        auto row = [&](int k) -> Quad<T> { return a[k]; };
+        gx = poly_bicubic<T, 1>(row, 0, u, v);
+        n = poly_bilinear<T, 1>(a[8], u, v);
+#if RTMI_POLY_BATCH == 1
+        asm volatile("" : "+v"(gx), "+v"(n) : : "memory");
+#pragma unroll
+        for (int k = 4; k < 8; k++) a[k] = p[k];
+#endif
+        gy = poly_bicubic<T, 1>(row, 4, u, v);
+#endif
     }
     static __device__ __forceinline__ void eval_lane(const FieldDev<T>& F, int cell, T u, T v, T& n, T& gx, T& gy) {
         const Quad<T>* p = reinterpret_cast<const Quad<T>*>(F.poly + (size_t)cell * kPolyStride);
+        if constexpr (MODE == kPolyCached) {
+            // the few-waves build has the registers: all nine rows in flight, one memory latency (the cells of a wave that
+            // straddles a grid line were all used a step ago: L1 hits)
+            Quad<T> a[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) a[k] = p[k];
+            auto row = [&](int k) -> Quad<T> { return a[k]; };
+            gx = poly_bicubic<T, 0>(row, 0, u, v);
+            gy = poly_bicubic<T, 0>(row, 4, u, v);
+            n = poly_bilinear<T, 0>(a[8], u, v);
+            return;
+        }
         T g[2];
 #pragma unroll
         for (int s = 0; s < 2; s++) {
             // two rows in flight (16 VGPRs in fp64), the next two behind their sums: this path must not set the register count
             Quad<T> a3 = p[4 * s + 3], a2 = p[4 * s + 2];
-            T r3 = poly_row<T, false>(a3, u), r2 = poly_row<T, false>(a2, u);
+            T r3 = poly_row<T, 0>(a3, u), r2 = poly_row<T, 0>(a2, u);
             asm volatile("" : "+v"(r3), "+v"(r2) : : "memory");
             Quad<T> a1 = p[4 * s + 1], a0 = p[4 * s];
-            T r1 = poly_row<T, false>(a1, u), r0 = poly_row<T, false>(a0, u);
+            T r1 = poly_row<T, 0>(a1, u), r0 = poly_row<T, 0>(a0, u);
             g[s] = fma_(fma_(fma_(r3, v, r2), v, r1), v, r0);
             asm volatile("" : "+v"(g[s]) : : "memory");
         }
         gx = g[0]; gy = g[1];
-        n = poly_bilinear<T, false>(p[8], u, v);
+        n = poly_bilinear<T, 0>(p[8], u, v);
+    }
+    // CACHED: the kept cell and its nine rows (wave-uniform values in vector registers)
+    int kept;
+    Quad<T> rows[MODE == kPolyCached ? 9 : 1];
+    __device__ __forceinline__ void init() { kept = -1; }
+    __device__ __forceinline__ void eval_kept(T u, T v, T& n, T& gx, T& gy) const {
+        auto row = [&](int k) -> Quad<T> { return rows[k]; };
+        gx = poly_bicubic<T, 2>(row, 0, u, v);
+        gy = poly_bicubic<T, 2>(row, 4, u, v);
+        n = poly_bilinear<T, 2>(rows[8], u, v);
     }
     __device__ __forceinline__ void lookup_xy(const FieldDev<T>& F, bool active, T x, T y, T& n, T& gx, T& gy) {
         PolyCell<T> c;
         poly_locate(F, x, y, active, c);
-        if constexpr (SCALAR) {
+        if constexpr (MODE == kPolyCached) {
+            const unsigned long long live = __ballot(active);
+            const int first = live ? __builtin_ctzll(live) : 0;
+            const int cu = __builtin_amdgcn_readlane(c.cell, first);
+            if (cu != kept && live != 0ull) {
+                // every lane loads the same 288 bytes (one address per instruction: a broadcast in the texture path)
+                typedef const Quad<T> __attribute__((address_space(1)))* GlobalRows;
+                GlobalRows p = (GlobalRows)(F.poly + (size_t)cu * kPolyStride);
+                asm volatile("" : "+v"(p));          // a per-lane address on purpose: vector loads into vector registers
+#pragma unroll
+                for (int k = 0; k < 9; k++) rows[k] = p[k];
+                kept = cu;
+                // retire the loads here, in the rare branch: left pending they make every later step's first use of a row
+                // wait for vmcnt(0), which also counts the trajectory stores of the step before
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+            }
+            if (__ballot(active && c.cell != cu) == 0ull) {
+                eval_kept(c.u, c.v, n, gx, gy);
+                return;
+            }
+            n = T(1); gx = T(0); gy = T(0);
+            if (active) {
+                if (c.cell == cu) eval_kept(c.u, c.v, n, gx, gy);
+                else eval_lane(F, c.cell, c.u, c.v, n, gx, gy);
+            }
+        } else if constexpr (SCALAR) {
             // the first live lane's cell; when every live lane is in it (98 % of a fan's wave-steps) all lanes evaluate its
             // polynomial in straight-line code -- an idle lane too, at its own (u, v) in [0, 1)^2: finite, and nobody reads it
             const unsigned long long live = __ballot(active);

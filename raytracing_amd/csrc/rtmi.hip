@@ -622,7 +622,7 @@ template <> __device__ __forceinline__ void derive_rt<double>(const BatchDev<dou
     else rt::derive<double, false>(a.K, r);
 }
 #if RTMI_POLY
-template <typename T> using InitGather = rt::PolyGather<T, false>;     // the fast forms' lookup, one lane per ray
+template <typename T> using InitGather = rt::PolyGather<T, rt::kPolyLane>;     // the fast forms' lookup, one lane per ray
 #else
 template <typename T> using InitGather = rt::GlobalGather<T>;
 #endif
@@ -733,9 +733,11 @@ template <typename T, int METHOD> constexpr bool uses_poly() { return RTMI_POLY 
 template <typename T, int METHOD, bool LDS> constexpr bool uses_tile() { return LDS && !uses_poly<T, METHOD>(); }
 template <typename T, int METHOD, bool LDS, int PH = RTMI_TILE_PHASES, bool POLY = uses_poly<T, METHOD>()> struct GatherOf { using type = rt::GlobalGather<T>; };
 template <typename T, int METHOD, int PH> struct GatherOf<T, METHOD, true, PH, false> { using type = rt::LdsGather<T, PH>; };
-template <typename T, int METHOD, bool LDS, int PH> struct GatherOf<T, METHOD, LDS, PH, true> { using type = rt::PolyGather<T, LDS>; };
+template <typename T, int METHOD, bool LDS, int PH> struct GatherOf<T, METHOD, LDS, PH, true> {
+    using type = rt::PolyGather<T, !LDS ? rt::kPolyLane : PH == 1 ? rt::kPolyCached : rt::kPolyScalar>;   // PH == 1: k_advance_lat
+};
 template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::GlobalGather<T>&, T*) {}
-template <typename T, bool LDS, bool S> __device__ __forceinline__ void gather_init(rt::PolyGather<T, S>&, T*) {}
+template <typename T, bool LDS, int MODE> __device__ __forceinline__ void gather_init(rt::PolyGather<T, MODE>& g, T*) { g.init(); }
 template <typename T, bool LDS, int PH> __device__ __forceinline__ void gather_init(rt::LdsGather<T, PH>& g, T* lds) {
     g.init(lds + (threadIdx.x >> 6) * rt::LdsGather<T, PH>::ELEMS);
 }
