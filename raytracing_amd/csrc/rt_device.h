@@ -776,9 +776,11 @@ template <typename T, int SC> __device__ __forceinline__ T poly_bilinear(Quad<T>
 //   live lane's cell changes -- every seventh step on the vert fan; a lookup in the kept cell is 33 fma and no memory access.
 // The arithmetic is poly_bicubic / poly_bilinear on the same numbers either way: the result does not depend on the policy,
 // on the wave mates or on which round served the lane.
-constexpr int kPolyLane = 0, kPolyScalar = 1, kPolyCached = 2;
+constexpr int kPolyLane = 0, kPolyScalar = 1, kPolyCached = 2, kPolyCached1 = 3;   // CACHED with two kept cells / with one
 template <typename T, int MODE> struct PolyGather {
     static constexpr bool SCALAR = MODE == kPolyScalar;
+    static constexpr bool CACHED = MODE == kPolyCached || MODE == kPolyCached1;
+    static constexpr int NA = CACHED ? 9 : 1, NB = MODE == kPolyCached ? 9 : 1;     // rows held in slot A / slot B
     static constexpr bool kPoly = true;
     typedef const Quad<T> __attribute__((address_space(4)))* ScalarRows;
     static __device__ __forceinline__ void eval_scalar(ScalarRows p, T u, T v, T& n, T& gx, T& gy) {
@@ -811,9 +813,9 @@ template <typename T, int MODE> struct PolyGather {
     }
     static __device__ __forceinline__ void eval_lane(const FieldDev<T>& F, int cell, T u, T v, T& n, T& gx, T& gy) {
         const Quad<T>* p = reinterpret_cast<const Quad<T>*>(F.poly + (size_t)cell * kPolyStride);
-        if constexpr (MODE == kPolyCached) {
-            // the few-waves build has the registers: all nine rows in flight, one memory latency (the cells of a wave that
-            // straddles a grid line were all used a step ago: L1 hits)
+        if constexpr (MODE == kPolyCached1) {
+            // this build has the registers: all nine rows in flight, one memory latency (the cells of a wave that straddles a
+            // grid line were all used a step ago: L1 hits)
             Quad<T> a[9];
 #pragma unroll
             for (int k = 0; k < 9; k++) a[k] = p[k];
@@ -838,44 +840,71 @@ template <typename T, int MODE> struct PolyGather {
         gx = g[0]; gy = g[1];
         n = poly_bilinear<T, 0>(p[8], u, v);
     }
-    // CACHED: the kept cell and its nine rows (wave-uniform values in vector registers)
-    int kept;
-    Quad<T> rows[MODE == kPolyCached ? 9 : 1];
-    __device__ __forceinline__ void init() { kept = -1; }
-    __device__ __forceinline__ void eval_kept(T u, T v, T& n, T& gx, T& gy) const {
-        auto row = [&](int k) -> Quad<T> { return rows[k]; };
+    // CACHED: the kept cell and its nine rows (wave-uniform values in vector registers); lanes outside it read their own cell
+    // (218 VGPRs, two waves per SIMD).  kPolyCached keeps TWO cells (a wave that is crossing a grid line has lanes on both
+    // sides for a few steps; the cell ahead goes into the slot that was not served from last): measured slower -- 304 VGPRs
+    // and twice the control flow, cfg2 2.59 vs 2.21 ms, a one-cell-wide fan 2.00 vs 1.86 -- and not selected by the host
+    // (env RTMI_LAT_TWO_SLOTS=1 for the A/B).
+    int tagA, tagB;
+    bool lastB;
+    Quad<T> rowsA[NA], rowsB[NB];
+    __device__ __forceinline__ void init() { tagA = tagB = -1; lastB = true; }
+    template <int N> static __device__ __forceinline__ void eval_rows(const Quad<T> (&rows)[N], T u, T v, T& n, T& gx, T& gy) {
+        auto row = [&](int k) -> Quad<T> { return rows[N == 9 ? k : 0]; };
         gx = poly_bicubic<T, 2>(row, 0, u, v);
         gy = poly_bicubic<T, 2>(row, 4, u, v);
-        n = poly_bilinear<T, 2>(rows[8], u, v);
+        n = poly_bilinear<T, 2>(rows[N == 9 ? 8 : 0], u, v);
+    }
+    template <int N> static __device__ __forceinline__ void load_rows(Quad<T> (&rows)[N], const FieldDev<T>& F, int cu) {
+        // every lane loads the same 288 bytes (one address per instruction: a broadcast in the texture path)
+        typedef const Quad<T> __attribute__((address_space(1)))* GlobalRows;
+        GlobalRows p = (GlobalRows)(F.poly + (size_t)cu * kPolyStride);
+        asm volatile("" : "+v"(p));          // a per-lane address on purpose: vector loads into vector registers
+#pragma unroll
+        for (int k = 0; k < N; k++) rows[k] = p[k];
+        // retire the loads here, in the rare branch: left pending they make every later step's first use of a row wait for
+        // vmcnt(0), which also counts the trajectory stores of the step before
+        __builtin_amdgcn_s_waitcnt(0x0F70);
     }
     __device__ __forceinline__ void lookup_xy(const FieldDev<T>& F, bool active, T x, T y, T& n, T& gx, T& gy) {
         PolyCell<T> c;
         poly_locate(F, x, y, active, c);
         if constexpr (MODE == kPolyCached) {
             const unsigned long long live = __ballot(active);
-            const int first = live ? __builtin_ctzll(live) : 0;
-            const int cu = __builtin_amdgcn_readlane(c.cell, first);
-            if (cu != kept && live != 0ull) {
-                // every lane loads the same 288 bytes (one address per instruction: a broadcast in the texture path)
-                typedef const Quad<T> __attribute__((address_space(1)))* GlobalRows;
-                GlobalRows p = (GlobalRows)(F.poly + (size_t)cu * kPolyStride);
-                asm volatile("" : "+v"(p));          // a per-lane address on purpose: vector loads into vector registers
-#pragma unroll
-                for (int k = 0; k < 9; k++) rows[k] = p[k];
-                kept = cu;
-                // retire the loads here, in the rare branch: left pending they make every later step's first use of a row
-                // wait for vmcnt(0), which also counts the trajectory stores of the step before
-                __builtin_amdgcn_s_waitcnt(0x0F70);
+            const int cu = __builtin_amdgcn_readlane(c.cell, live ? __builtin_ctzll(live) : 0);
+            bool useB;
+            if (cu == tagA) useB = false;
+            else if (cu == tagB) useB = true;
+            else {
+                useB = !lastB;
+                if (useB) { load_rows(rowsB, F, cu); tagB = cu; }
+                else { load_rows(rowsA, F, cu); tagA = cu; }
             }
-            if (__ballot(active && c.cell != cu) == 0ull) {
-                eval_kept(c.u, c.v, n, gx, gy);
-                return;
+            lastB = useB;
+            // every lane evaluates the first live lane's cell in straight-line code; lanes of another cell are redone below
+            if (useB) eval_rows(rowsB, c.u, c.v, n, gx, gy);
+            else eval_rows(rowsA, c.u, c.v, n, gx, gy);
+            const bool rest = active && c.cell != cu;
+            const unsigned long long rem = __ballot(rest);
+            if (rem != 0ull) {
+                const int cu2 = __builtin_amdgcn_readlane(c.cell, __builtin_ctzll(rem));
+                if (useB) { if (cu2 != tagA) { load_rows(rowsA, F, cu2); tagA = cu2; } }
+                else { if (cu2 != tagB) { load_rows(rowsB, F, cu2); tagB = cu2; } }
+                if (rest) {
+                    if (c.cell == cu2) {
+                        if (useB) eval_rows(rowsA, c.u, c.v, n, gx, gy);
+                        else eval_rows(rowsB, c.u, c.v, n, gx, gy);
+                    } else {
+                        eval_lane(F, c.cell, c.u, c.v, n, gx, gy);      // a wave in three or more cells
+                    }
+                }
             }
-            n = T(1); gx = T(0); gy = T(0);
-            if (active) {
-                if (c.cell == cu) eval_kept(c.u, c.v, n, gx, gy);
-                else eval_lane(F, c.cell, c.u, c.v, n, gx, gy);
-            }
+        } else if constexpr (MODE == kPolyCached1) {
+            const unsigned long long live = __ballot(active);
+            const int cu = __builtin_amdgcn_readlane(c.cell, live ? __builtin_ctzll(live) : 0);
+            if (cu != tagA) { load_rows(rowsA, F, cu); tagA = cu; }
+            eval_rows(rowsA, c.u, c.v, n, gx, gy);
+            if (active && c.cell != cu) eval_lane(F, c.cell, c.u, c.v, n, gx, gy);
         } else if constexpr (SCALAR) {
             // the first live lane's cell; when every live lane is in it (98 % of a fan's wave-steps) all lanes evaluate its
             // polynomial in straight-line code -- an idle lane too, at its own (u, v) in [0, 1)^2: finite, and nobody reads it

@@ -734,7 +734,7 @@ template <typename T, int METHOD, bool LDS> constexpr bool uses_tile() { return 
 template <typename T, int METHOD, bool LDS, int PH = RTMI_TILE_PHASES, bool POLY = uses_poly<T, METHOD>()> struct GatherOf { using type = rt::GlobalGather<T>; };
 template <typename T, int METHOD, int PH> struct GatherOf<T, METHOD, true, PH, false> { using type = rt::LdsGather<T, PH>; };
 template <typename T, int METHOD, bool LDS, int PH> struct GatherOf<T, METHOD, LDS, PH, true> {
-    using type = rt::PolyGather<T, !LDS ? rt::kPolyLane : PH == 1 ? rt::kPolyCached : rt::kPolyScalar>;   // PH == 1: k_advance_lat
+    using type = rt::PolyGather<T, !LDS ? rt::kPolyLane : PH == 1 ? rt::kPolyCached : PH == 2 ? rt::kPolyCached1 : rt::kPolyScalar>;   // PH 1 / 2: k_advance_lat<.., 1 / 2 waves per SIMD>
 };
 template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::GlobalGather<T>&, T*) {}
 template <typename T, bool LDS, int MODE> __device__ __forceinline__ void gather_init(rt::PolyGather<T, MODE>& g, T*) { g.init(); }
@@ -918,10 +918,12 @@ void k_advance(BatchDev<T> a, int nsteps) {
 // dependent chain behind -- 2 060 cycles per step at one wave per SIMD against 705 of issue -- so this build may use the whole
 // register file (launch bound: one wave per SIMD) and reads the 4x4 window from the tile in one go; the scheduler then
 // overlaps the two axes, the two gradient components and the LDS round trips.  Same arithmetic, same order of every sum: same bits.
-template <typename T, int METHOD, bool ISO>
-__global__ __launch_bounds__(256, 1) void k_advance_lat(BatchDev<T> a, int nsteps) {
+// WAVES: the waves per SIMD the build is for.  With the polynomial lookup (rt::PolyGather, CACHED): 1 keeps two cells'
+// coefficients in vector registers, 2 keeps one.
+template <typename T, int METHOD, bool ISO, int WAVES>
+__global__ __launch_bounds__(256, WAVES) void k_advance_lat(BatchDev<T> a, int nsteps) {
     __shared__ __attribute__((aligned(16))) T lds[uses_tile<T, METHOD, true>() ? 4 * rt::LdsGather<T, 1>::ELEMS : 2];
-    advance_bundle<T, METHOD, ISO, true, false, false, 1>(a, lds, (long)blockIdx.x * blockDim.x, nsteps);
+    advance_bundle<T, METHOD, ISO, true, false, false, uses_poly<T, METHOD>() ? WAVES : 1>(a, lds, (long)blockIdx.x * blockDim.x, nsteps);
 }
 template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool COH, int PH>
 __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, long blk, int nsteps) {
@@ -1327,17 +1329,20 @@ static bool uniform_rows_ok(const rtmi_batch* b) {
     return b->p.record_stride == 0 || (!b->dirty_state && (double)b->R * (double)b->esz * 6.0 < 2147483647.0);
 }
 // op2/op6 fp64 tile builds for few waves (k_advance_lat): [method 2 | 6][iso]
-static const void* advance_lat_fn(int m, bool iso) {
-    static const void* const tab[2][2] = {{(const void*)k_advance_lat<double, 2, false>, (const void*)k_advance_lat<double, 2, true>},
-                                          {(const void*)k_advance_lat<double, 6, false>, (const void*)k_advance_lat<double, 6, true>}};
-    return tab[m == 6 ? 1 : 0][iso ? 1 : 0];
+static const void* advance_lat_fn(int m, bool iso, int waves) {
+    static const void* const tab[2][2][2] = {
+        {{(const void*)k_advance_lat<double, 2, false, 1>, (const void*)k_advance_lat<double, 2, false, 2>},
+         {(const void*)k_advance_lat<double, 2, true, 1>, (const void*)k_advance_lat<double, 2, true, 2>}},
+        {{(const void*)k_advance_lat<double, 6, false, 1>, (const void*)k_advance_lat<double, 6, false, 2>},
+         {(const void*)k_advance_lat<double, 6, true, 1>, (const void*)k_advance_lat<double, 6, true, 2>}}};
+    return tab[m == 6 ? 1 : 0][iso ? 1 : 0][waves == 2 ? 1 : 0];
 }
 static const void* pick_advance(const rtmi_batch* b) {
     const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
     // at most two waves per SIMD's worth of rays: the latency build (env RTMI_NO_LAT=1 keeps the throughput build, for A/B)
     if (lds && b->p.dtype == RTMI_F64 && (b->p.method == 2 || b->p.method == 6) && !b->vstep && uniform_rows_ok(b) &&
         !b->p.reference_order && b->lat_waves_per_simd > 0 && (b->R + 63) / 64 <= (int64_t)2 * b->lat_simds && !getenv("RTMI_NO_LAT"))
-        return advance_lat_fn(b->p.method, iso);
+        return advance_lat_fn(b->p.method, iso, (b->R + 63) / 64 <= (int64_t)b->lat_simds && getenv("RTMI_LAT_TWO_SLOTS") ? 1 : 2);   // env: A/B of the two-slot build
     // the VAR build: per-ray DELTA_S / max_size when set, and per-lane row bookkeeping always
     if (b->vstep || !uniform_rows_ok(b))
         return b->p.dtype == RTMI_F64 ? advance_var_fn<double>(batch_kernel_index(b), iso) : advance_var_fn<float>(batch_kernel_index(b), iso);
