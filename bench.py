@@ -181,8 +181,10 @@ def main():
                     help="ray order inside the batch: the sorted fan, or a seeded random permutation of it")
     ap.add_argument("--refill-min", type=int, default=0)
     ap.add_argument("--sort", action="store_true", help="sort rays inside the batch by launch cell and angle (sort_rays)")
-    ap.add_argument("--field-path", default="auto", choices=["auto", "lds", "global"],
-                    help="auto (default): LDS tile when recording densely, else global; lds / global force one")
+    ap.add_argument("--field-path", default="auto", choices=["auto", "lds", "global", "shared"],
+                    help="auto (default): the library's choice (rtmi_params.field_path 0); shared (= lds, its old name): the "
+                         "wave-shared lookup -- a wave-uniform cell's polynomial through the scalar cache for the fast-form "
+                         "methods, the LDS tile for the reference-order ones; global: every lane reads for itself")
     ap.add_argument("--rec-rows", type=int, default=0, help="rows to allocate (0 = from max_size; full: 3072 for vert)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0,
@@ -264,7 +266,7 @@ def main():
         return rb.Batch(fld, args.method, step, max_size, lim, sc["gamma"], th, sc["start"][0], sc["start"][1],
                         record_stride=stride_, rec_rows=rec_rows_, block_size=args.block,
                         launch_mode=args.mode, refill_min=args.refill_min, slice_steps=args.slice_steps,
-                        field_path={"auto": 0, "global": 1, "lds": 2}[args.field_path], sort_rays=args.sort,
+                        field_path={"auto": 0, "global": 1, "lds": 2, "shared": 2}[args.field_path], sort_rays=args.sort,
                         lazy_clear=True,    # every pass re-runs the same launch conditions: same rows rewritten
                         keep_n_ray=args.n_ray, reference_order=args.reference_order)
 
@@ -393,7 +395,7 @@ def main():
                     alg_model={"bytes_per_ray_step": balg, "GB_per_s": balg * steps_per_pass / ksec / 1e9,
                                "note": "SURVEY.md 8d accounting (state in/out + 36-coefficient gather per ray-step); not a "
                                        "bound for this kernel: state stays in registers for all steps of a ray and the "
-                                       "gather is served from LDS/L2, so these bytes never reach HBM"})
+                                       "lookup reads a wave-uniform cell's coefficients through the scalar cache, so these bytes never reach HBM"})
         out = {
             "metric": "ray-steps/sec (whole node) on vert_heterogeneous, 1M rays; % HBM roofline",
             "value": total_steps / dt, "unit": "ray-steps/s", "n_gpus": world, "steps": args.steps,

@@ -901,6 +901,25 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
 template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool COH = false, int PH = RTMI_TILE_PHASES>
 __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, long blk, int nsteps);
 
+// Which 256-ray bundle a hardware block takes.  Blocks are dealt to the eight XCDs round-robin (block h runs on XCD h % 8,
+// as the h / 8-th block there), each XCD with an L2 of its own; neighbouring bundles of a fan walk through the same cells of
+// the field, so RTMI_XCD_GROUP consecutive bundles go to ONE XCD (its L2 then serves the second to G-th from the first's
+// misses) while the groups still interleave over the XCDs (a contiguous eighth of the fan per XCD is badly balanced:
+// DESIGN.md 5.1).  Identity for the blocks past the last whole round of 8 x G.
+#ifndef RTMI_XCD_GROUP
+#define RTMI_XCD_GROUP 8     // measured (A/B, one session): interface 24.6 -> 23.6 ms at 8, 24.0 at 4; vert, fisheye, fp32 unchanged
+#endif
+__device__ __forceinline__ unsigned xcd_grouped_block(unsigned h, unsigned nblocks) {
+#if RTMI_XCD_GROUP > 1
+    constexpr unsigned G = RTMI_XCD_GROUP, ROUND = 8u * G;
+    if (h < nblocks / ROUND * ROUND) {
+        const unsigned xcd = h & 7u, idx = h >> 3;
+        return ((idx / G) * 8u + xcd) * G + idx % G;
+    }
+#endif
+    return h;
+}
+
 // The loop at :866-879: one lane per ray, state in registers for up to nsteps DELTA_S steps.
 // ISO (gamma == 1) drops the anisotropic factor's dead arithmetic; LDS selects the wave-private field tile
 // (rt::LdsGather) over per-lookup global gathers.  Results are bit-identical across all four variants.
@@ -912,7 +931,7 @@ template <typename T, int METHOD, bool ISO, bool LDS, bool VAR>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? RTMI_F32_WAVES : LDS ? (light_method(METHOD) ? RTMI_TILE_WAVES : heavy_method(METHOD) ? 2 : 3) : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES))
 void k_advance(BatchDev<T> a, int nsteps) {
     __shared__ __attribute__((aligned(16))) T lds[uses_tile<T, METHOD, LDS>() ? 4 * rt::LdsGather<T>::ELEMS : 2];
-    advance_bundle<T, METHOD, ISO, LDS, VAR>(a, lds, (long)blockIdx.x * blockDim.x, nsteps);
+    advance_bundle<T, METHOD, ISO, LDS, VAR>(a, lds, (long)xcd_grouped_block(blockIdx.x, gridDim.x) * blockDim.x, nsteps);
 }
 // The tile kernel built for FEW waves: a batch of <= 2 waves per SIMD (cfg2's 65 536 rays: one) has nothing to hide a step's
 // dependent chain behind -- 2 060 cycles per step at one wave per SIMD against 705 of issue -- so this build may use the whole

@@ -1,0 +1,12 @@
+#!/bin/bash
+# round-3 profile set after the polynomial lookup (run through gpurun); tools/profile_summary.py <tag>... turns gpurun_out/prof_<tag>/ into profiles/<tag>_*
+set -u
+tools/profile_config.sh r03q_vert_full --record full
+tools/profile_config.sh r03q_vert_none --record none
+tools/profile_config.sh r03q_cfg2_full --rays 65536 --record full
+tools/profile_config.sh r03q_cfg2_none --rays 65536 --record none
+tools/profile_config.sh r03q_cfg3_fisheye_none --scenario fisheye --record none
+tools/profile_config.sh r03q_cfg3_fisheye_full --scenario fisheye --record full
+tools/profile_config.sh r03q_cfg4_f32_none --dtype f32 --rays 8388608 --record none
+tools/profile_config.sh r03q_strong8_full --total-rays 1048576 --emulate-world 8 --record full
+tools/profile_config.sh r03q_iface_none --scenario interface --record none
