@@ -13,6 +13,10 @@
 #define RTMI_POLY 1     // 1: the fast-form step methods look the field up as one polynomial per cell (PolyGather); 0: B-spline sums
 #endif
 
+// A wave vote straight from the predicate.  HIP's __ballot(int) converts the bool to an int and compares it with zero again
+// (v_cndmask + v_cmp per vote, 12 vector instructions per step of the bench kernel); the builtin takes the i1.
+__device__ __forceinline__ unsigned long long rt_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 namespace rt {
 
 // The library is compiled with -ffp-contract=off: every fusion below is an explicit fma(), so a value is
@@ -145,7 +149,7 @@ template <typename T> __device__ __forceinline__ void sincos_add_small(T s, T c,
 template <typename T> __device__ __forceinline__ void sincos_add(double theta, T s, T c, T k, T* so, T* co) {
     const bool small = M<T>::abs_(k) < M<T>::small_angle;
     // per-lane choice of formula; the vote only selects a layout without exec-mask bookkeeping for the common case
-    if (__ballot(!small) == 0ull) {
+    if (rt_ballot(!small) == 0ull) {
         sincos_add_small(s, c, k, so, co);
     } else if (small) {
         sincos_add_small(s, c, k, so, co);
@@ -156,7 +160,7 @@ template <typename T> __device__ __forceinline__ void sincos_add(double theta, T
 // sin/cos of `target` == (angle of (s, c)) + k: by rotation when k is small and no refresh is due, else from scratch
 template <typename T> __device__ __forceinline__ void sincos_add(double target, T s, T c, T k, T* so, T* co, bool refresh) {
     const bool small = M<T>::abs_(k) < M<T>::small_angle && !refresh;
-    if (__ballot(!small) == 0ull) {
+    if (rt_ballot(!small) == 0ull) {
         sincos_add_small(s, c, k, so, co);
     } else if (small) {
         sincos_add_small(s, c, k, so, co);
@@ -348,7 +352,7 @@ template <typename T> __device__ __forceinline__ void field_locate(const FieldDe
     const T urx = (x - F.ax) * F.inv_hx, ury = (y - F.ay) * F.inv_hy;
     const bool fx = !F.exact && urx >= T(5) && urx < (T)(F.qx - 7);     // false for NaN
     const bool fy = !F.exact && ury >= T(5) && ury < (T)(F.qy - 7);
-    if (__ballot(!(fx && fy)) == 0ull) {
+    if (rt_ballot(!(fx && fy)) == 0ull) {
         axis_fast(urx, floor_(urx), c.jx, c.lx, c.lwx, c.wx);
         axis_fast(ury, floor_(ury), c.jy, c.ly, c.lwy, c.wy);
     } else {
@@ -556,7 +560,7 @@ template <typename T, int PHASES = RTMI_TILE_PHASES> struct LdsGather {
         const bool regular = c.jx == c.lx - 2 && c.jy == c.ly - 2;
         // an idle lane counts as served (it reads tile corner (0,0); nobody uses what it computes)
         bool fits = !active || (valid && regular && (unsigned)cx <= (unsigned)(TILE - 4) && (unsigned)cy <= (unsigned)(TILE - 4));
-        if (__ballot(!fits) != 0ull) {
+        if (rt_ballot(!fits) != 0ull) {
             const FieldDev<T> F = rare_field(F_);
             if (cooldown == 0 && F.qx >= TILE && F.qy >= TILE) {
                 const int mnx = wave_min_i(active && regular ? c.lx - 3 : 0x7fffffff);
@@ -586,7 +590,7 @@ template <typename T, int PHASES = RTMI_TILE_PHASES> struct LdsGather {
     __device__ __forceinline__ void fetch(const FieldDev<T>& F, const Cell<T>& c, bool active, T z[4], Pair<T> g[4][4]) {
         int cx, cy;
         const bool fits = place(F, c, active, cx, cy);
-        if (__ballot(!fits) == 0ull) {
+        if (rt_ballot(!fits) == 0ull) {
             read_tile(cx, cy, z, g);              // the common case, wave-uniform: straight-line LDS reads
         } else if (fits) {
             read_tile(cx, cy, z, g);
@@ -605,7 +609,7 @@ template <typename T, int PHASES = RTMI_TILE_PHASES> struct LdsGather {
     __device__ __forceinline__ void lookup(const FieldDev<T>& F, const Cell<T>& c, bool active, T& n, T& gx, T& gy) {
         int cx, cy;
         const bool fits = place(F, c, active, cx, cy);
-        if (__ballot(!fits) == 0ull || fits) {   // every lane in the tile (the common, wave-uniform case), or this one is
+        if (rt_ballot(!fits) == 0ull || fits) {   // every lane in the tile (the common, wave-uniform case), or this one is
             if constexpr (PHASES > 1) {
             const RT_LDS Pair<T>* gw = gt + cy * GPITCH + cx;
             const RT_LDS T* zw = zt + (cy + 1) * ZPITCH + (cx + 1);
@@ -683,12 +687,6 @@ __device__ __forceinline__ void GlobalGather<T>::lookup(const FieldDev<T>& F, co
 // not-a-knot end cells included (tests/test_polytab_host.py) -- there is no rim case.  What is left of the old one is
 // FITPACK's argument clamp (quirk Q4) for a point outside the grid: per lane, behind a wave vote that only picks the layout.
 template <typename T> struct PolyCell { int cell; T u, v; };
-template <typename T> __device__ __forceinline__ void poly_axis(T x, T a, T b, T inv_h, int ncell, bool& in, T& xa, T& jf, int& j) {
-    xa = x - a;
-    jf = floor_(xa * inv_h);
-    j = (int)jf;
-    in = (unsigned)j < (unsigned)ncell;           // NaN converts to 0: "in", and the NaN flows through u
-}
 template <typename T> __device__ __forceinline__ void poly_axis_clamped(T x, T a, T b, T inv_h, int ncell, T& xa, T& jf, int& j) {
     x = x < a ? a : x;
     x = x > b ? b : x;
@@ -697,18 +695,20 @@ template <typename T> __device__ __forceinline__ void poly_axis_clamped(T x, T a
     jf = jf < T(0) ? T(0) : (jf > (T)(ncell - 1) ? (T)(ncell - 1) : jf);
     j = (int)jf;
 }
-template <typename T> __device__ __forceinline__ void poly_locate(const FieldDev<T>& F, T x, T y, bool active, PolyCell<T>& c) {
-    bool inx, iny;
-    T xa, ya, jfx, jfy;
-    int jx, jy;
-    poly_axis(x, F.ax, F.bx, F.inv_hx, F.ncx, inx, xa, jfx, jx);
-    poly_axis(y, F.ay, F.by, F.inv_hy, F.qy - 1, iny, ya, jfy, jy);
-    // an idle lane (a terminated ray's stale state drifts out of the grid) never addresses the table with its cell: no clamp
-    inx = inx || !active; iny = iny || !active;
-    if (__ballot(!(inx && iny)) != 0ull) {
+// live: the wave's vote on `active` (the caller has it anyway).  An idle lane (a terminated ray's stale state drifts out of the
+// grid) never addresses the table with its cell, so only LIVE lanes outside the grid send the wave into the clamp layout.
+// (The votes are combined as lane masks in scalar registers: booleans passed around by reference come back as byte values in
+// vector registers and cost a dozen vector instructions per step.)
+template <typename T>
+__device__ __forceinline__ void poly_locate(const FieldDev<T>& F, T x, T y, unsigned long long live, PolyCell<T>& c) {
+    T xa = x - F.ax, ya = y - F.ay;
+    T jfx = floor_(xa * F.inv_hx), jfy = floor_(ya * F.inv_hy);
+    int jx = (int)jfx, jy = (int)jfy;                // NaN converts to 0: "inside", and the NaN flows through u
+    const unsigned long long outx = rt_ballot((unsigned)jx >= (unsigned)F.ncx), outy = rt_ballot((unsigned)jy >= (unsigned)(F.qy - 1));
+    if (((outx | outy) & live) != 0ull) {
         const FieldDev<T> G = rare_field(F);
-        if (!inx) poly_axis_clamped(x, G.ax, G.bx, G.inv_hx, G.ncx, xa, jfx, jx);
-        if (!iny) poly_axis_clamped(y, G.ay, G.by, G.inv_hy, G.qy - 1, ya, jfy, jy);
+        if ((unsigned)jx >= (unsigned)G.ncx) poly_axis_clamped(x, G.ax, G.bx, G.inv_hx, G.ncx, xa, jfx, jx);
+        if ((unsigned)jy >= (unsigned)(G.qy - 1)) poly_axis_clamped(y, G.ay, G.by, G.inv_hy, G.qy - 1, ya, jfy, jy);
     }
     c.u = fma_(xa, F.inv_hx, -jfx);
     c.v = fma_(ya, F.inv_hy, -jfy);
@@ -868,9 +868,9 @@ template <typename T, int MODE> struct PolyGather {
     }
     __device__ __forceinline__ void lookup_xy(const FieldDev<T>& F, bool active, T x, T y, T& n, T& gx, T& gy) {
         PolyCell<T> c;
-        poly_locate(F, x, y, active, c);
+        const unsigned long long live = rt_ballot(active);
+        poly_locate(F, x, y, live, c);
         if constexpr (MODE == kPolyCached) {
-            const unsigned long long live = __ballot(active);
             const int cu = __builtin_amdgcn_readlane(c.cell, live ? __builtin_ctzll(live) : 0);
             bool useB;
             if (cu == tagA) useB = false;
@@ -885,7 +885,7 @@ template <typename T, int MODE> struct PolyGather {
             if (useB) eval_rows(rowsB, c.u, c.v, n, gx, gy);
             else eval_rows(rowsA, c.u, c.v, n, gx, gy);
             const bool rest = active && c.cell != cu;
-            const unsigned long long rem = __ballot(rest);
+            const unsigned long long rem = rt_ballot(rest);
             if (rem != 0ull) {
                 const int cu2 = __builtin_amdgcn_readlane(c.cell, __builtin_ctzll(rem));
                 if (useB) { if (cu2 != tagA) { load_rows(rowsA, F, cu2); tagA = cu2; } }
@@ -900,7 +900,6 @@ template <typename T, int MODE> struct PolyGather {
                 }
             }
         } else if constexpr (MODE == kPolyCached1) {
-            const unsigned long long live = __ballot(active);
             const int cu = __builtin_amdgcn_readlane(c.cell, live ? __builtin_ctzll(live) : 0);
             if (cu != tagA) { load_rows(rowsA, F, cu); tagA = cu; }
             eval_rows(rowsA, c.u, c.v, n, gx, gy);
@@ -908,14 +907,13 @@ template <typename T, int MODE> struct PolyGather {
         } else if constexpr (SCALAR) {
             // the first live lane's cell; when every live lane is in it (98 % of a fan's wave-steps) all lanes evaluate its
             // polynomial in straight-line code -- an idle lane too, at its own (u, v) in [0, 1)^2: finite, and nobody reads it
-            const unsigned long long live = __ballot(active);
             const int first = live ? __builtin_ctzll(live) : 0;
             int cu = __builtin_amdgcn_readlane(c.cell, first);
             // the entry's address is formed from the scalar and pinned to scalar registers BEFORE any comparison with the
             // per-lane cell: inside "cell == cu" the compiler would otherwise substitute the lane's value and load per lane
             ScalarRows p = (ScalarRows)(F.poly + (size_t)cu * kPolyStride);
             asm volatile("" : "+s"(p));
-            if (__ballot(active && c.cell != cu) == 0ull) {
+            if ((rt_ballot(c.cell != cu) & live) == 0ull) {
                 eval_scalar(p, c.u, c.v, n, gx, gy);
                 return;
             }
@@ -924,7 +922,7 @@ template <typename T, int MODE> struct PolyGather {
             bool todo = active;
 #pragma nounroll
             for (int round = 0; round < 2; ++round) {
-                if (__ballot(todo) == 0ull) break;
+                if (rt_ballot(todo) == 0ull) break;
                 if (todo) {
                     cu = __builtin_amdgcn_readfirstlane(c.cell);
                     p = (ScalarRows)(F.poly + (size_t)cu * kPolyStride);

@@ -859,7 +859,7 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
     }
     // one DELTA_S step of every lane; false once no lane of the wave is live
     auto one_step = [&]() -> bool {
-        if (__ballot(alive) == 0ull) return false;
+        if (rt_ballot(alive) == 0ull) return false;
         const bool active = alive;
         ++i;
         const bool inside = rt::ray_step<T, METHOD, ISO>(a.F, K, gather, active, r, i);
@@ -906,6 +906,9 @@ __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, lon
 // the field, so RTMI_XCD_GROUP consecutive bundles go to ONE XCD (its L2 then serves the second to G-th from the first's
 // misses) while the groups still interleave over the XCDs (a contiguous eighth of the fan per XCD is badly balanced:
 // DESIGN.md 5.1).  Identity for the blocks past the last whole round of 8 x G.
+#ifndef RTMI_BOX_IN_VGPRS
+#define RTMI_BOX_IN_VGPRS 0
+#endif
 #ifndef RTMI_XCD_GROUP
 #define RTMI_XCD_GROUP 8     // measured (A/B, one session): interface 24.6 -> 23.6 ms at 8, 24.0 at 4; vert, fisheye, fp32 unchanged
 #endif
@@ -954,6 +957,12 @@ __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, lon
     bool alive = k < a.R && ld_state<COH>(a.alive + (k < a.R ? k : 0));
     // VAR: every ray carries its own DELTA_S and max_size (the calibration sweep as one candidate x ray batch)
     rt::Consts<T> K = a.K;
+#if RTMI_BOX_IN_VGPRS
+    // the box of the boundary test as vector-register values: the step loop is short of scalar registers (it spills them to
+    // vector lanes and re-reads kernel arguments per recorded row) and has vector registers to spare
+#pragma unroll
+    for (int q = 0; q < 4; q++) asm volatile("" : "+v"(K.box[q]));
+#endif
     int max_size = a.max_size;
     if (VAR && a.vstep && k < a.R) { K.step = a.vstep[k]; K.step2h = a.vstep2h[k]; K.step2 = K.step2h * T(2); max_size = a.vmax[k]; }
     if (alive) load_ray<T, METHOD, ISO, COH>(a, k, r, i);
@@ -1107,7 +1116,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : light_method(METHOD) ? RT
     bool alive = false;
     bool exhausted = false;  // wave-uniform
     for (;;) {
-        unsigned long long live_mask = __ballot(alive);
+        unsigned long long live_mask = rt_ballot(alive);
         const int n_dead = 64 - __popcll(live_mask);
         if (!exhausted && (n_dead >= refill_min || live_mask == 0)) {
             unsigned long long base = 0;
@@ -1127,7 +1136,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : light_method(METHOD) ? RT
                 }
             }
             exhausted = base + (unsigned long long)n_dead >= (unsigned long long)a.R;
-            live_mask = __ballot(alive);
+            live_mask = rt_ballot(alive);
             __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): no state load pending into the step loop (see k_advance)
         }
         if (live_mask == 0) {
@@ -1135,7 +1144,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : light_method(METHOD) ? RT
             continue;  // the claimed rays were all finished already; claim again (the queue advanced)
         }
         for (int it = 0; it < chunk; ++it) {
-            if (__ballot(alive) == 0ull) break;
+            if (rt_ballot(alive) == 0ull) break;
             const bool active = alive;
             ++i;
             const bool inside = rt::ray_step<T, METHOD, ISO>(a.F, a.K, gather, active, r, i);
