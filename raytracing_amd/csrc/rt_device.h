@@ -6,6 +6,12 @@
 
 #include "rt_polytab.h"
 
+#ifndef RTMI_CHORD_SERIES
+// the step's arclength from the advancement's closed form (chord_length) instead of the positions: 1 for the first-order
+// advancement (op1/op2: the chord IS DELTA_S; op1 12.5 -> 11.8 ms), 2 for the second-order one as well (measured slower:
+// the vote and eps carried across the lookup cost more than the square root -- headline 14.9 -> 15.5 ms, cfg2 2.20 -> 2.48)
+#define RTMI_CHORD_SERIES 1
+#endif
 #ifndef RTMI_POLY_BATCH
 #define RTMI_POLY_BATCH 1     // scalar loads of a lookup: 0 row by row, 1 one spline + n then the other (measured best), 2 all at once (spills SGPRs)
 #endif
@@ -146,27 +152,58 @@ template <typename T> __device__ __forceinline__ void sincos_add_small(T s, T c,
     *so = fma_(c, sk, fma_(-s, ck1, s));
     *co = fma_(-s, sk, fma_(-c, ck1, c));
 }
-template <typename T> __device__ __forceinline__ void sincos_add(double theta, T s, T c, T k, T* so, T* co) {
-    const bool small = M<T>::abs_(k) < M<T>::small_angle;
-    // per-lane choice of formula; the vote only selects a layout without exec-mask bookkeeping for the common case
+// The same for |k| < 2^-9 (a turn of 0.1 degree per step: every step of the vert_heterogeneous and interface fans, 4e-4 and
+// less): one series term fewer each -- the dropped ones are k^6/5040 < 2^-66 of sin k and k^6/720 < 2^-63 of 1: nothing
+// in fp64 -- 10 instructions for 13.  Measured (A/B, one session, profiles/r03_ab_small_savings.txt): vert_heterogeneous without
+// recording 8.78 -> 8.52 ms, the recording headline unchanged, but fisheye -- whose turns are not tiny, and which now pays
+// a second vote -- 7.9 -> 8.7 ms and the few-waves build 2.20 -> 2.24: off.
+#ifndef RTMI_TINY_ROT
+#define RTMI_TINY_ROT 0
+#endif
+template <typename T> __device__ __forceinline__ void sincos_add_tiny(T s, T c, T k, T* so, T* co) {
+    const T z = k * k;
+    const T ps = fma_const(z, T(1.0 / 120.0), T(-1.0 / 6.0));
+    const T sk = fma_(z * k, ps, k);                 // sin k
+    const T pc = fma_const(z, T(-1.0 / 24.0), T(0.5));
+    const T ck1 = z * pc;                            // 1 - cos k
+    *so = fma_(c, sk, fma_(-s, ck1, s));
+    *co = fma_(-s, sk, fma_(-c, ck1, c));
+}
+// Which formula a lane uses depends on its own k only (tiny / small / a full evaluation at `target`); the votes select a
+// layout without exec-mask bookkeeping for the two common cases that every lane of the wave is tiny, or every lane small.
+// (the full evaluation is at base + (add_k ? k : 0), formed only where it is needed)
+template <typename T, bool ADD_K> __device__ __forceinline__ void sincos_add_select(double base, T s, T c, T k, T* so, T* co, bool refresh) {
+    const T ak = M<T>::abs_(k);
+    const bool small = ak < M<T>::small_angle && !refresh;
+#if RTMI_TINY_ROT
+    const bool tiny = ak < T(0.001953125) && !refresh;
+    if (rt_ballot(!tiny) == 0ull) {
+        sincos_add_tiny(s, c, k, so, co);
+    } else if (rt_ballot(!small || tiny) == 0ull) {
+        sincos_add_small(s, c, k, so, co);
+    } else if (tiny) {
+        sincos_add_tiny(s, c, k, so, co);
+    } else if (small) {
+        sincos_add_small(s, c, k, so, co);
+    } else {
+        M<T>::sincos_(ADD_K ? base + (double)k : base, so, co);
+    }
+#else
     if (rt_ballot(!small) == 0ull) {
         sincos_add_small(s, c, k, so, co);
     } else if (small) {
         sincos_add_small(s, c, k, so, co);
     } else {
-        M<T>::sincos_(theta + (double)k, so, co);
+        M<T>::sincos_(ADD_K ? base + (double)k : base, so, co);
     }
+#endif
+}
+template <typename T> __device__ __forceinline__ void sincos_add(double theta, T s, T c, T k, T* so, T* co) {
+    sincos_add_select<T, true>(theta, s, c, k, so, co, false);
 }
 // sin/cos of `target` == (angle of (s, c)) + k: by rotation when k is small and no refresh is due, else from scratch
 template <typename T> __device__ __forceinline__ void sincos_add(double target, T s, T c, T k, T* so, T* co, bool refresh) {
-    const bool small = M<T>::abs_(k) < M<T>::small_angle && !refresh;
-    if (rt_ballot(!small) == 0ull) {
-        sincos_add_small(s, c, k, so, co);
-    } else if (small) {
-        sincos_add_small(s, c, k, so, co);
-    } else {
-        M<T>::sincos_(target, so, co);
-    }
+    sincos_add_select<T, false>(target, s, c, k, so, co, refresh);
 }
 
 constexpr double kGoldRatio = 0.6180339887498949;   // (sqrt(5)-1)/2, RT_bench.py:65
@@ -996,16 +1033,40 @@ template <typename T> __device__ __forceinline__ void adv_first(const Ray<T>& r,
         fy = fma_(r.uy, step, r.y);
     }
 }
-template <typename T> __device__ __forceinline__ void adv_second(const Ray<T>& r, const Consts<T>& k, Acc& fx, Acc& fy) {
+// eps: the step's chord is DELTA_S sqrt(1 + eps) -- the displacement is DELTA_S u + (DELTA_S^2 / 2n) v with v = grad n - (grad n . u) u
+// perpendicular to the unit tangent u, so eps = (DELTA_S / 2n)^2 |v|^2 (see chord_length)
+template <typename T> __device__ __forceinline__ void adv_second(const Ray<T>& r, const Consts<T>& k, Acc& fx, Acc& fy, T& eps) {
     const T d = fma_(r.gy, r.uy, r.gx * r.ux);  // np.dot on 2 elements rounds exactly like this
     const T s = k.step2h * r.rn;                // step**2 / (2 n)
+    const T vx = fma_(-d, r.ux, r.gx), vy = fma_(-d, r.uy, r.gy);
     if constexpr (kMixed<T>) {
-        fx = r.x + (Acc)fma_(fma_(-d, r.ux, r.gx), s, r.ux * k.step);
-        fy = r.y + (Acc)fma_(fma_(-d, r.uy, r.gy), s, r.uy * k.step);
+        fx = r.x + (Acc)fma_(vx, s, r.ux * k.step);
+        fy = r.y + (Acc)fma_(vy, s, r.uy * k.step);
     } else {
-        fx = fma_(fma_(-d, r.ux, r.gx), s, fma_(r.ux, k.step, r.x));
-        fy = fma_(fma_(-d, r.uy, r.gy), s, fma_(r.uy, k.step, r.y));
+        fx = fma_(vx, s, fma_(r.ux, k.step, r.x));
+        fy = fma_(vy, s, fma_(r.uy, k.step, r.y));
     }
+#if RTMI_CHORD_SERIES > 1
+    const T q = (k.step * T(0.5)) * r.rn;       // the constant product folds on the host side of the loop
+    eps = q * q * fma_(vy, vy, vx * vx);
+#else
+    eps = T(-1);
+#endif
+}
+// The arclength of one step, np.linalg.norm(old - new) in the reference (:785).  The reference takes it from the ROUNDED
+// positions (a 2.6e-3 difference of coordinates of order 5: 2e-13 relative noise per step); from the advancement itself it is
+// DELTA_S sqrt(1 + eps) exactly, and for eps < 2^-26 (everywhere but within a few cells of the interface scenario's jump)
+// DELTA_S (1 + eps/2) to 2^-55: one fma instead of two subtractions, a square root by rsq + 6 and its transcendental.  eps < 0:
+// no closed form (curvature advancement): from the positions.  Per-lane choice; the vote selects the layout.
+template <typename T> __device__ __forceinline__ T chord_length(const Consts<T>& k, const Ray<T>& r, Acc fx, Acc fy, T eps) {
+#if RTMI_CHORD_SERIES
+    const bool series = eps >= T(0) && eps < T(1.4901161193847656e-08);
+    if (rt_ballot(!series) == 0ull) return fma_(k.step * T(0.5), eps, k.step);
+    if (series) return fma_(k.step * T(0.5), eps, k.step);
+    if (eps >= T(0)) return k.step * M<T>::sqrt_(T(1) + eps);
+#endif
+    const T dx = (T)(r.x - fx), dy = (T)(r.y - fy);
+    return M<T>::sqrt_(fma_(dy, dy, dx * dx));  // np.linalg.norm on 2 elements
 }
 // returns the reference's flag: true == curvature NOT negligible (quirk Q14)
 template <typename T> __device__ __forceinline__ bool adv_curv(const Ray<T>& r, const Consts<T>& k, Acc& fx, Acc& fy) {
@@ -1094,10 +1155,10 @@ __device__ __forceinline__ T ang_golden_aniso(const Ray<T>& r, const Consts<T>& 
 
 // ---- opN (:469-764), split around the field lookup: advancement, then angle determination
 template <typename T, int METHOD>
-__device__ __forceinline__ bool op_advance(const Consts<T>& k, const Ray<T>& r, Acc& fx, Acc& fy) {
-    if constexpr (METHOD == 1 || METHOD == 2) { adv_first(r, k.step, fx, fy); return true; }
-    else if constexpr (METHOD == 3 || METHOD == 4 || METHOD == 5 || METHOD == 10) return adv_curv(r, k, fx, fy);
-    else { adv_second(r, k, fx, fy); return true; }
+__device__ __forceinline__ bool op_advance(const Consts<T>& k, const Ray<T>& r, Acc& fx, Acc& fy, T& eps) {
+    if constexpr (METHOD == 1 || METHOD == 2) { adv_first(r, k.step, fx, fy); eps = RTMI_CHORD_SERIES ? T(0) : T(-1); return true; }   // |u| = 1: the chord is DELTA_S
+    else if constexpr (METHOD == 3 || METHOD == 4 || METHOD == 5 || METHOD == 10) { eps = T(-1); return adv_curv(r, k, fx, fy); }
+    else { adv_second(r, k, fx, fy, eps); return true; }
 }
 template <typename T, int METHOD>
 __device__ __forceinline__ Acc op_angle(const Consts<T>& k, const Ray<T>& r, bool flag, Acc fx, Acc fy, T fn, T fgx, T fgy, T frn) {
@@ -1119,9 +1180,8 @@ __device__ __forceinline__ Acc op_angle(const Consts<T>& k, const Ray<T>& r, boo
 // store_update_results (:783-790) + the row bookkeeping of the loop body (:871-875)
 template <typename T, bool ISO, bool ROT = false>
 __device__ __forceinline__ void store_update(const Consts<T>& k, Ray<T>& r, Acc fx, Acc fy, Acc fth, T fn, T fgx, T fgy,
-                                             T frn, bool refresh = false) {
-    const T dx = (T)(r.x - fx), dy = (T)(r.y - fy);
-    const T dist = M<T>::sqrt_(fma_(dy, dy, dx * dx));  // np.linalg.norm on 2 elements
+                                             T frn, T eps, bool refresh = false) {
+    const T dist = chord_length(k, r, fx, fy, eps);
     r.dsim += (Acc)dist;
     r.dreal += (Acc)k.step;  // quirk Q16: accumulated, not i*step
     T s, c;
@@ -1206,7 +1266,8 @@ __device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& 
     } else {
     Acc fx, fy, fth;
     T fn, fgx, fgy;
-    const bool flag = op_advance<T, METHOD>(k, r, fx, fy);
+    T eps;
+    const bool flag = op_advance<T, METHOD>(k, r, fx, fy, eps);
     n_gradient(F, gather, active, (T)fx, (T)fy, fn, fgx, fgy);
     const T frn = rcp_full(fn);
     bool boot = false;
@@ -1220,9 +1281,9 @@ __device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& 
         fth = op_angle<T, METHOD>(k, r, flag, fx, fy, fn, fgx, fgy, frn);
     }
     if constexpr (RotatesUnit<T, METHOD>::value)
-        store_update<T, ISO, true>(k, r, fx, fy, fth, fn, fgx, fgy, frn, (i & (RotatesUnit<T, METHOD>::refresh - 1)) == 0);
+        store_update<T, ISO, true>(k, r, fx, fy, fth, fn, fgx, fgy, frn, eps, (i & (RotatesUnit<T, METHOD>::refresh - 1)) == 0);
     else
-        store_update<T, ISO>(k, r, fx, fy, fth, fn, fgx, fgy, frn);
+        store_update<T, ISO>(k, r, fx, fy, fth, fn, fgx, fgy, frn, eps);
     return boot || !outside(k, r);
     }
 }
