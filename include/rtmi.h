@@ -233,6 +233,12 @@ void rtmi_batch_destroy(rtmi_batch *b);
  * glibc 2.35's sin()/cos(), i.e. numpy's np.sin/np.cos, bit for bit for |x| < 105414350) evaluated on the device
  * for n host values.  s[n], c[n]: host, fp64. */
 int rtmi_debug_sincos(int64_t n, const double *x, double *s, double *c);
+/* Diagnostic: the lookup the fast-form step methods (op1/2/6/7/8, every fp32 batch) make -- the grid cell's polynomial
+ * (one per cell, converted from FITPACK's splines on the true knots at field build) -- for npts host points
+ * -> n, dn/dx, dn/dy (host, fp64).  Within 1e-15 of the field's scale of rtmi_field_eval (FITPACK's own arithmetic,
+ * n_gradient :141-156) in every cell; tests compare it bit for bit with the host restatement of the same table. */
+int rtmi_debug_field_lookup(const rtmi_field *f, int64_t npts, const double *x, const double *y, double *n,
+                            double *gx, double *gy);
 
 #ifdef __cplusplus
 }

@@ -80,6 +80,7 @@ SYMBOLS = {
     "rtmi_batch_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "rtmi_batch_destroy": (None, [C.c_void_p]),
     "rtmi_debug_sincos": (C.c_int, [C.c_int64, _dp, _dp, _dp]),
+    "rtmi_debug_field_lookup": (C.c_int, [C.c_void_p, C.c_int64] + [_dp] * 5),
 }
 
 _lib = None

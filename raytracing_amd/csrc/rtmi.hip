@@ -281,14 +281,21 @@ __global__ void k_polytab(const double* Z, const double* cdx, const double* cdy,
     for (int i = 36; i < rt::kPolyStride; i++) o[i] = T(0);
 }
 
-template <typename T>
+// FAST: the fast-form step methods' lookup (the cell's polynomial, one lane per point); else FITPACK's arithmetic on the
+// B-spline window (the field is passed with exact = 1)
+template <typename T, bool FAST>
 __global__ void k_field_eval(rt::FieldDev<T> F, long npts, const double* x, const double* y, double* n, double* gx,
                              double* gy) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= npts) return;
     T a, b, c;
-    rt::GlobalGather<T> gg;
-    rt::n_gradient(F, gg, true, (T)x[i], (T)y[i], a, b, c);
+    if constexpr (FAST) {
+        rt::PolyGather<T, rt::kPolyLane> gg;
+        rt::n_gradient(F, gg, true, (T)x[i], (T)y[i], a, b, c);
+    } else {
+        rt::GlobalGather<T> gg;
+        rt::n_gradient(F, gg, true, (T)x[i], (T)y[i], a, b, c);
+    }
     n[i] = a; gx[i] = b; gy[i] = c;
 }
 
@@ -546,11 +553,11 @@ RTMI_EXPORT int rtmi_field_read(const rtmi_field* f, double* x, double* y, doubl
     return RTMI_OK;
 }
 
-RTMI_EXPORT int rtmi_field_eval(const rtmi_field* f, int64_t npts, const double* x, const double* y, double* n,
-                                double* gx, double* gy) {
-    ARG_TRY(f && x && y && n && gx && gy, "rtmi_field_eval: null");
-    ARG_TRY(npts >= 0, "rtmi_field_eval: npts < 0");
-    DEVICE_TRY(f, "rtmi_field_eval");
+static int field_eval_impl(const rtmi_field* f, int64_t npts, const double* x, const double* y, double* n, double* gx,
+                           double* gy, bool fast, const char* who) {
+    if (!(f && x && y && n && gx && gy)) return fail(RTMI_ERR_ARG, std::string(who) + ": null");
+    if (npts < 0) return fail(RTMI_ERR_ARG, std::string(who) + ": npts < 0");
+    DEVICE_TRY(f, who);
     if (npts == 0) return RTMI_OK;
     double* d = nullptr;
     const size_t nb = (size_t)npts * sizeof(double);
@@ -561,20 +568,30 @@ RTMI_EXPORT int rtmi_field_eval(const rtmi_field* f, int64_t npts, const double*
         if (hipMemcpyAsync(d, x, nb, hipMemcpyHostToDevice, st) != hipSuccess ||
             hipMemcpyAsync(d + npts, y, nb, hipMemcpyHostToDevice, st) != hipSuccess) { rc = RTMI_ERR_HIP; break; }
         const dim3 g((unsigned)((npts + 255) / 256)), b(256);
-        if (f->dtype == RTMI_F64)
-            hipLaunchKernelGGL(k_field_eval<double>, g, b, 0, st, field_dev<double>(f, 1), (long)npts, d, d + npts,
-                               d + 2 * npts, d + 3 * npts, d + 4 * npts);
-        else
-            hipLaunchKernelGGL(k_field_eval<float>, g, b, 0, st, field_dev<float>(f, 1), (long)npts, d, d + npts,
-                               d + 2 * npts, d + 3 * npts, d + 4 * npts);
+        double *dn = d + 2 * npts, *dgx = d + 3 * npts, *dgy = d + 4 * npts;
+        if (f->dtype == RTMI_F64) {
+            if (fast) hipLaunchKernelGGL((k_field_eval<double, true>), g, b, 0, st, field_dev<double>(f, 0), (long)npts, d, d + npts, dn, dgx, dgy);
+            else hipLaunchKernelGGL((k_field_eval<double, false>), g, b, 0, st, field_dev<double>(f, 1), (long)npts, d, d + npts, dn, dgx, dgy);
+        } else {
+            if (fast) hipLaunchKernelGGL((k_field_eval<float, true>), g, b, 0, st, field_dev<float>(f, 0), (long)npts, d, d + npts, dn, dgx, dgy);
+            else hipLaunchKernelGGL((k_field_eval<float, false>), g, b, 0, st, field_dev<float>(f, 1), (long)npts, d, d + npts, dn, dgx, dgy);
+        }
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { rc = RTMI_ERR_HIP; break; }
-        if (hipMemcpy(n, d + 2 * npts, nb, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(gx, d + 3 * npts, nb, hipMemcpyDeviceToHost) != hipSuccess ||
-            hipMemcpy(gy, d + 4 * npts, nb, hipMemcpyDeviceToHost) != hipSuccess) rc = RTMI_ERR_HIP;
+        if (hipMemcpy(n, dn, nb, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(gx, dgx, nb, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(gy, dgy, nb, hipMemcpyDeviceToHost) != hipSuccess) rc = RTMI_ERR_HIP;
     } while (0);
     (void)hipFree(d);
-    if (rc) return fail(rc, "rtmi_field_eval: HIP failure");
+    if (rc) return fail(rc, std::string(who) + ": HIP failure");
     return RTMI_OK;
+}
+RTMI_EXPORT int rtmi_field_eval(const rtmi_field* f, int64_t npts, const double* x, const double* y, double* n,
+                                double* gx, double* gy) {
+    return field_eval_impl(f, npts, x, y, n, gx, gy, false, "rtmi_field_eval");
+}
+RTMI_EXPORT int rtmi_debug_field_lookup(const rtmi_field* f, int64_t npts, const double* x, const double* y, double* n,
+                                        double* gx, double* gy) {
+    return field_eval_impl(f, npts, x, y, n, gx, gy, true, "rtmi_debug_field_lookup");
 }
 
 // ================================================================== ray batch
@@ -839,6 +856,10 @@ template <typename T, int METHOD, bool ISO, typename G, bool UROW, bool COH = fa
 __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Consts<T>& K, G& gather, rt::Ray<T>& r, long k, int& i,
                                              bool& alive, int max_size, int nsteps, long blk) {
     const bool RECORD = a.stride != 0;
+    // the record stride as an opaque scalar-register value: left as a kernel argument the compiler re-reads it from the
+    // argument segment for every recorded row (s_load + s_waitcnt lgkmcnt(0): a scalar-cache round trip per row)
+    int stride = a.stride;
+    asm volatile("" : "+s"(stride));
     int until = 0;
     long row = 0;
     // UROW: scalar row bookkeeping common to the live lanes: steps until the next recorded row, rows that may still be
@@ -848,14 +869,14 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
     const int voff = (int)(threadIdx.x * sizeof(T));
     if (UROW && RECORD) {
         const int i0 = __builtin_amdgcn_readfirstlane(rt::wave_max_i(alive ? i : 0));
-        const int row0 = i0 / a.stride;
-        until = a.stride - (i0 % a.stride);
+        const int row0 = i0 / stride;
+        until = stride - (i0 % stride);
         rows_left = (int)(a.rec_rows - 1 - row0 < 0x7fffffffL ? a.rec_rows - 1 - row0 : 0x7fffffffL);
         rowp = a.s_ray + (size_t)row0 * 6 * a.R + blk;
         nrowp = a.n_ray ? a.n_ray + (size_t)row0 * a.R + blk : nullptr;
     } else if (RECORD && alive) {
-        until = a.stride - (i % a.stride);   // steps until the next recorded row
-        row = i / a.stride;
+        until = stride - (i % stride);   // steps until the next recorded row
+        row = i / stride;
     }
     // one DELTA_S step of every lane; false once no lane of the wave is live
     auto one_step = [&]() -> bool {
@@ -865,7 +886,7 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
         const bool inside = rt::ray_step<T, METHOD, ISO>(a.F, K, gather, active, r, i);
         if (UROW && RECORD) {
             if (--until == 0) {
-                until = a.stride;
+                until = stride;
                 rowp += 6 * a.R;
                 if (nrowp) nrowp += a.R;
                 if (--rows_left >= 0 && active) write_row_uniform(a, rowp, nrowp, voff, r);
@@ -874,7 +895,7 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
         if (active) {
             if (!UROW && RECORD) {
                 if (--until == 0) {
-                    until = a.stride;
+                    until = stride;
                     ++row;
                     if (row < a.rec_rows) write_row(a, row, k, r);
                 }

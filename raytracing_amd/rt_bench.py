@@ -205,6 +205,14 @@ class Field:
         check(lib().rtmi_field_eval(self._h, len(x), dptr(x), dptr(y), dptr(n), dptr(gx), dptr(gy)))
         return n, gx, gy
 
+    def lookup_fast(self, x, y):
+        """The fast-form step methods' own lookup (the cell's polynomial, rtmi_debug_field_lookup) -> n, dn/dx, dn/dy."""
+        x = np.ascontiguousarray(np.atleast_1d(x), dtype=np.float64)
+        y = np.ascontiguousarray(np.atleast_1d(y), dtype=np.float64)
+        n = np.empty_like(x); gx = np.empty_like(x); gy = np.empty_like(x)
+        check(lib().rtmi_debug_field_lookup(self._h, len(x), dptr(x), dptr(y), dptr(n), dptr(gx), dptr(gy)))
+        return n, gx, gy
+
     def close(self):
         if self._h:
             lib().rtmi_field_destroy(self._h)

@@ -6,6 +6,8 @@ golden vectors captured from the reference.  Tolerances (fp64):
     (SURVEY.md section 7); they run in the reference's own operation order (rt_exact.h) and are held to 1e-9 on
     every ray here and to the oracle's exact bits in tests/test_gpu_exact.py.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1222,3 +1224,40 @@ def test_wavefronts_large_fan_properties(rb, gpu_fields):
         assert np.median(w["angle_diff"]) < 1e-3 and w["angle_diff"][100:-100].max() < 2e-2
         assert np.all(np.diff(w["y_fine"]) > 0) and w["y_fine"][0] == w["y"][0] and w["y_fine"][-1] == w["y"][-1]
         assert np.abs(np.interp(w["y_fine"], w["y"], w["x"]) - w["x_fine"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("scen", ["vert_heterogeneous", "fisheye", "interface"])
+def test_cell_polynomial_lookup_on_the_device(scen, rb, gpu_fields, oracle_fields, tmp_path_factory):
+    """The fast-form methods' lookup (rtmi_debug_field_lookup: one polynomial per grid cell, rt_polytab.h) on the device:
+      * bit for bit the host restatement (tests/native/polytab_check.cpp: the table built by the library's own host
+        functions from the oracle's coefficient arrays -- which are the device's bits -- and looked up in the same operation
+        order): the device's table IS that table, in every cell, rim cells and clamped points included;
+      * within 2e-15 of the field's scale of FITPACK's own evaluation (the oracle's n_gradient = the reference's bits)."""
+    import ctypes as C
+    import subprocess
+    from test_polytab_host import _table, _eval, ROOT, _dp
+    so = str(tmp_path_factory.mktemp("polytab_gpu") / "libpolytab_check.so")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC", "-o", so,
+                           os.path.join(ROOT, "tests", "native", "polytab_check.cpp")])
+    L = C.CDLL(so)
+    L.polytab_build.argtypes = [_dp, C.c_int, _dp, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _dp]
+    L.polytab_eval.argtypes = [_dp, C.c_int, C.c_int] + [C.c_double] * 6 + [C.c_long, _dp, _dp, _dp, _dp, _dp]
+    F, OF = gpu_fields(scen), oracle_fields(scen)
+    x, y, Z, cdy, cdx = OF.arrays()
+    for a, b in zip(F.arrays()[2:], (Z, cdy, cdx)):
+        assert np.array_equal(a, b)                   # the device's coefficient arrays are the oracle's bits
+    tab, ihx, ihy = _table(L, x, y, Z, cdy, cdx)
+    rng = np.random.default_rng(17)
+    N = 100_000
+    px = np.concatenate([rng.uniform(x[0], x[-1], N), rng.uniform(x[0], x[3], N // 10), rng.uniform(x[-4], x[-1], N // 10),
+                         rng.uniform(x[0] - 1, x[-1] + 1, N // 10), x[[0, 1, 2, -3, -2, -1]]])
+    py = np.concatenate([rng.uniform(y[0], y[-1], N), rng.uniform(y[0], y[-1], N // 10), rng.uniform(y[-4], y[-1], N // 10),
+                         rng.uniform(y[0] - 1, y[-1] + 1, N // 10), y[[0, 1, 2, -3, -2, -1]]])
+    dev = F.lookup_fast(px, py)
+    host = _eval(L, tab, x, y, ihx, ihy, px, py)
+    for name, a, b in zip(("n", "dn/dx", "dn/dy"), dev, host):
+        assert np.array_equal(a, b), name
+    want = OF.n_gradient(px, py)
+    gscale = max(np.abs(cdx).max(), np.abs(cdy).max())
+    for a, b, scale in zip(dev, want, (np.abs(Z).max(), gscale, gscale)):
+        assert np.abs(a - b).max() < 2e-15 * scale
