@@ -223,7 +223,7 @@ __device__ __forceinline__ double ang_cost(const Ray<double>& r, double step, do
 // the reference does.  Either way the outcome is the reference's, so a, b, c, d -- advanced with the reference's own
 // unfused bracket arithmetic -- are its bits, and so is the returned midpoint.
 //
-//   Phase A (the first kGoldTaylorFrom iterations, bracket width pi .. ~5e-3): one new FAST cost value per iteration.  Of
+//   Phase A (the first kGoldTaylorFrom iterations, bracket width pi .. ~1e-2): one new FAST cost value per iteration.  Of
 //     the two points of the new bracket one is the previous iteration's better point ("survivor"; equal up to a few ulps of t
 //     to the point the reference would evaluate again), the other is the survivor moved by h_j = pi*GR^(j+4) towards the
 //     kept side; its sin/cos come from rotating the survivor's through h_j (table rt_golden_rot.h), no sincos evaluation.
@@ -237,7 +237,8 @@ __device__ __forceinline__ double ang_cost(const Ray<double>& r, double step, do
 //     and since xi_c < xi_d the reference's outcome F(c) < F(d) is V > 0 -- for certain when |V| (d - c) exceeds the remainder
 //     bound M4 rho^4/12 (rho = max |xi|, M4 >= |d4F/dt4| from suprema of the momentum curve's derivatives, Consts::gold_sup)
 //     plus the rounding error the reference's arithmetic can have made in its two values (the same g*K1 + f*K2 + K3 with
-//     g <= g0 + 2 E1 rho) plus the error of V's coefficients.  ~34 instructions per iteration against ~90 in phase A.  The
+//     g <= g0 + 2 E1 rho) plus the error of V's coefficients.  24 vector instructions per iteration (the threshold is kept between iterations and
+//     refreshed only where it does not decide, see below) against 58 in phase A.  The
 //     minimiser stays inside every bracket, so rho shrinks with the bracket and the comparison is decided by the sign of V in
 //     all but ~4e-3 of the steps (the reference's own rounding noise in its last three iterations).
 struct GoldBounds { double K1, LIP, K2, K3; };
@@ -245,7 +246,7 @@ struct GoldBounds { double K1, LIP, K2, K3; };
 struct GoldExpansion { double g0, F1, F2, F3; };
 
 #ifndef RTMI_GOLD_TAYLOR_FROM
-#define RTMI_GOLD_TAYLOR_FROM 14   // iterations of phase A; bracket width pi*GR^14 = 3.7e-3 when phase T takes over
+#define RTMI_GOLD_TAYLOR_FROM 12   // iterations of phase A; bracket width pi*GR^12 = 9.8e-3 when phase T takes over
 #endif
 constexpr int kGoldTaylorFrom = RTMI_GOLD_TAYLOR_FROM;
 static_assert(kGoldTaylorFrom <= RT_GOLD_ROT_ENTRIES, "phase A rotates through rt_golden_rot.h");
@@ -309,7 +310,7 @@ __device__ __forceinline__ double golden_filtered(FastA fast_a, double EA, Expan
     const double eps0 = kU * (16.0 + 4.0 * __builtin_fabs(th));
     const double F2h = 0.5 * T.F2, F36 = T.F3 * (1.0 / 6.0);
     // |d4F/dt4| <= 4 (E0 E4 + 4 E1 E3 + 3 E2^2), E0 = sup |e| <= g0 + E1 rho, for rho <= kRhoMax
-    constexpr double kRhoMax = 0.0078125;
+    constexpr double kRhoMax = 0.015625;
     const double M4c = (1.001 / 12.0) * 4.0 * fma_(T.g0 + E[1] * kRhoMax, E[4], fma_(4.0 * E[1], E[3], 3.0 * E[2] * E[2]));
     // V's coefficients: F1 = 2 e.e1 inherits e's absolute error e_abs (e is a cancelled difference, its derivative is not);
     // F2, F3 and the evaluation of V a relative 64u of their terms (|sigma| <= 2 rho, |pi2| <= 3 rho^2)
@@ -319,17 +320,32 @@ __device__ __forceinline__ double golden_filtered(FastA fast_a, double EA, Expan
     // outside what the bounds were derived for (never on the path): every comparison goes to the reference's arithmetic
     const bool ok = X0.F2 > 0.0 && T.F2 > 0.0 && __builtin_fabs(xs) < 0.03125 && __builtin_fabs(T.F3) < 1e300 && M4c < 1e300;
     double invd = 1.002 / (d - c);                              // 1/(d - c): slack for the recurrence against the rounded widths
+    // The threshold is thrA / (d - c) + thrB with thrA = M4c rho^4 + noise(rho), thrB = rho (rho cF3 + cF2) + errV0, both
+    // increasing in rho, and rho never grows (every c, d lies inside the bracket before): a threshold formed from an EARLIER
+    // iteration's thrA, thrB is still a valid one.  So they are refreshed only for a lane whose comparison the kept pair does
+    // not decide -- the first two or three iterations, where the remainder term still matters, and the last three, where the
+    // reference's own noise does -- and the ~17 iterations between cost one fma for their threshold instead of ten
+    // instructions.  Starting values: rho of the whole bracket.
+    double thrA, thrB;
+    bool rho_ok;
+    auto refresh = [&](double rho) {
+        const double Gb = fma_(E1x2, rho, T.g0);
+        const double noise = fma_(2.0 * Gb, fma_(B.K2, Gb, B.K1), K3x2);
+        const double r2 = rho * rho;
+        thrA = fma_(M4c * r2, r2, noise);
+        thrB = fma_(rho, fma_(rho, cF3, cF2), errV0);
+        rho_ok = ok && rho < kRhoMax;
+    };
+    refresh(__builtin_fmax(__builtin_fabs(a - t0), __builtin_fabs(b - t0)));
     for (; it < kGoldMaxIter && __builtin_fabs(c - d) > tol; ++it) {
         const double xc = c - t0, xd = d - t0;
         const double sg = xc + xd, p2 = fma_(sg, sg, -(xc * xd));
         const double V = fma_(F36, p2, fma_(F2h, sg, T.F1));
-        const double rho = __builtin_fmax(__builtin_fabs(xc), __builtin_fabs(xd));
-        const double Gb = fma_(E1x2, rho, T.g0);
-        const double noise = fma_(2.0 * Gb, fma_(B.K2, Gb, B.K1), K3x2);
-        const double r2 = rho * rho;
-        const double thr = fma_(fma_(M4c * r2, r2, noise), invd, fma_(rho, fma_(rho, cF3, cF2), errV0));
         bool lt = V > 0.0;
-        if (!(ok && __builtin_fabs(V) > thr && rho < kRhoMax)) lt = exact(c) < exact(d);   // also when anything is NaN
+        if (!(rho_ok && __builtin_fabs(V) > fma_(thrA, invd, thrB))) {      // also when anything is NaN
+            refresh(__builtin_fmax(__builtin_fabs(xc), __builtin_fabs(xd)));
+            if (!(rho_ok && __builtin_fabs(V) > fma_(thrA, invd, thrB))) lt = exact(c) < exact(d);
+        }
         if (lt) b = d; else a = c;
         c = b - (b - a) * GR;
         d = a + (b - a) * GR;
