@@ -246,7 +246,7 @@ struct GoldBounds { double K1, LIP, K2, K3; };
 struct GoldExpansion { double g0, F1, F2, F3; };
 
 #ifndef RTMI_GOLD_TAYLOR_FROM
-#define RTMI_GOLD_TAYLOR_FROM 12   // iterations of phase A; bracket width pi*GR^12 = 9.8e-3 when phase T takes over
+#define RTMI_GOLD_TAYLOR_FROM 11   // iterations of phase A; bracket width pi*GR^11 = 1.6e-2 when phase T takes over (A/B: 14: 170 ms for cfg5, 12: 159.5, 11: 156.4, 10: 160, 9: 164)
 #endif
 constexpr int kGoldTaylorFrom = RTMI_GOLD_TAYLOR_FROM;
 static_assert(kGoldTaylorFrom <= RT_GOLD_ROT_ENTRIES, "phase A rotates through rt_golden_rot.h");
@@ -310,7 +310,10 @@ __device__ __forceinline__ double golden_filtered(FastA fast_a, double EA, Expan
     const double eps0 = kU * (16.0 + 4.0 * __builtin_fabs(th));
     const double F2h = 0.5 * T.F2, F36 = T.F3 * (1.0 / 6.0);
     // |d4F/dt4| <= 4 (E0 E4 + 4 E1 E3 + 3 E2^2), E0 = sup |e| <= g0 + E1 rho, for rho <= kRhoMax
-    constexpr double kRhoMax = 0.015625;
+#ifndef RTMI_GOLD_RHO_MAX
+#define RTMI_GOLD_RHO_MAX 0.03125
+#endif
+    constexpr double kRhoMax = RTMI_GOLD_RHO_MAX;
     const double M4c = (1.001 / 12.0) * 4.0 * fma_(T.g0 + E[1] * kRhoMax, E[4], fma_(4.0 * E[1], E[3], 3.0 * E[2] * E[2]));
     // V's coefficients: F1 = 2 e.e1 inherits e's absolute error e_abs (e is a cancelled difference, its derivative is not);
     // F2, F3 and the evaluation of V a relative 64u of their terms (|sigma| <= 2 rho, |pi2| <= 3 rho^2)
