@@ -276,7 +276,13 @@ __device__ __forceinline__ double golden_filtered(FastA fast_a, double EA, Expan
         fast_a(sX, cX, fX, gX);
         fast_a(sY, cY, fY, gY);
         bool x_is_c = true;
+        // the rotation (sin h_j, cos h_j) of iteration j is asked for one iteration ahead: read where it is used it is a
+        // scalar load with its wait right behind it, eleven scalar-cache round trips per step
+        double sh_next = kGoldRot[0], ch_next = kGoldRot[1];
+        static_assert(kGoldTaylorFrom < RT_GOLD_ROT_ENTRIES, "the look-ahead reads entry kGoldTaylorFrom");
         for (; it < kGoldTaylorFrom && __builtin_fabs(c - d) > tol; ++it) {
+            const double sh_now = sh_next, ch = ch_next;
+            sh_next = kGoldRot[2 * it + 2]; ch_next = kGoldRot[2 * it + 3];
             const double bound = fma_(gX + gY, K1A, fma_(fX + fY, B.K2, K3A));
             bool xless = fX < fY;
             bool lt = xless == x_is_c;
@@ -288,8 +294,8 @@ __device__ __forceinline__ double golden_filtered(FastA fast_a, double EA, Expan
             c = b - (b - a) * GR;
             d = a + (b - a) * GR;
             if (!xless) { fX = fY; gX = gY; sX = sY; cX = cY; }
-            const double ch = kGoldRot[2 * it + 1];
-            const double sh = lt ? -kGoldRot[2 * it] : kGoldRot[2 * it];
+            // -sin h_j when the lower part of the bracket is kept: the sign bit flipped by the outcome's lane mask
+            const double sh = __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, sh_now) ^ (lt ? 0x8000000000000000ull : 0ull));
             sY = fma_(cX, sh, sX * ch);
             cY = fma_(-sX, sh, cX * ch);
             fast_a(sY, cY, fY, gY);
