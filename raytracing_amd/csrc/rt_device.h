@@ -12,6 +12,9 @@
 // the vote and eps carried across the lookup cost more than the square root -- headline 14.9 -> 15.5 ms, cfg2 2.20 -> 2.48)
 #define RTMI_CHORD_SERIES 1
 #endif
+#ifndef RTMI_KEPT_SCALAR_LOAD
+#define RTMI_KEPT_SCALAR_LOAD 0   // the few-waves build reloads its kept cell with vector loads (0) or through the scalar cache + 72 copies (1: measured slower, cfg2 2.25 -> 2.54 ms)
+#endif
 #ifndef RTMI_POLY_BATCH
 #define RTMI_POLY_BATCH 1     // scalar loads of a lookup: 0 row by row, 1 one spline + n then the other (measured best), 2 all at once (spills SGPRs)
 #endif
@@ -226,6 +229,9 @@ template <typename T> struct FieldDev {
     // fast-form step methods evaluate (PolyGather below); zn / g serve the reference-order methods and rtmi_field_eval
     const T* poly;
     int ncx;     // cells per grid row, qx - 1
+    // rdx / rdy: [q][8] fp64, per cell index of an axis the correctly rounded reciprocals of the seven knot differences
+    // FITPACK's fpbspl divides by there (rt_exact.h, axis_exact); nullptr in fp32 fields (the reference-order path is fp64)
+    const double *rdx, *rdy;
 };
 
 // Rare branches of the step loop (a lookup near the grid's rim, re-staging the LDS tile, a lane falling back to a global
@@ -893,6 +899,23 @@ template <typename T, int MODE> struct PolyGather {
         n = poly_bilinear<T, 2>(rows[N == 9 ? 8 : 0], u, v);
     }
     template <int N> static __device__ __forceinline__ void load_rows(Quad<T> (&rows)[N], const FieldDev<T>& F, int cu) {
+#if RTMI_KEPT_SCALAR_LOAD
+        // through the scalar cache, then copied into the vector registers that keep them.  As vector loads (every lane the
+        // same address) they had to be retired with vmcnt(0) before the step loop went on -- left pending, every later step's
+        // first use of a row waits for vmcnt(0) -- and on gfx9's single in-order counter that also waits for every trajectory
+        // store still on its way to HBM: a microsecond per cell change while recording.  Scalar loads wait on lgkmcnt alone.
+        ScalarRows p = (ScalarRows)(F.poly + (size_t)cu * kPolyStride);
+        asm volatile("" : "+s"(p));
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const Quad<T> a = p[k];
+            // pinned to vector registers: known to be wave-uniform the compiler keeps all 72 values in scalar registers
+            // across the step loop and copies every one of them per lookup
+            T x = a.x, y = a.y, z = a.z, w = a.w;
+            asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w));
+            rows[k] = Quad<T>{x, y, z, w};
+        }
+#else
         // every lane loads the same 288 bytes (one address per instruction: a broadcast in the texture path)
         typedef const Quad<T> __attribute__((address_space(1)))* GlobalRows;
         GlobalRows p = (GlobalRows)(F.poly + (size_t)cu * kPolyStride);
@@ -902,6 +925,7 @@ template <typename T, int MODE> struct PolyGather {
         // retire the loads here, in the rare branch: left pending they make every later step's first use of a row wait for
         // vmcnt(0), which also counts the trajectory stores of the step before
         __builtin_amdgcn_s_waitcnt(0x0F70);
+#endif
     }
     __device__ __forceinline__ void lookup_xy(const FieldDev<T>& F, bool active, T x, T y, T& n, T& gx, T& gy) {
         PolyCell<T> c;

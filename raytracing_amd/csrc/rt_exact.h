@@ -96,12 +96,28 @@ __device__ __forceinline__ double impulse(double a, double b, double step) { ret
 // ---------------------------------------------------------------- n_gradient in FITPACK's arithmetic
 // One axis: fpbisp's clamp + interval search (through rt::locate, exact on the true knots) and fpbspl for k = 1
 // and k = 3 with IEEE divisions and separate multiply/add, exactly as oracle/rt_oracle.c fpbspl().
-__device__ __forceinline__ void axis_exact(double v, int q, double a, double h, double b, double ih, int& j, int& l,
+//
+// The seven divisions of one axis all divide by a difference of knots, and a cell has only one set of them: the field build
+// tabulates their CORRECTLY ROUNDED reciprocals per cell index (rd[j][0..6], fp_recip_build on the host: the same knots by
+// the same operations, then an IEEE division).  1.0 / d is then the table value itself, and a / d is Markstein's division
+//     q0 = a r,   e = a - d q0  (exact: one fma),   q = q0 + e r  (one fma)      with r = RN(1 / d)
+// which returns the correctly rounded quotient (Markstein 1990; Cornea, Harrison, Tang: Scientific Computing on Itanium,
+// thm 8.3 -- no overflow or underflow here: 0 <= a <= 1, d ~ the grid pitch): 3 instructions for the 11 of the IEEE sequence
+// (v_div_scale x2, v_rcp, four fma, v_div_fmas, v_div_fixup), 110 fewer per lookup.  Bits: every test that holds a
+// reference-order method to the oracle's bits runs through it (the oracle divides).
+__device__ __forceinline__ double mdiv(double a, double d, double r) {
+    const double q0 = a * r;
+    return fma_(fma_(-d, q0, a), r, q0);
+}
+__device__ __forceinline__ void axis_exact(double v, int q, double a, double h, double b, double ih, const double* rd, int& j, int& l,
                                            double wl[2], double w[4]) {
     double t0, t1;
     j = locate(v, q, a, h, b, ih, t0, t1);      // v is clamped in place (quirk Q4)
+    // the cell's seven reciprocals: two 32-byte rows (L1-resident: q x 64 bytes per axis)
+    typedef double Quad4 __attribute__((ext_vector_type(4)));
+    const Quad4 ra = *reinterpret_cast<const Quad4*>(rd + (size_t)j * 8), rb = *reinterpret_cast<const Quad4*>(rd + (size_t)j * 8 + 4);
     {   // k = 1 on [t0, t1]
-        const double f = 1.0 / (t1 - t0);
+        const double f = ra.x;                  // 1.0 / (t1 - t0)
         wl[0] = 0.0 + f * (t1 - v);
         wl[1] = f * (v - t0);
     }
@@ -110,33 +126,33 @@ __device__ __forceinline__ void axis_exact(double v, int q, double a, double h, 
     const double tm2 = knot3(l - 2, q, a, h, b), tm1 = knot3(l - 1, q, a, h, b), k0 = knot3(l, q, a, h, b);
     const double k1 = knot3(l + 1, q, a, h, b), k2 = knot3(l + 2, q, a, h, b), k3 = knot3(l + 3, q, a, h, b);
     // j = 1
-    double f = 1.0 / (k1 - k0);
+    double f = ra.y;                            // 1.0 / (k1 - k0)
     double h0 = 0.0 + f * (k1 - v), h1 = f * (v - k0), h2, h3;
     // j = 2
     double hh0 = h0, hh1 = h1, hh2;
-    f = hh0 / (k1 - tm1);
+    f = mdiv(hh0, k1 - tm1, ra.z);
     h0 = 0.0 + f * (k1 - v);
     h1 = f * (v - tm1);
-    f = hh1 / (k2 - k0);
+    f = mdiv(hh1, k2 - k0, ra.w);
     h1 = h1 + f * (k2 - v);
     h2 = f * (v - k0);
     // j = 3
     hh0 = h0; hh1 = h1; hh2 = h2;
-    f = hh0 / (k1 - tm2);
+    f = mdiv(hh0, k1 - tm2, rb.x);
     h0 = 0.0 + f * (k1 - v);
     h1 = f * (v - tm2);
-    f = hh1 / (k2 - tm1);
+    f = mdiv(hh1, k2 - tm1, rb.y);
     h1 = h1 + f * (k2 - v);
     h2 = f * (v - tm1);
-    f = hh2 / (k3 - k0);
+    f = mdiv(hh2, k3 - k0, rb.z);
     h2 = h2 + f * (k3 - v);
     h3 = f * (v - k0);
     w[0] = h0; w[1] = h1; w[2] = h2; w[3] = h3;
 }
 
 __device__ __forceinline__ void field_locate(const FieldDev<double>& F, double x, double y, Cell<double>& c) {
-    axis_exact(x, F.qx, F.ax, F.hx, F.bx, F.inv_hx, c.jx, c.lx, c.lwx, c.wx);
-    axis_exact(y, F.qy, F.ay, F.hy, F.by, F.inv_hy, c.jy, c.ly, c.lwy, c.wy);
+    axis_exact(x, F.qx, F.ax, F.hx, F.bx, F.inv_hx, F.rdx, c.jx, c.lx, c.lwx, c.wx);
+    axis_exact(y, F.qy, F.ay, F.hy, F.by, F.inv_hy, F.rdy, c.jy, c.ly, c.lwy, c.wy);
 }
 
 // fpbisp's double sum: sp += c * wy[i] * wx[j], y index outer (splines are built as (y, x), :455)

@@ -92,6 +92,7 @@ struct rtmi_field {
     // packed, dtype-typed arrays the trace kernels gather from
     void *zn = nullptr, *g = nullptr;
     void* poly = nullptr;        // [(qy-1)*(qx-1)][rt::kPolyStride] of dtype: one polynomial per cell (rt_polytab.h)
+    double* rdiv = nullptr;      // [qx][8] then [qy][8]: reciprocals of the knot differences fpbspl divides by (rt_exact.h)
     hipStream_t stream = nullptr;
 };
 
@@ -126,6 +127,8 @@ template <typename T> static rt::FieldDev<T> field_dev(const rtmi_field* f, int 
     F.inv_hy = (T)(1.0 / f->hy);
     F.poly = (const T*)f->poly;
     F.ncx = f->qx - 1;
+    F.rdx = f->rdiv;
+    F.rdy = f->rdiv ? f->rdiv + (size_t)f->qx * 8 : nullptr;
     return F;
 }
 
@@ -353,6 +356,29 @@ FpAxis fp_axis_build(const std::vector<double>& x) {
     }
     return A;
 }
+// Per cell index j of an axis: the correctly rounded reciprocals of the seven knot differences rt::ex::axis_exact divides by
+// (same knots by the same operations as the device forms them: x is numpy.linspace as linspace() below restates it; then an
+// IEEE division).  [m][8]: 1/(x[j+1]-x[j]), 1/(k1-k0), 1/(k1-tm1), 1/(k2-k0), 1/(k1-tm2), 1/(k2-tm1), 1/(k3-k0), 0.
+std::vector<double> fp_recip_build(const std::vector<double>& x) {
+    const int m = (int)x.size();
+    std::vector<double> out((size_t)m * 8, 0.0);
+    auto knot = [&](int l) { return l <= 3 ? x[0] : (l >= m ? x[m - 1] : x[l - 2]); };   // rt::knot3
+    for (int j = 0; j < m - 1; j++) {
+        int l = j + 2;
+        l = l < 3 ? 3 : (l > m - 1 ? m - 1 : l);
+        const double tm2 = knot(l - 2), tm1 = knot(l - 1), k0 = knot(l), k1 = knot(l + 1), k2 = knot(l + 2), k3 = knot(l + 3);
+        double* o = &out[(size_t)j * 8];
+        o[0] = 1.0 / (x[j + 1] - x[j]);
+        o[1] = 1.0 / (k1 - k0);
+        o[2] = 1.0 / (k1 - tm1);
+        o[3] = 1.0 / (k2 - k0);
+        o[4] = 1.0 / (k1 - tm2);
+        o[5] = 1.0 / (k2 - tm1);
+        o[6] = 1.0 / (k3 - k0);
+    }
+    for (int i = 0; i < 8; i++) out[(size_t)(m - 1) * 8 + i] = out[(size_t)(m - 2) * 8 + i];
+    return out;
+}
 std::vector<double> linspace(double a, double b, int n) {
     std::vector<double> v(n);
     const double step = (b - a) / (double)(n - 1);
@@ -410,6 +436,13 @@ static int field_finish_impl(rtmi_field* f, double delta) {
             hipLaunchKernelGGL(k_pack<float>, dim3((nz + 255) / 256), dim3(256), 0, st, f->dZ, f->dCdy, f->dCdx,
                                (float*)f->zn, (float*)f->g, nz);
         HIP_TRY(hipGetLastError());
+        {   // reciprocals of the knot differences for the reference-order lookup (rt_exact.h)
+            const std::vector<double> RX = fp_recip_build(linspace(f->ax, f->bx, qx)), RY = fp_recip_build(linspace(f->ay, f->by, qy));
+            HIP_TRY(hipMalloc(&f->rdiv, (RX.size() + RY.size()) * sizeof(double)));
+            HIP_TRY(hipMemcpyAsync(f->rdiv, RX.data(), RX.size() * sizeof(double), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(f->rdiv + RX.size(), RY.data(), RY.size() * sizeof(double), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));  // the host vectors go out of scope
+        }
         // one polynomial per cell for the fast-form lookups: per-axis basis tables on the host (long double), cells on the device
         {
             const double ihx = (double)(f->dtype == RTMI_F64 ? 1.0 / f->hx : (double)(float)(1.0 / f->hx));
@@ -469,6 +502,7 @@ RTMI_EXPORT void rtmi_field_destroy(rtmi_field* f) {
     if (!f) return;
     (void)hipFree(f->dZ); (void)hipFree(f->dCdy); (void)hipFree(f->dCdx); (void)hipFree(f->zn); (void)hipFree(f->g);
     (void)hipFree(f->poly);
+    (void)hipFree(f->rdiv);
     delete f;
 }
 
