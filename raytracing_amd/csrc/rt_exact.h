@@ -35,6 +35,16 @@ __device__ __attribute__((noinline)) double cos_(double x) {
     sincos_k(x, &s, &c);
     return c;
 }
+// Both of one angle in one call: the two evaluations are glibc's own (gl::sin, gl::cos: same operations, same bits as sin_ and
+// cos_), inlined side by side so that what they have in common -- the range test, |x|, the table index and entry, the
+// polynomial pieces in r^2, the reduction by pi/2 -- is computed once, and one call is paid instead of two.
+struct SinCos { double s, c; };
+__device__ __attribute__((noinline)) SinCos sincos_(double x) {
+    SinCos r;
+    if (gl::in_range(x)) { r.s = gl::sin(kSinCosTab, x); r.c = gl::cos(kSinCosTab, x); }
+    else sincos_k(x, &r.s, &r.c);
+    return r;
+}
 // np.arctan2 as the reference's numpy evaluates it (AVX512_SKX builds: Intel SVML's __svml_atan28_ha; not libm's atan2 in the
 // last bit for 7 % of arguments) -- same text as oracle/rt_oracle.c np_arctan2, see there; tools/check_np_atan2.py: 0
 // mismatches against np.arctan2 on 1.6e7 argument pairs.  Its reciprocal starts from the VRCP14PD instruction, which is a
@@ -208,13 +218,13 @@ __device__ __forceinline__ bool adv_curv(const Ray<double>& r, const Consts<doub
     }
     const double dc = curv * k.step;
     if (r.gx * r.uy - r.gy * r.ux > 0) {   // np.cross (:360)
-        const double t = r.th - dc;
-        fx = r.x + (r.uy - sin_(t)) / curv;             // r.uy == sin(theta), r.ux == cos(theta): same function, same bits
-        fy = r.y + (cos_(t) - r.ux) / curv;
+        const SinCos t = sincos_(r.th - dc);
+        fx = r.x + (r.uy - t.s) / curv;                 // r.uy == sin(theta), r.ux == cos(theta): same function, same bits
+        fy = r.y + (t.c - r.ux) / curv;
     } else {
-        const double t = r.th + dc;
-        fx = r.x + (sin_(t) - r.uy) / curv;
-        fy = r.y + (-cos_(t) + r.ux) / curv;
+        const SinCos t = sincos_(r.th + dc);
+        fx = r.x + (t.s - r.uy) / curv;
+        fy = r.y + (-t.c + r.ux) / curv;
     }
     return true;
 }
@@ -222,8 +232,8 @@ __device__ __forceinline__ bool adv_curv(const Ray<double>& r, const Consts<doub
 // ---------------------------------------------------------------- angle determination (:370-407)
 __device__ __forceinline__ double ang_rk2(const Ray<double>& r, double step, double fn, double fgx, double fgy) {
     const double k1 = step * (r.ux * r.gy - r.uy * r.gx) / r.n;
-    const double t = r.th + k1;
-    const double k2 = step * (cos_(t) * fgy - sin_(t) * fgx) / fn;
+    const SinCos t = sincos_(r.th + k1);
+    const double k2 = step * (t.c * fgy - t.s * fgx) / fn;
     return r.th + (k1 + k2) / 2.0;
 }
 __device__ __forceinline__ double ang_cost(const Ray<double>& r, double step, double fgx, double fgy) {
@@ -381,11 +391,13 @@ __device__ __forceinline__ double golden_filtered(FastA fast_a, double EA, Expan
 
 // The two cost functions in the reference's arithmetic -- the rare path of golden_filtered, kept out of line.
 __device__ __attribute__((noinline)) double exact_cost_iso(double t, double fn, double px, double py, double ix, double iy) {
-    return sq(fn * cos_(t) - px - ix) + sq(fn * sin_(t) - py - iy);                                   // (:595, :697)
+    const SinCos u = sincos_(t);
+    return sq(fn * u.c - px - ix) + sq(fn * u.s - py - iy);                                           // (:595, :697)
 }
 __device__ __attribute__((noinline)) double exact_cost_aniso(double t, double fn, double gam, double g2, double mix, double miy,
                                                             double cgx, double cgy, double fgx, double fgy, double step) {
-    const double s = sin_(t), c = cos_(t);                                                            // (:728, :761)
+    const SinCos u = sincos_(t);
+    const double s = u.s, c = u.c;                                                                    // (:728, :761)
     const double a = aniso(s, c, gam);
     const double mx = moment(fn, a, g2, c, -sq(s));
     const double my = moment(fn, a, g2, s, sq(c));
@@ -581,7 +593,8 @@ __device__ __forceinline__ void store_update(const Consts<double>& k, Ray<double
     const double dist = norm2(r.x - fx, r.y - fy);
     r.dsim += dist;
     r.dreal += k.step;
-    const double c = cos_(fth), s = sin_(fth);
+    const SinCos u = sincos_(fth);
+    const double c = u.c, s = u.s;
     const double coef = aniso(s, c, k.gamma);
     r.mx = moment(fn, coef, k.g2m1, c, -sq(s));
     r.my = moment(fn, coef, k.g2m1, s, sq(c));
@@ -595,7 +608,8 @@ __device__ __forceinline__ void store_update(const Consts<double>& k, Ray<double
 
 // derived quantities from the stored state: the same functions of the same bits as when they were first formed
 __device__ __forceinline__ void derive(const Consts<double>& k, Ray<double>& r) {
-    r.ux = cos_(r.th); r.uy = sin_(r.th);
+    const SinCos u = sincos_(r.th);
+    r.ux = u.c; r.uy = u.s;
     r.coef = aniso(r.uy, r.ux, k.gamma);
     r.nray = r.coef * r.n;
     r.rn = 0;
