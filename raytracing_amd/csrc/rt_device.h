@@ -12,9 +12,6 @@
 // the vote and eps carried across the lookup cost more than the square root -- headline 14.9 -> 15.5 ms, cfg2 2.20 -> 2.48)
 #define RTMI_CHORD_SERIES 1
 #endif
-#ifndef RTMI_KEPT_SCALAR_LOAD
-#define RTMI_KEPT_SCALAR_LOAD 0   // the few-waves build reloads its kept cell with vector loads (0) or through the scalar cache + 72 copies (1: measured slower, cfg2 2.25 -> 2.54 ms)
-#endif
 #ifndef RTMI_POLY_BATCH
 #define RTMI_POLY_BATCH 1     // scalar loads of a lookup: 0 row by row, 1 one spline + n then the other (measured best), 2 all at once (spills SGPRs)
 #endif
@@ -819,11 +816,11 @@ template <typename T, int SC> __device__ __forceinline__ T poly_bilinear(Quad<T>
 //   live lane's cell changes -- every seventh step on the vert fan; a lookup in the kept cell is 33 fma and no memory access.
 // The arithmetic is poly_bicubic / poly_bilinear on the same numbers either way: the result does not depend on the policy,
 // on the wave mates or on which round served the lane.
-constexpr int kPolyLane = 0, kPolyScalar = 1, kPolyCached = 2, kPolyCached1 = 3;   // CACHED with two kept cells / with one
+constexpr int kPolyLane = 0, kPolyScalar = 1, kPolyCached = 2;
 template <typename T, int MODE> struct PolyGather {
     static constexpr bool SCALAR = MODE == kPolyScalar;
-    static constexpr bool CACHED = MODE == kPolyCached || MODE == kPolyCached1;
-    static constexpr int NA = CACHED ? 9 : 1, NB = MODE == kPolyCached ? 9 : 1;     // rows held in slot A / slot B
+    static constexpr bool CACHED = MODE == kPolyCached;
+    static constexpr int NA = CACHED ? 9 : 1;     // rows held
     static constexpr bool kPoly = true;
     typedef const Quad<T> __attribute__((address_space(4)))* ScalarRows;
     static __device__ __forceinline__ void eval_scalar(ScalarRows p, T u, T v, T& n, T& gx, T& gy) {
@@ -856,7 +853,7 @@ template <typename T, int MODE> struct PolyGather {
     }
     static __device__ __forceinline__ void eval_lane(const FieldDev<T>& F, int cell, T u, T v, T& n, T& gx, T& gy) {
         const Quad<T>* p = reinterpret_cast<const Quad<T>*>(F.poly + (size_t)cell * kPolyStride);
-        if constexpr (MODE == kPolyCached1) {
+        if constexpr (CACHED) {
             // this build has the registers: all nine rows in flight, one memory latency (the cells of a wave that straddles a
             // grid line were all used a step ago: L1 hits)
             Quad<T> a[9];
@@ -884,14 +881,13 @@ template <typename T, int MODE> struct PolyGather {
         n = poly_bilinear<T, 0>(p[8], u, v);
     }
     // CACHED: the kept cell and its nine rows (wave-uniform values in vector registers); lanes outside it read their own cell
-    // (218 VGPRs, two waves per SIMD).  kPolyCached keeps TWO cells (a wave that is crossing a grid line has lanes on both
-    // sides for a few steps; the cell ahead goes into the slot that was not served from last): measured slower -- 304 VGPRs
-    // and twice the control flow, cfg2 2.59 vs 2.21 ms, a one-cell-wide fan 2.00 vs 1.86 -- and not selected by the host
-    // (env RTMI_LAT_TWO_SLOTS=1 for the A/B).
-    int tagA, tagB;
-    bool lastB;
-    Quad<T> rowsA[NA], rowsB[NB];
-    __device__ __forceinline__ void init() { tagA = tagB = -1; lastB = true; }
+    // (218 VGPRs, two waves per SIMD).  Tried and measured slower, A/B in one session each: TWO kept cells (a wave that is
+    // crossing a grid line has lanes on both sides for a few steps; the cell ahead into the slot not served from last) --
+    // 304 VGPRs and twice the control flow: cfg2 2.59 vs 2.21 ms, a one-cell-wide fan 2.00 vs 1.86; reloading through the
+    // scalar cache with 72 copies into the vector registers (no vmcnt wait behind the trajectory stores): 2.54 vs 2.25 ms.
+    int tagA;
+    Quad<T> rowsA[NA];
+    __device__ __forceinline__ void init() { tagA = -1; }
     template <int N> static __device__ __forceinline__ void eval_rows(const Quad<T> (&rows)[N], T u, T v, T& n, T& gx, T& gy) {
         auto row = [&](int k) -> Quad<T> { return rows[N == 9 ? k : 0]; };
         gx = poly_bicubic<T, 2>(row, 0, u, v);
@@ -899,23 +895,6 @@ template <typename T, int MODE> struct PolyGather {
         n = poly_bilinear<T, 2>(rows[N == 9 ? 8 : 0], u, v);
     }
     template <int N> static __device__ __forceinline__ void load_rows(Quad<T> (&rows)[N], const FieldDev<T>& F, int cu) {
-#if RTMI_KEPT_SCALAR_LOAD
-        // through the scalar cache, then copied into the vector registers that keep them.  As vector loads (every lane the
-        // same address) they had to be retired with vmcnt(0) before the step loop went on -- left pending, every later step's
-        // first use of a row waits for vmcnt(0) -- and on gfx9's single in-order counter that also waits for every trajectory
-        // store still on its way to HBM: a microsecond per cell change while recording.  Scalar loads wait on lgkmcnt alone.
-        ScalarRows p = (ScalarRows)(F.poly + (size_t)cu * kPolyStride);
-        asm volatile("" : "+s"(p));
-#pragma unroll
-        for (int k = 0; k < N; k++) {
-            const Quad<T> a = p[k];
-            // pinned to vector registers: known to be wave-uniform the compiler keeps all 72 values in scalar registers
-            // across the step loop and copies every one of them per lookup
-            T x = a.x, y = a.y, z = a.z, w = a.w;
-            asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w));
-            rows[k] = Quad<T>{x, y, z, w};
-        }
-#else
         // every lane loads the same 288 bytes (one address per instruction: a broadcast in the texture path)
         typedef const Quad<T> __attribute__((address_space(1)))* GlobalRows;
         GlobalRows p = (GlobalRows)(F.poly + (size_t)cu * kPolyStride);
@@ -925,44 +904,15 @@ template <typename T, int MODE> struct PolyGather {
         // retire the loads here, in the rare branch: left pending they make every later step's first use of a row wait for
         // vmcnt(0), which also counts the trajectory stores of the step before
         __builtin_amdgcn_s_waitcnt(0x0F70);
-#endif
     }
     __device__ __forceinline__ void lookup_xy(const FieldDev<T>& F, bool active, T x, T y, T& n, T& gx, T& gy) {
         PolyCell<T> c;
         const unsigned long long live = rt_ballot(active);
         poly_locate(F, x, y, live, c);
-        if constexpr (MODE == kPolyCached) {
-            const int cu = __builtin_amdgcn_readlane(c.cell, live ? __builtin_ctzll(live) : 0);
-            bool useB;
-            if (cu == tagA) useB = false;
-            else if (cu == tagB) useB = true;
-            else {
-                useB = !lastB;
-                if (useB) { load_rows(rowsB, F, cu); tagB = cu; }
-                else { load_rows(rowsA, F, cu); tagA = cu; }
-            }
-            lastB = useB;
-            // every lane evaluates the first live lane's cell in straight-line code; lanes of another cell are redone below
-            if (useB) eval_rows(rowsB, c.u, c.v, n, gx, gy);
-            else eval_rows(rowsA, c.u, c.v, n, gx, gy);
-            const bool rest = active && c.cell != cu;
-            const unsigned long long rem = rt_ballot(rest);
-            if (rem != 0ull) {
-                const int cu2 = __builtin_amdgcn_readlane(c.cell, __builtin_ctzll(rem));
-                if (useB) { if (cu2 != tagA) { load_rows(rowsA, F, cu2); tagA = cu2; } }
-                else { if (cu2 != tagB) { load_rows(rowsB, F, cu2); tagB = cu2; } }
-                if (rest) {
-                    if (c.cell == cu2) {
-                        if (useB) eval_rows(rowsA, c.u, c.v, n, gx, gy);
-                        else eval_rows(rowsB, c.u, c.v, n, gx, gy);
-                    } else {
-                        eval_lane(F, c.cell, c.u, c.v, n, gx, gy);      // a wave in three or more cells
-                    }
-                }
-            }
-        } else if constexpr (MODE == kPolyCached1) {
+        if constexpr (CACHED) {
             const int cu = __builtin_amdgcn_readlane(c.cell, live ? __builtin_ctzll(live) : 0);
             if (cu != tagA) { load_rows(rowsA, F, cu); tagA = cu; }
+            // every lane evaluates the first live lane's cell in straight-line code; lanes of another cell are redone
             eval_rows(rowsA, c.u, c.v, n, gx, gy);
             if (active && c.cell != cu) eval_lane(F, c.cell, c.u, c.v, n, gx, gy);
         } else if constexpr (SCALAR) {

@@ -785,7 +785,7 @@ template <typename T, int METHOD, bool LDS> constexpr bool uses_tile() { return 
 template <typename T, int METHOD, bool LDS, int PH = RTMI_TILE_PHASES, bool POLY = uses_poly<T, METHOD>()> struct GatherOf { using type = rt::GlobalGather<T>; };
 template <typename T, int METHOD, int PH> struct GatherOf<T, METHOD, true, PH, false> { using type = rt::LdsGather<T, PH>; };
 template <typename T, int METHOD, bool LDS, int PH> struct GatherOf<T, METHOD, LDS, PH, true> {
-    using type = rt::PolyGather<T, !LDS ? rt::kPolyLane : PH == 1 ? rt::kPolyCached : PH == 2 ? rt::kPolyCached1 : rt::kPolyScalar>;   // PH 1 / 2: k_advance_lat<.., 1 / 2 waves per SIMD>
+    using type = rt::PolyGather<T, !LDS ? rt::kPolyLane : PH == 1 ? rt::kPolyCached : rt::kPolyScalar>;   // PH 1: k_advance_lat
 };
 template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::GlobalGather<T>&, T*) {}
 template <typename T, bool LDS, int MODE> __device__ __forceinline__ void gather_init(rt::PolyGather<T, MODE>& g, T*) { g.init(); }
@@ -961,9 +961,6 @@ __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, lon
 // the field, so RTMI_XCD_GROUP consecutive bundles go to ONE XCD (its L2 then serves the second to G-th from the first's
 // misses) while the groups still interleave over the XCDs (a contiguous eighth of the fan per XCD is badly balanced:
 // DESIGN.md 5.1).  Identity for the blocks past the last whole round of 8 x G.
-#ifndef RTMI_BOX_IN_VGPRS
-#define RTMI_BOX_IN_VGPRS 0
-#endif
 #ifndef RTMI_XCD_GROUP
 #define RTMI_XCD_GROUP 8     // measured (A/B, one session): interface 24.6 -> 23.6 ms at 8, 24.0 at 4; vert, fisheye, fp32 unchanged
 #endif
@@ -991,16 +988,15 @@ void k_advance(BatchDev<T> a, int nsteps) {
     __shared__ __attribute__((aligned(16))) T lds[uses_tile<T, METHOD, LDS>() ? 4 * rt::LdsGather<T>::ELEMS : 2];
     advance_bundle<T, METHOD, ISO, LDS, VAR>(a, lds, (long)xcd_grouped_block(blockIdx.x, gridDim.x) * blockDim.x, nsteps);
 }
-// The tile kernel built for FEW waves: a batch of <= 2 waves per SIMD (cfg2's 65 536 rays: one) has nothing to hide a step's
-// dependent chain behind -- 2 060 cycles per step at one wave per SIMD against 705 of issue -- so this build may use the whole
-// register file (launch bound: one wave per SIMD) and reads the 4x4 window from the tile in one go; the scheduler then
-// overlaps the two axes, the two gradient components and the LDS round trips.  Same arithmetic, same order of every sum: same bits.
-// WAVES: the waves per SIMD the build is for.  With the polynomial lookup (rt::PolyGather, CACHED): 1 keeps two cells'
-// coefficients in vector registers, 2 keeps one.
-template <typename T, int METHOD, bool ISO, int WAVES>
-__global__ __launch_bounds__(256, WAVES) void k_advance_lat(BatchDev<T> a, int nsteps) {
+// The kernel built for FEW waves: a batch of <= 2 waves per SIMD (cfg2's 65 536 rays: one) has nothing to hide a step's
+// dependent chain behind -- 1 800 cycles per step at one wave per SIMD against 545 of issue -- so this build spends registers
+// on latency (launch bound: two waves per SIMD, 218 VGPRs): the wave keeps its cell's 36 polynomial coefficients in vector
+// registers and reloads them when the cell changes (rt::PolyGather, CACHED); a lookup in the kept cell touches no memory.
+// Same arithmetic as every other build: same bits.  (RTMI_POLY 0: the LDS tile's 4x4 window read in one go.)
+template <typename T, int METHOD, bool ISO>
+__global__ __launch_bounds__(256, 2) void k_advance_lat(BatchDev<T> a, int nsteps) {
     __shared__ __attribute__((aligned(16))) T lds[uses_tile<T, METHOD, true>() ? 4 * rt::LdsGather<T, 1>::ELEMS : 2];
-    advance_bundle<T, METHOD, ISO, true, false, false, uses_poly<T, METHOD>() ? WAVES : 1>(a, lds, (long)blockIdx.x * blockDim.x, nsteps);
+    advance_bundle<T, METHOD, ISO, true, false, false, 1>(a, lds, (long)blockIdx.x * blockDim.x, nsteps);
 }
 template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool COH, int PH>
 __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, long blk, int nsteps) {
@@ -1012,12 +1008,6 @@ __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, lon
     bool alive = k < a.R && ld_state<COH>(a.alive + (k < a.R ? k : 0));
     // VAR: every ray carries its own DELTA_S and max_size (the calibration sweep as one candidate x ray batch)
     rt::Consts<T> K = a.K;
-#if RTMI_BOX_IN_VGPRS
-    // the box of the boundary test as vector-register values: the step loop is short of scalar registers (it spills them to
-    // vector lanes and re-reads kernel arguments per recorded row) and has vector registers to spare
-#pragma unroll
-    for (int q = 0; q < 4; q++) asm volatile("" : "+v"(K.box[q]));
-#endif
     int max_size = a.max_size;
     if (VAR && a.vstep && k < a.R) { K.step = a.vstep[k]; K.step2h = a.vstep2h[k]; K.step2 = K.step2h * T(2); max_size = a.vmax[k]; }
     if (alive) load_ray<T, METHOD, ISO, COH>(a, k, r, i);
@@ -1412,20 +1402,17 @@ static bool uniform_rows_ok(const rtmi_batch* b) {
     return b->p.record_stride == 0 || (!b->dirty_state && (double)b->R * (double)b->esz * 6.0 < 2147483647.0);
 }
 // op2/op6 fp64 tile builds for few waves (k_advance_lat): [method 2 | 6][iso]
-static const void* advance_lat_fn(int m, bool iso, int waves) {
-    static const void* const tab[2][2][2] = {
-        {{(const void*)k_advance_lat<double, 2, false, 1>, (const void*)k_advance_lat<double, 2, false, 2>},
-         {(const void*)k_advance_lat<double, 2, true, 1>, (const void*)k_advance_lat<double, 2, true, 2>}},
-        {{(const void*)k_advance_lat<double, 6, false, 1>, (const void*)k_advance_lat<double, 6, false, 2>},
-         {(const void*)k_advance_lat<double, 6, true, 1>, (const void*)k_advance_lat<double, 6, true, 2>}}};
-    return tab[m == 6 ? 1 : 0][iso ? 1 : 0][waves == 2 ? 1 : 0];
+static const void* advance_lat_fn(int m, bool iso) {
+    static const void* const tab[2][2] = {{(const void*)k_advance_lat<double, 2, false>, (const void*)k_advance_lat<double, 2, true>},
+                                          {(const void*)k_advance_lat<double, 6, false>, (const void*)k_advance_lat<double, 6, true>}};
+    return tab[m == 6 ? 1 : 0][iso ? 1 : 0];
 }
 static const void* pick_advance(const rtmi_batch* b) {
     const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
     // at most two waves per SIMD's worth of rays: the latency build (env RTMI_NO_LAT=1 keeps the throughput build, for A/B)
     if (lds && b->p.dtype == RTMI_F64 && (b->p.method == 2 || b->p.method == 6) && !b->vstep && uniform_rows_ok(b) &&
         !b->p.reference_order && b->lat_waves_per_simd > 0 && (b->R + 63) / 64 <= (int64_t)2 * b->lat_simds && !getenv("RTMI_NO_LAT"))
-        return advance_lat_fn(b->p.method, iso, (b->R + 63) / 64 <= (int64_t)b->lat_simds && getenv("RTMI_LAT_TWO_SLOTS") ? 1 : 2);   // env: A/B of the two-slot build
+        return advance_lat_fn(b->p.method, iso);
     // the VAR build: per-ray DELTA_S / max_size when set, and per-lane row bookkeeping always
     if (b->vstep || !uniform_rows_ok(b))
         return b->p.dtype == RTMI_F64 ? advance_var_fn<double>(batch_kernel_index(b), iso) : advance_var_fn<float>(batch_kernel_index(b), iso);
