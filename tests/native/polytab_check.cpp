@@ -50,3 +50,27 @@ extern "C" void polytab_eval(const double* tab, int qx, int qy, double ax, doubl
         n[i] = std::fma(std::fma(p[35], u, p[34]), v, std::fma(p[33], u, p[32]));
     }
 }
+
+// Markstein's division as rt::ex::mdiv does it on the device (raytracing_amd/csrc/rt_exact.h): a / d from r = RN(1 / d).
+// Returns how many of n (a, d) pairs give a quotient that is not the IEEE one; d runs over the knot differences of an m-point
+// linspace axis [lo, hi] (1, 2 and 3 pitches wide, with linspace's roundings), a over [0, 1] (fpbspl's partial weights).
+extern "C" long mdiv_mismatches(double lo, double hi, int m, long n, unsigned long long seed) {
+    std::vector<double> x(m);
+    const double step = (hi - lo) / (double)(m - 1);
+    for (int i = 0; i < m; i++) x[i] = (double)i * step + lo;
+    x[m - 1] = hi;
+    long bad = 0;
+    unsigned long long s = seed;
+    auto next = [&]() { s = s * 6364136223846793005ull + 1442695040888963407ull; return s; };
+    for (long k = 0; k < n; k++) {
+        const int j = (int)(next() >> 33) % (m - 3);
+        const int w = 1 + (int)((next() >> 40) % 3);
+        const double d = x[j + w] - x[j];
+        const double a = (double)(next() >> 11) * 0x1.0p-53;
+        const double r = 1.0 / d;
+        const double q0 = a * r;
+        const double q = std::fma(std::fma(-d, q0, a), r, q0);
+        if (q != a / d) bad++;
+    }
+    return bad;
+}

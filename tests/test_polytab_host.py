@@ -21,9 +21,11 @@ def _p(a):
 @pytest.fixture(scope="module")
 def polylib(tmp_path_factory):
     so = str(tmp_path_factory.mktemp("polytab") / "libpolytab_check.so")
-    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-shared", "-fPIC", "-o", so,
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-mfma", "-std=c++17", "-shared", "-fPIC", "-o", so,
                            os.path.join(ROOT, "tests", "native", "polytab_check.cpp")])
     L = C.CDLL(so)
+    L.mdiv_mismatches.restype = C.c_long
+    L.mdiv_mismatches.argtypes = [C.c_double, C.c_double, C.c_int, C.c_long, C.c_ulonglong]
     L.polytab_build.argtypes = [_dp, C.c_int, _dp, C.c_int, _dp, _dp, _dp, C.c_double, C.c_double, _dp]
     L.polytab_eval.argtypes = [_dp, C.c_int, C.c_int] + [C.c_double] * 6 + [C.c_long, _dp, _dp, _dp, _dp, _dp]
     return L
@@ -81,3 +83,11 @@ def test_cell_polynomials_noisy_samples(polylib):
     want = F.n_gradient(px, py)
     for a, b, c in zip(got, want, (Z, cdx, cdy)):
         assert np.abs(a - b).max() < 4e-15 * np.abs(c).max()
+
+
+def test_markstein_division_equals_ieee_division(polylib):
+    """rt::ex::mdiv (the reference-order lookup's divisions by knot differences: q0 = a r, q = q0 + (a - d q0) r with
+    r = RN(1/d) from the field build's table) against the IEEE quotient, on the three scenarios' axes: 0 mismatches on 3e8
+    pairs.  (On the device every reference-order trajectory test holds the result to the oracle's bits, whose C divides.)"""
+    for lo, hi, m, seed in ((-5.0, 8.0, 737, 1), (-5.5, 4.0, 539, 2), (-4.5, 4.5, 510, 3), (-5.0, 23.0, 1587, 4), (-5.0, 7.0, 680, 5)):
+        assert polylib.mdiv_mismatches(lo, hi, m, 60_000_000, seed) == 0
