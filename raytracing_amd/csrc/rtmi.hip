@@ -788,7 +788,15 @@ template <typename T, int METHOD, bool LDS, int PH> struct GatherOf<T, METHOD, L
     using type = rt::PolyGather<T, !LDS ? rt::kPolyLane : PH == 1 ? rt::kPolyCached : rt::kPolyScalar>;   // PH 1: k_advance_lat
 };
 template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::GlobalGather<T>&, T*) {}
-template <typename T, bool LDS, int MODE> __device__ __forceinline__ void gather_init(rt::PolyGather<T, MODE>& g, T*) { g.init(); }
+template <typename T, bool LDS, int MODE> __device__ __forceinline__ void gather_init(rt::PolyGather<T, MODE>& g, T* lds) {
+    // the scalar mode's prefetch sink: 1 KB of LDS per wave (poly_lds_elems)
+    if constexpr (MODE == rt::kPolyScalar && RTMI_POLY_PREFETCH) g.init((RT_LDS char*)lds + (threadIdx.x >> 6) * 1024);
+    else g.init();
+}
+// LDS of a step kernel in units of T: the reference-order methods' tile, or the polynomial lookup's prefetch sink (4 waves x 1 KB)
+template <typename T, int METHOD, bool LDS, int PH = RTMI_TILE_PHASES> constexpr int kernel_lds_elems() {
+    return uses_tile<T, METHOD, LDS>() ? 4 * rt::LdsGather<T, PH>::ELEMS : (uses_poly<T, METHOD>() && LDS && RTMI_POLY_PREFETCH && PH != 1) ? (int)(4096 / sizeof(T)) : 2;
+}
 template <typename T, bool LDS, int PH> __device__ __forceinline__ void gather_init(rt::LdsGather<T, PH>& g, T* lds) {
     g.init(lds + (threadIdx.x >> 6) * rt::LdsGather<T, PH>::ELEMS);
 }
@@ -985,7 +993,7 @@ __device__ __forceinline__ unsigned xcd_grouped_block(unsigned h, unsigned nbloc
 template <typename T, int METHOD, bool ISO, bool LDS, bool VAR>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? RTMI_F32_WAVES : LDS ? (light_method(METHOD) ? RTMI_TILE_WAVES : heavy_method(METHOD) ? 2 : 3) : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES))
 void k_advance(BatchDev<T> a, int nsteps) {
-    __shared__ __attribute__((aligned(16))) T lds[uses_tile<T, METHOD, LDS>() ? 4 * rt::LdsGather<T>::ELEMS : 2];
+    __shared__ __attribute__((aligned(16))) T lds[kernel_lds_elems<T, METHOD, LDS>()];
     advance_bundle<T, METHOD, ISO, LDS, VAR>(a, lds, (long)xcd_grouped_block(blockIdx.x, gridDim.x) * blockDim.x, nsteps);
 }
 // The kernel built for FEW waves: a batch of <= 2 waves per SIMD (cfg2's 65 536 rays: one) has nothing to hide a step's
@@ -1022,6 +1030,9 @@ __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, lon
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), expcnt and lgkmcnt untouched
     advance_loop<T, METHOD, ISO, decltype(gather), !VAR, COH>(a, K, gather, r, k, i, alive, max_size, nsteps, blk);
     if (alive) store_ray<T, METHOD, COH>(a, k, r, i, true);
+    // the polynomial lookup's prefetches write this block's LDS: none may still be on its way when the block's LDS is given
+    // to another one
+    if constexpr (uses_poly<T, METHOD>() && LDS && RTMI_POLY_PREFETCH) __builtin_amdgcn_s_waitcnt(0x0F70);
     return alive;
 }
 
@@ -1057,7 +1068,7 @@ __device__ __forceinline__ void compiler_fence() { __atomic_signal_fence(__ATOMI
 template <typename T, int METHOD, bool ISO, bool LDS>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? RTMI_F32_SLICED_WAVES : LDS ? (light_method(METHOD) ? RTMI_TILE_WAVES : heavy_method(METHOD) ? 2 : 3) : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES))
 void k_advance_sliced(BatchDev<T> a, int slice, unsigned long long capacity, unsigned long long* ctl, unsigned long long timeout_ticks) {
-    __shared__ __attribute__((aligned(16))) T lds[uses_tile<T, METHOD, LDS>() ? 4 * rt::LdsGather<T>::ELEMS : 2];
+    __shared__ __attribute__((aligned(16))) T lds[kernel_lds_elems<T, METHOD, LDS>()];
     __shared__ unsigned long long s_entry;
     const unsigned long long NB = (unsigned long long)((a.R + 255) / 256);
     unsigned long long* head = ctl;
@@ -1149,7 +1160,7 @@ void k_advance_sliced(BatchDev<T> a, int slice, unsigned long long capacity, uns
 #endif
 template <typename T, int METHOD, bool ISO, bool LDS>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : light_method(METHOD) ? RTMI_REFILL_WAVES : 2) void k_trace_refill(BatchDev<T> a, int refill_min, int chunk) {
-    __shared__ __attribute__((aligned(16))) T lds[uses_tile<T, METHOD, LDS>() ? 4 * rt::LdsGather<T>::ELEMS : 2];
+    __shared__ __attribute__((aligned(16))) T lds[kernel_lds_elems<T, METHOD, LDS>()];
     typename GatherOf<T, METHOD, LDS>::type gather;
     gather_init<T, LDS>(gather, lds);
     const bool RECORD = a.stride != 0;
