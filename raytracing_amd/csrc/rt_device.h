@@ -12,9 +12,6 @@
 // the vote and eps carried across the lookup cost more than the square root -- headline 14.9 -> 15.5 ms, cfg2 2.20 -> 2.48)
 #define RTMI_CHORD_SERIES 1
 #endif
-#ifndef RTMI_POLY_PREFETCH
-#define RTMI_POLY_PREFETCH 0   // 1: the wave-shared lookup asks L2 for the cells ahead when its cell changes (PolyGather::prefetch).  Measured: interface 23.6 -> 23.0 ms, but fisheye (a new cell every step) 8.3 -> 9.1, vert 8.8 -> 9.0, fp32 48.7 -> 49.6: off
-#endif
 #ifndef RTMI_POLY_BATCH
 #define RTMI_POLY_BATCH 1     // scalar loads of a lookup: 0 row by row, 1 one spline + n then the other (measured best), 2 all at once (spills SGPRs)
 #endif
@@ -890,36 +887,7 @@ template <typename T, int MODE> struct PolyGather {
     // scalar cache with 72 copies into the vector registers (no vmcnt wait behind the trajectory stores): 2.54 vs 2.25 ms.
     int tagA;
     Quad<T> rowsA[NA];
-    // SCALAR: the cell before this one and the last change of cell along x (+-1) and along y (+-ncx), wave-uniform, and
-    // this wave's 1 KB of LDS that prefetches land in (nothing ever reads it)
-    int prev_cell, step_x, step_y;
-    RT_LDS char* sink;
-    __device__ __forceinline__ void init(RT_LDS char* wave_sink = nullptr) { tagA = -1; prev_cell = -1; step_x = step_y = 0; sink = wave_sink; }
-    // A cell is 320 bytes of a table far larger than the caches (127 - 345 MB); what makes a lookup cheap is that a
-    // neighbouring wave -- in time and in the fan -- has just pulled the same lines into the XCD's L2.  Where that fails (the
-    // interface fan: a large grid, rays that diverge over 22 units) a wave meets a cold cell every seventh step and waits an
-    // HBM round trip.  So when the wave's cell changes it asks for the cells it will enter next: the same move again (cell +
-    // d) and the last move along the other axis -- five 64-byte lines each, one lane per line, as loads whose destination is
-    // LDS (global_load_lds: no register to keep free, nothing waits for them); they leave the lines in L2, which is where
-    // the scalar loads of the coming lookups find them.
-    __device__ __forceinline__ void prefetch(const FieldDev<T>& F, int cu, int before) {
-        const int d = cu - before;                    // wave-uniform, like everything up to the lane's own line below
-        if (before >= 0) {
-            const int sx = __builtin_amdgcn_readfirstlane(step_x), sy = __builtin_amdgcn_readfirstlane(step_y);
-            int other = 0;
-            if (d == 1 || d == -1) { other = sy; step_x = d; }
-            else if (d == F.ncx || d == -F.ncx) { other = sx; step_y = d; }
-            const int lane = (int)__lane_id(), which = lane >= 5 ? 1 : 0, line = lane - 5 * which;
-            const int target = which ? cu + other : cu + d;
-            const unsigned ncell = (unsigned)F.ncx * (unsigned)(F.qy - 1);
-            if (lane < 10 && (which == 0 || other != 0) && (unsigned)target < ncell) {
-                typedef const char __attribute__((address_space(1)))* GlobalBytes;
-                GlobalBytes g = (GlobalBytes)(F.poly + (size_t)target * kPolyStride) + line * 64;
-                __builtin_amdgcn_global_load_lds(g, sink, 16, 0, 0);
-            }
-        }
-        prev_cell = cu;
-    }
+    __device__ __forceinline__ void init() { tagA = -1; }
     template <int N> static __device__ __forceinline__ void eval_rows(const Quad<T> (&rows)[N], T u, T v, T& n, T& gx, T& gy) {
         auto row = [&](int k) -> Quad<T> { return rows[N == 9 ? k : 0]; };
         gx = poly_bicubic<T, 2>(row, 0, u, v);
@@ -956,12 +924,6 @@ template <typename T, int MODE> struct PolyGather {
             // per-lane cell: inside "cell == cu" the compiler would otherwise substitute the lane's value and load per lane
             ScalarRows p = (ScalarRows)(F.poly + (size_t)cu * kPolyStride);
             asm volatile("" : "+s"(p));
-#if RTMI_POLY_PREFETCH
-            {   // (the members live in vector registers; the scalar copy keeps the test and the branch scalar)
-                const int before = __builtin_amdgcn_readfirstlane(prev_cell);
-                if (cu != before) prefetch(F, cu, before);
-            }
-#endif
             if ((rt_ballot(c.cell != cu) & live) == 0ull) {
                 eval_scalar(p, c.u, c.v, n, gx, gy);
                 return;

@@ -788,14 +788,12 @@ template <typename T, int METHOD, bool LDS, int PH> struct GatherOf<T, METHOD, L
     using type = rt::PolyGather<T, !LDS ? rt::kPolyLane : PH == 1 ? rt::kPolyCached : rt::kPolyScalar>;   // PH 1: k_advance_lat
 };
 template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::GlobalGather<T>&, T*) {}
-template <typename T, bool LDS, int MODE> __device__ __forceinline__ void gather_init(rt::PolyGather<T, MODE>& g, T* lds) {
-    // the scalar mode's prefetch sink: 1 KB of LDS per wave (poly_lds_elems)
-    if constexpr (MODE == rt::kPolyScalar && RTMI_POLY_PREFETCH) g.init((RT_LDS char*)lds + (threadIdx.x >> 6) * 1024);
-    else g.init();
-}
-// LDS of a step kernel in units of T: the reference-order methods' tile, or the polynomial lookup's prefetch sink (4 waves x 1 KB)
+template <typename T, bool LDS, int MODE> __device__ __forceinline__ void gather_init(rt::PolyGather<T, MODE>& g, T*) { g.init(); }
+// LDS of a step kernel in units of T: the reference-order methods' tile; the polynomial lookup needs none.  (An L2 prefetch of
+// the cells ahead -- global_load_lds into a per-wave sink whenever the wave's cell changes -- was measured: interface 23.6 ->
+// 23.0 ms, but fisheye, a new cell every step, 8.3 -> 9.1, vert_heterogeneous 8.8 -> 9.0, fp32 48.7 -> 49.6: not kept.)
 template <typename T, int METHOD, bool LDS, int PH = RTMI_TILE_PHASES> constexpr int kernel_lds_elems() {
-    return uses_tile<T, METHOD, LDS>() ? 4 * rt::LdsGather<T, PH>::ELEMS : (uses_poly<T, METHOD>() && LDS && RTMI_POLY_PREFETCH && PH != 1) ? (int)(4096 / sizeof(T)) : 2;
+    return uses_tile<T, METHOD, LDS>() ? 4 * rt::LdsGather<T, PH>::ELEMS : 2;
 }
 template <typename T, bool LDS, int PH> __device__ __forceinline__ void gather_init(rt::LdsGather<T, PH>& g, T* lds) {
     g.init(lds + (threadIdx.x >> 6) * rt::LdsGather<T, PH>::ELEMS);
@@ -1030,9 +1028,6 @@ __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, lon
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), expcnt and lgkmcnt untouched
     advance_loop<T, METHOD, ISO, decltype(gather), !VAR, COH>(a, K, gather, r, k, i, alive, max_size, nsteps, blk);
     if (alive) store_ray<T, METHOD, COH>(a, k, r, i, true);
-    // the polynomial lookup's prefetches write this block's LDS: none may still be on its way when the block's LDS is given
-    // to another one
-    if constexpr (uses_poly<T, METHOD>() && LDS && RTMI_POLY_PREFETCH) __builtin_amdgcn_s_waitcnt(0x0F70);
     return alive;
 }
 
