@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-3 profile set after the polynomial lookup (run through gpurun); tools/profile_summary.py <tag>... turns gpurun_out/prof_<tag>/ into profiles/<tag>_*
+# round-3 profile set of the present kernels (run through gpurun); tools/profile_summary.py <tag>... turns gpurun_out/prof_<tag>/ into profiles/<tag>_*
 set -u
 tools/profile_config.sh r03q_vert_full --record full
 tools/profile_config.sh r03q_vert_none --record none
@@ -8,5 +8,9 @@ tools/profile_config.sh r03q_cfg2_none --rays 65536 --record none
 tools/profile_config.sh r03q_cfg3_fisheye_none --scenario fisheye --record none
 tools/profile_config.sh r03q_cfg3_fisheye_full --scenario fisheye --record full
 tools/profile_config.sh r03q_cfg4_f32_none --dtype f32 --rays 8388608 --record none
+tools/profile_config.sh r03q_cfg5_aniso_none --scenario anisotropy --record none
+tools/profile_config.sh r03q_cfg5_shard8_none --scenario anisotropy --record none --total-rays 1048576 --emulate-world 8
+tools/profile_config.sh r03q_op3_vert_none --method 3 --record none
+tools/profile_config.sh r03q_op9_vert_none --method 9 --rays 524288 --record none
 tools/profile_config.sh r03q_strong8_full --total-rays 1048576 --emulate-world 8 --record full
 tools/profile_config.sh r03q_iface_none --scenario interface --record none
