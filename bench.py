@@ -296,8 +296,7 @@ def main():
         # reduction kernel + a host sync, which a real stepping caller would not pay per launch either)
         group = max(1, 256 // args.chunk)
         while True:
-            for _ in range(group):
-                batch.step(args.chunk)
+            batch.step(args.chunk, group)          # `group` launches as one hipGraph (rtmi_step_repeat)
             if batch.stats()["live_rays"] == 0:
                 break
 

@@ -164,6 +164,10 @@ int rtmi_batch_reset(rtmi_batch *b);
 /* One launch that advances every live ray by at most nsteps DELTA_S steps (the body of the loop at :866-879;
  * nsteps = 1 is exactly one call of selected_func + store_update_results per ray). */
 int rtmi_step(rtmi_batch *b, int32_t nsteps);
+/* `count` times rtmi_step(b, nsteps), submitted as ONE hipGraph (a chain of `count` kernel nodes, built on first use and kept
+ * while nsteps / count / the kernel stay the same): a host that advances the batch a few steps at a time pays one call and
+ * one event pair per group instead of three runtime calls per launch.  Same results as the single calls. */
+int rtmi_step_repeat(rtmi_batch *b, int32_t nsteps, int32_t count);
 /* Run every ray to termination (:866-879 to exhaustion/break). */
 int rtmi_run(rtmi_batch *b);
 /* Block until the batch's stream is idle. */

@@ -68,6 +68,7 @@ SYMBOLS = {
     "rtmi_batch_set_per_ray": (C.c_int, [C.c_void_p, _dp, _ip]),
     "rtmi_batch_reset": (C.c_int, [C.c_void_p]),
     "rtmi_step": (C.c_int, [C.c_void_p, C.c_int32]),
+    "rtmi_step_repeat": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "rtmi_run": (C.c_int, [C.c_void_p]),
     "rtmi_sync": (C.c_int, [C.c_void_p]),
     "rtmi_read_d_ray": (C.c_int, [C.c_void_p, _dp]),

@@ -1283,7 +1283,14 @@ struct rtmi_batch {
     int mode_used = RTMI_LAUNCH_PLAIN;
     void* staging = nullptr;     // device scratch of the read / metric / set_state paths, grown on demand, freed with the batch
     size_t staging_bytes = 0;
+    // rtmi_step_repeat: `count` launches of `nsteps` steps as one hipGraph (a chain of kernel nodes), kept while the same
+    // kernel, step count and launch count are asked for
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    const void* graph_kfn = nullptr;
+    int graph_nsteps = 0, graph_count = 0, graph_block = 0;
 };
+static void drop_graph(rtmi_batch* b);
 
 // device scratch owned by the batch (one allocation reused by every read path instead of a hipMalloc/hipFree per call)
 static int batch_staging(rtmi_batch* b, size_t bytes, void** out) {
@@ -1483,6 +1490,7 @@ RTMI_EXPORT void rtmi_batch_destroy(rtmi_batch* b) {
     if (b->h_counters) (void)hipHostFree(b->h_counters);
     if (b->own_s) (void)hipFree(b->s_ray);
     if (b->own_n) (void)hipFree(b->n_ray);
+    drop_graph(b);
     for (auto& e : b->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete b;
 }
@@ -1624,6 +1632,7 @@ RTMI_EXPORT int rtmi_batch_set_per_ray(rtmi_batch* b, const double* step, const 
     ARG_TRY(b->p.launch_mode == RTMI_LAUNCH_PLAIN || b->p.launch_mode == RTMI_LAUNCH_AUTO,
             "rtmi_batch_set_per_ray: per-ray steps run on the one-lane-per-ray kernel (RTMI_LAUNCH_PLAIN or RTMI_LAUNCH_AUTO)");
     DEVICE_TRY(b->field, "rtmi_batch_set_per_ray");
+    drop_graph(b);     // a step graph holds the kernel arguments by value
     if (b->launches != 0 || b->dirty_state)
         return fail(RTMI_ERR_STATE, "rtmi_batch_set_per_ray: only valid on a fresh or reset batch (before any rtmi_step / rtmi_run / "
                                     "rtmi_batch_set_state): rays that already stopped would be revived");
@@ -1820,6 +1829,70 @@ static int next_event_pair(rtmi_batch* b, std::pair<hipEvent_t, hipEvent_t>** ou
         }
     }
     *out = &b->events[b->ev_used++];
+    return RTMI_OK;
+}
+
+RTMI_EXPORT int rtmi_step(rtmi_batch* b, int32_t nsteps);
+static void drop_graph(rtmi_batch* b) {
+    if (b->graph_exec) (void)hipGraphExecDestroy(b->graph_exec);
+    if (b->graph) (void)hipGraphDestroy(b->graph);
+    b->graph_exec = nullptr; b->graph = nullptr; b->graph_kfn = nullptr; b->graph_nsteps = b->graph_count = 0;
+}
+// A chain of `count` kernel nodes, each the advance kernel for `nsteps` steps with the batch's present arguments.
+template <typename T> static hipError_t build_step_graph(rtmi_batch* b, int nsteps, int count) {
+    drop_graph(b);
+    BatchDev<T> a = batch_dev<T>(b);
+    b->kfn = pick_advance(b);
+    const int bs = b->p.block_size > 0 ? b->p.block_size : 256;
+    hipError_t e = hipGraphCreate(&b->graph, 0);
+    if (e != hipSuccess) return e;
+    void* args[] = {&a, &nsteps};
+    hipKernelNodeParams kp{};
+    kp.func = const_cast<void*>(b->kfn);
+    kp.gridDim = dim3((unsigned)((b->R + bs - 1) / bs));
+    kp.blockDim = dim3(bs);
+    kp.sharedMemBytes = 0;
+    kp.kernelParams = args;
+    kp.extra = nullptr;
+    hipGraphNode_t prev = nullptr;
+    for (int i = 0; i < count; i++) {
+        hipGraphNode_t node = nullptr;
+        e = hipGraphAddKernelNode(&node, b->graph, prev ? &prev : nullptr, prev ? 1 : 0, &kp);
+        if (e != hipSuccess) return e;
+        prev = node;
+    }
+    e = hipGraphInstantiate(&b->graph_exec, b->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess) return e;
+    b->graph_kfn = b->kfn; b->graph_nsteps = nsteps; b->graph_count = count; b->graph_block = bs;
+    return hipSuccess;
+}
+
+RTMI_EXPORT int rtmi_step_repeat(rtmi_batch* b, int32_t nsteps, int32_t count) {
+    ARG_TRY(b, "rtmi_step_repeat: null");
+    ARG_TRY(nsteps > 0 && count > 0 && count <= 65536, "rtmi_step_repeat: nsteps must be > 0 and count in 1..65536");
+    DEVICE_TRY(b->field, "rtmi_step_repeat");
+    ARG_TRY(b->p.block_size == 0 || (b->p.block_size % 64 == 0 && b->p.block_size <= 256),
+            "rtmi_step_repeat: block_size must be a multiple of 64, at most 256");
+    const int bs = b->p.block_size > 0 ? b->p.block_size : 256;
+    // the graph holds the kernel arguments by value: rebuilt when anything they derive from may have changed (the kernel
+    // choice follows set_state / set_per_ray; reset and restore keep the same buffers and parameters)
+    if (!b->graph_exec || b->graph_kfn != pick_advance(b) || b->graph_nsteps != nsteps || b->graph_count != count || b->graph_block != bs) {
+        const hipError_t e = b->p.dtype == RTMI_F64 ? build_step_graph<double>(b, nsteps, count) : build_step_graph<float>(b, nsteps, count);
+        if (e != hipSuccess) {   // no graph: the same launches one by one
+            drop_graph(b);
+            (void)hipGetLastError();
+            for (int i = 0; i < count; i++) { const int rc = rtmi_step(b, nsteps); if (rc) return rc; }
+            return RTMI_OK;
+        }
+    }
+    std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
+    int rc0 = next_event_pair(b, &evp);
+    if (rc0) return rc0;
+    HIP_TRY(hipEventRecord(evp->first, b->stream));
+    HIP_TRY(hipGraphLaunch(b->graph_exec, b->stream));
+    HIP_TRY(hipEventRecord(evp->second, b->stream));
+    b->launches += (uint32_t)count;
+    b->mode_used = RTMI_LAUNCH_PLAIN;
     return RTMI_OK;
 }
 

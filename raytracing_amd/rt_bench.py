@@ -354,8 +354,12 @@ class Batch:
     def reset(self):
         check(lib().rtmi_batch_reset(self._h))
 
-    def step(self, nsteps=1):
-        check(lib().rtmi_step(self._h, int(nsteps)))
+    def step(self, nsteps=1, count=1):
+        """Advance every live ray by nsteps DELTA_S steps; count > 1: that many such launches as one hipGraph."""
+        if count > 1:
+            check(lib().rtmi_step_repeat(self._h, int(nsteps), int(count)))
+        else:
+            check(lib().rtmi_step(self._h, int(nsteps)))
 
     def run(self):
         check(lib().rtmi_run(self._h))

@@ -1261,3 +1261,42 @@ def test_cell_polynomial_lookup_on_the_device(scen, rb, gpu_fields, oracle_field
     gscale = max(np.abs(cdx).max(), np.abs(cdy).max())
     for a, b, scale in zip(dev, want, (np.abs(Z).max(), gscale, gscale)):
         assert np.abs(a - b).max() < 2e-15 * scale
+
+
+@pytest.mark.parametrize("scen,m,stride", [("vert_heterogeneous", 6, 1), ("fisheye", 7, 4), ("anisotropy", 11, 0)])
+def test_step_repeat_graph_equals_single_steps(scen, m, stride, rb, gpu_fields):
+    """rtmi_step_repeat (count launches of nsteps steps as one hipGraph) against the same launches one by one, and against one
+    launch to termination: the same bits -- rows, d_ray, final state; the graph is rebuilt when nsteps / count change and
+    survives a reset."""
+    R = 700 if m != 11 else 150
+    lim = LIMITS[scen]
+    if scen == "fisheye":
+        th, x0, y0, step, ms = np.linspace(np.pi / 4, 3 * np.pi / 4, R), 1.0, 0.0, 2 * np.pi / 303, 3040
+    else:
+        th, x0, y0, step, ms = np.linspace(0.06, np.pi / 2, R), -2.0, -2.0, rb.DELTA_S, 4000
+    gam = 3 if scen == "anisotropy" else 1
+
+    def make():
+        return rb.Batch(gpu_fields(scen), m, step, ms, lim, gam, th, x0, y0, record_stride=stride)
+    ref = make(); ref.run()
+    want = (ref.d_ray(), ref.final(), ref.rows() if stride else None)
+    ref.close()
+    b = make()
+    for nsteps, count in ((1, 37), (3, 11), (1, 37), (16, 300)):           # 37 + 33 + 37 + 4800 steps >= max_size
+        b.step(nsteps, count)
+    assert b.stats()["live_rays"] == 0 and b.stats()["launches"] == 37 + 11 + 37 + 300
+    got = (b.d_ray(), b.final(), b.rows() if stride else None)
+    for u, v in zip(got, want):
+        assert (u is None and v is None) or np.array_equal(u, v)
+    b.reset()
+    while b.stats()["live_rays"]:
+        b.step(16, 64)                                                     # the graph built above is reused after a reset
+    assert np.array_equal(b.final(), want[1])
+    c = make()
+    for _ in range(37):
+        c.step(1)
+    c.step(3, 11)
+    d = make(); d.step(1, 37); d.step(3, 11)
+    assert np.array_equal(c.final(), d.final()) and np.array_equal(c.d_ray(), d.d_ray())
+    b.close(); c.close(); d.close()
+
