@@ -909,8 +909,12 @@ template <typename T, int MODE> struct PolyGather {
         PolyCell<T> c;
         const unsigned long long live = rt_ballot(active);
         poly_locate(F, x, y, live, c);
+        if constexpr (CACHED || SCALAR) {
+            // no live lane (the step loops leave before this can happen): nothing addresses the table with an idle lane's cell
+            if (live == 0ull) { n = T(1); gx = T(0); gy = T(0); return; }
+        }
         if constexpr (CACHED) {
-            const int cu = __builtin_amdgcn_readlane(c.cell, live ? __builtin_ctzll(live) : 0);
+            const int cu = __builtin_amdgcn_readlane(c.cell, __builtin_ctzll(live));
             if (cu != tagA) { load_rows(rowsA, F, cu); tagA = cu; }
             // every lane evaluates the first live lane's cell in straight-line code; lanes of another cell are redone
             eval_rows(rowsA, c.u, c.v, n, gx, gy);
@@ -918,8 +922,7 @@ template <typename T, int MODE> struct PolyGather {
         } else if constexpr (SCALAR) {
             // the first live lane's cell; when every live lane is in it (98 % of a fan's wave-steps) all lanes evaluate its
             // polynomial in straight-line code -- an idle lane too, at its own (u, v) in [0, 1)^2: finite, and nobody reads it
-            const int first = live ? __builtin_ctzll(live) : 0;
-            int cu = __builtin_amdgcn_readlane(c.cell, first);
+            int cu = __builtin_amdgcn_readlane(c.cell, __builtin_ctzll(live));
             // the entry's address is formed from the scalar and pinned to scalar registers BEFORE any comparison with the
             // per-lane cell: inside "cell == cu" the compiler would otherwise substitute the lane's value and load per lane
             ScalarRows p = (ScalarRows)(F.poly + (size_t)cu * kPolyStride);
