@@ -1079,8 +1079,41 @@ template <typename T> __device__ __forceinline__ Acc ang_rk2(const Ray<T>& r, T 
     const T k2 = step * fma_(c2, fgy, -(s2 * fgx)) * fn_rcp;
     return r.th + (Acc)((k1 + k2) * T(0.5));
 }
+// atan2(ys, yc) + theta, folded into (-pi, pi], for a vector given by its components ACROSS (ys) and ALONG (yc) the ray's unit
+// tangent (cos theta, sin theta): the direction a step turns to is always next to the one it comes from, so the new angle is
+// theta + atan(ys / yc) with |ys / yc| << 1 -- a reciprocal and a five-term series (|t| < 2^-5: the next term is t^10/11 <
+// 2^-53) instead of a full atan2 of the untouched components (~65 instructions in ocml) -- and it is better conditioned too:
+// the products with n that the two components share cancel before anything is rounded.  A lane whose turn is larger, or
+// whose vector points backwards, takes atan2 itself; the vote only selects the layout.  RTMI_ATAN_NEAR 0: always atan2.
+#ifndef RTMI_ATAN_NEAR
+#define RTMI_ATAN_NEAR 1
+#endif
+template <typename T> __device__ __forceinline__ Acc angle_near(Acc theta, T ux, T uy, T ys, T yc) {
+    const T t = ys * rcp_full(yc);
+    const bool near = yc > T(0) && M<T>::abs_(t) < T(0.03125) && __builtin_fabs(theta) <= Acc(3.141592653589793);   // (a launch angle beyond +-pi: atan2 folds it)
+    auto series = [&]() -> Acc {
+        const T z = t * t;
+        T p = fma_const(z, T(1.0 / 9.0), T(-1.0 / 7.0));
+        p = fma_const(z, p, T(1.0 / 5.0));
+        p = fma_const(z, p, T(-1.0 / 3.0));
+        const Acc th = theta + (Acc)fma_(t * z, p, t);
+        // atan2's range: theta itself is in (-pi, pi], the turn is small
+        return th > Acc(3.141592653589793) ? th - Acc(6.283185307179586) : (th <= Acc(-3.141592653589793) ? th + Acc(6.283185307179586) : th);
+    };
+    auto full = [&]() -> Acc {      // the vector in the fixed frame again: (yc, ys) turned by theta
+        return (Acc)M<T>::atan2_(fma_(yc, uy, ys * ux), fma_(yc, ux, -(ys * uy)));
+    };
+    if (rt_ballot(!near) == 0ull) return series();
+    return near ? series() : full();
+}
 template <typename T> __device__ __forceinline__ Acc ang_cost(const Ray<T>& r, T step, T fgx, T fgy) {
+#if RTMI_ATAN_NEAR
+    // P = n u + I (momentum + impulse): across the tangent I x u... = I_y u_x - I_x u_y, along it n + I . u (|u| = 1)
+    const T ix = impulse(r.gx, fgx, step), iy = impulse(r.gy, fgy, step);
+    return angle_near<T>(r.th, r.ux, r.uy, fma_(iy, r.ux, -(ix * r.uy)), r.n + fma_(ix, r.ux, iy * r.uy));
+#else
     return (Acc)M<T>::atan2_(fma_(r.n, r.uy, impulse(r.gy, fgy, step)), fma_(r.n, r.ux, impulse(r.gx, fgx, step)));
+#endif
 }
 
 // golden() (:175-199) on a cost functor; recomputes both cost values every iteration like the
@@ -1150,7 +1183,11 @@ __device__ __forceinline__ Acc op_angle(const Consts<T>& k, const Ray<T>& r, boo
     else {  // 7: finite_diff (:370-372) over [P0, P1, P2, P3] = [h0, h1, (x,y), f]; position differences in fp64
         const T vx = (T)(Acc(11) * fx - Acc(18) * r.x + Acc(9) * (Acc)r.hx1 - Acc(2) * (Acc)r.hx0);
         const T vy = (T)(Acc(11) * fy - Acc(18) * r.y + Acc(9) * (Acc)r.hy1 - Acc(2) * (Acc)r.hy0);
+#if RTMI_ATAN_NEAR
+        return angle_near<T>(r.th, r.ux, r.uy, fma_(vy, r.ux, -(vx * r.uy)), fma_(vx, r.ux, vy * r.uy));
+#else
         return (Acc)M<T>::atan2_(vy, vx);
+#endif
     }
 }
 
