@@ -139,12 +139,12 @@ int rtmi_batch_create(const rtmi_field *f, const rtmi_params *p, int64_t R, cons
  * VECTOR_LIST, :73; may be NULL for other methods); istep[R] = last written row (NULL keeps it).  Every ray
  * with istep+1 < max_size becomes live.  This is the explicit-argument form of one selected_func call
  * (:868): opN(i_angle, init_n, i_grad, i_unitv, i_vpos, coef_i, grd, z, step) with caller-chosen inputs.
- * fp64 op2/op6 batches carry the unit tangent (cos theta, sin theta) as ray state (it is advanced by rotation, not
+ * fp64 op1/op2/op6/op8 batches carry the unit tangent (cos theta, sin theta) as ray state (it is advanced by rotation, not
  * recomputed from theta every step); a state set here restarts it from sin/cos of theta -- a state of the caller's own
  * making has no other.  To continue a run from a checkpoint use rtmi_batch_get_state / rtmi_batch_restore_state. */
 int rtmi_batch_set_state(rtmi_batch *b, const double *state9, const double *hist4, const int32_t *istep);
 /* Checkpoint: copy the current ray state to host buffers (any may be NULL), caller's ray order: state9 and istep as in
- * rtmi_batch_set_state; aux4[4][R] = the method's private state -- op7: the position history (hist4); fp64 op2/op6: rows 0-1
+ * rtmi_batch_set_state; aux4[4][R] = the method's private state -- op7: the position history (hist4); fp64 op1/2/6/8: rows 0-1
  * the carried unit tangent (cos, sin), rows 2-3 zero; otherwise zero; alive[R] = 1 while the ray would still step (0 once it
  * left the box, :878, or ran out of rows). */
 int rtmi_batch_get_state(rtmi_batch *b, double *state9, double *aux4, int32_t *istep, uint8_t *alive);

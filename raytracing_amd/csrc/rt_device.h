@@ -1263,11 +1263,19 @@ template <typename T, int METHOD> struct RotatesUnit {
     static constexpr bool value = (RTMI_UNIT_REFRESH_F32 > 0) && (METHOD == 2 || METHOD == 6);
     static constexpr int refresh = RTMI_UNIT_REFRESH_F32 > 0 ? RTMI_UNIT_REFRESH_F32 : 1;
 };
+// op1 and op8 as well (RTMI_ROT_18): their new angle is the old one plus a small turn too (angle_near), so their unit tangent
+// is rotated like op2/op6's.  op7 is not: its two extra state arrays' slots are the history's.
+#ifndef RTMI_ROT_18
+#define RTMI_ROT_18 1
+#endif
+constexpr bool rotating_method(int m) { return m == 2 || m == 6 || (RTMI_ROT_18 && RTMI_ATAN_NEAR && (m == 1 || m == 8)); }
 template <int METHOD> struct RotatesUnit<double, METHOD> {
-    static constexpr bool value = METHOD == 2 || METHOD == 6;
+    static constexpr bool value = rotating_method(METHOD);
     static constexpr int refresh = kUnitRefresh;
 };
-inline bool rotates_unit(int method, bool f64) { return (f64 || RTMI_UNIT_REFRESH_F32 > 0) && (method == 2 || method == 6); }
+inline bool rotates_unit(int method, bool f64) {
+    return f64 ? rotating_method(method) : (RTMI_UNIT_REFRESH_F32 > 0 && (method == 2 || method == 6));
+}
 
 // One iteration of trazar's loop for row index i (the row being produced); returns "still inside the box".
 // For op7 rows 1 and 2 are the bootstrap steps (:833-864): first- and second-order backward differences and

@@ -643,7 +643,7 @@ template <typename T> struct BatchDev {
     int has_hist;     // op7 only: hx0, hy0, hx1, hy1 follow n, gx, gy
     int exact;        // fp64 op3/4/5/9/10/11: derived values and lookups in the reference's operation order (rt_exact.h)
     int iso;          // the step kernels run their ISO build (gamma == 1, method < 10, not exact): coef taken as exactly 1
-    int rot;          // fp64 op2/op6 (rt::RotatesUnit): the unit vector (cos, sin) is state, kept in unit(0), unit(1)
+    int rot;          // fp64 op1/2/6/8 (rt::RotatesUnit): the unit vector (cos, sin) is state, kept in unit(0), unit(1)
     __device__ __forceinline__ double* acc(int q) const { return st + (size_t)q * R; }                 // 0..5: x y th dsim dreal tt
     __device__ __forceinline__ T* aux(int q) const { return reinterpret_cast<T*>(st + (size_t)6 * R) + (size_t)q * R; }   // 0..2: n gx gy; 3..6: history
     __device__ __forceinline__ T* unit(int q) const { return aux(3 + q); }     // rot batches have no history arrays
