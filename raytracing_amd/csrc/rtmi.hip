@@ -824,8 +824,10 @@ template <typename T> __device__ __forceinline__ const BatchDev<T>& rare_batch(c
 #ifndef RTMI_TILE_WAVES
 #define RTMI_TILE_WAVES 4      // waves per SIMD the LDS-tile variant of k_advance is built for (the light methods)
 #endif
-// op2 and op6 (one field lookup per step, no golden section, no curvature terms) fit one more wave per SIMD than the rest
-constexpr bool light_method(int m) { return m == 2 || m == 6; }
+// op2 and op6 (one field lookup per step, no golden section, no curvature terms) fit one more wave per SIMD than the rest;
+// with the cell-polynomial lookup op1/7/8 do too (they spill 60-90 bytes per lane at 128 VGPRs and are still 8-10 % faster at
+// four waves than at three: op1 8.97 -> 8.03 ms)
+constexpr bool light_method(int m) { return m == 2 || m == 6 || (RTMI_POLY && (m == 1 || m == 7 || m == 8)); }
 // op4 and the golden-section methods carry the most state: their tile builds keep two waves per SIMD
 constexpr bool heavy_method(int m) { return m == 4 || m == 5 || m >= 9; }
 #ifndef RTMI_GLOBAL_WAVES
