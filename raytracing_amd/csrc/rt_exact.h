@@ -97,9 +97,21 @@ __device__ __forceinline__ double sq(double x) { return x * x; }                
 __device__ __forceinline__ double dot2(double a0, double a1, double b0, double b1) { return __builtin_fma(a1, b1, a0 * b0); }
 __device__ __forceinline__ double norm2(double a0, double a1) { return sqrt_(dot2(a0, a1, a0, a1)); }
 __device__ __forceinline__ double aniso(double s, double c, double gamma) { return sqrt_(sq(gamma * s) + sq(c)); }   // :118-119
+// a / d from r = RN(1 / d): Markstein's division (see axis_exact below) -- the correctly rounded quotient in 3 instructions
+__device__ __forceinline__ double mdiv(double a, double d, double r) {
+    const double q0 = a * r;
+    return fma_(fma_(-d, q0, a), r, q0);
+}
 // moment() (:217-230) with coef = anisotropy(theta, gamma) passed in
 __device__ __forceinline__ double moment(double n, double coef, double g2m1, double o0, double o1) {
     return n * coef * o0 * (1.0 + o1 * g2m1 / sq(coef));
+}
+// both moments of one direction (cos, sin) = (c, s): they divide by the same coef^2 -- one IEEE reciprocal and two Markstein
+// divisions give the two IEEE quotients (17 instructions for 22)
+__device__ __forceinline__ void moments(double n, double coef, double g2m1, double c, double s, double& mx, double& my) {
+    const double d = sq(coef), r = 1.0 / d;
+    mx = n * coef * c * (1.0 + mdiv(-sq(s) * g2m1, d, r));
+    my = n * coef * s * (1.0 + mdiv(sq(c) * g2m1, d, r));
 }
 __device__ __forceinline__ double impulse(double a, double b, double step) { return step * (a + b) / 2.0; }          // :214
 
@@ -115,10 +127,6 @@ __device__ __forceinline__ double impulse(double a, double b, double step) { ret
 // thm 8.3 -- no overflow or underflow here: 0 <= a <= 1, d ~ the grid pitch): 3 instructions for the 11 of the IEEE sequence
 // (v_div_scale x2, v_rcp, four fma, v_div_fmas, v_div_fixup), 110 fewer per lookup.  Bits: every test that holds a
 // reference-order method to the oracle's bits runs through it (the oracle divides).
-__device__ __forceinline__ double mdiv(double a, double d, double r) {
-    const double q0 = a * r;
-    return fma_(fma_(-d, q0, a), r, q0);
-}
 __device__ __forceinline__ void axis_exact(double v, int q, double a, double h, double b, double ih, const double* rd, int& j, int& l,
                                            double wl[2], double w[4]) {
     double t0, t1;
@@ -205,8 +213,9 @@ __device__ __forceinline__ void adv_first(const Ray<double>& r, double step, dou
 }
 __device__ __forceinline__ void adv_second(const Ray<double>& r, const Consts<double>& k, double& fx, double& fy) {   // :330
     const double d = dot2(r.gx, r.gy, r.ux, r.uy);
-    fx = (r.x + r.ux * k.step) + (r.gx - d * r.ux) * k.step2 / (2.0 * r.n);
-    fy = (r.y + r.uy * k.step) + (r.gy - d * r.uy) * k.step2 / (2.0 * r.n);
+    const double den = 2.0 * r.n, rden = 1.0 / den;      // both quotients by 2n: one IEEE reciprocal, two Markstein divisions
+    fx = (r.x + r.ux * k.step) + mdiv((r.gx - d * r.ux) * k.step2, den, rden);
+    fy = (r.y + r.uy * k.step) + mdiv((r.gy - d * r.uy) * k.step2, den, rden);
 }
 // returns the reference's flag: true == curvature NOT negligible (quirk Q14)
 __device__ __forceinline__ bool adv_curv(const Ray<double>& r, const Consts<double>& k, double& fx, double& fy) {
@@ -330,12 +339,14 @@ __device__ __forceinline__ double golden_filtered(FastA fast_a, double EA, Expan
     }
     if (!(__builtin_fabs(c - d) > tol)) return (b + a) / 2.0;
     // ---- phase T.  Centre: theta moved by one Newton step (with the cubic term) of the expansion at theta.
-    const GoldExpansion X0 = expand(s0, c0);
-    const double x0 = -X0.F1 / X0.F2;
-    const double xs = fma_(-0.5 * X0.F3 * x0, x0 / X0.F2, x0);
+    // (the centre is a choice, not a result: whatever it is, the thresholds below hold for it and the outcomes are the
+    // reference's -- so the Newton step needs neither IEEE divisions nor the third derivative: without the cubic term it lands
+    // within x0^2 |F3 / 2 F2| of the minimiser, 2e-7 for the 4e-4 a step turns by, where the remainder bound wants < 4e-5)
+    const GoldExpansion X0 = expand(s0, c0, false);
+    const double xs = -X0.F1 * rcp_full(X0.F2);
     double s1, c1;
     sincos_add_small(s0, c0, xs, &s1, &c1);                     // |xs| < 2^-5 is checked below
-    const GoldExpansion T = expand(s1, c1);
+    const GoldExpansion T = expand(s1, c1, true);
     const double t0 = th + xs;
     // the centre's angle is known to: the rounding of th + xs and of t - t0, the series of the rotation (angle error < 4u),
     // and theta against its carried (sin, cos) -- a uniform shift eps0 of every xi, i.e. an error F2*eps0 of V
@@ -354,7 +365,7 @@ __device__ __forceinline__ double golden_filtered(FastA fast_a, double EA, Expan
     const double E1x2 = 2.0 * E[1], K3x2 = 2.0 * B.K3;
     // outside what the bounds were derived for (never on the path): every comparison goes to the reference's arithmetic
     const bool ok = X0.F2 > 0.0 && T.F2 > 0.0 && __builtin_fabs(xs) < 0.03125 && __builtin_fabs(T.F3) < 1e300 && M4c < 1e300;
-    double invd = 1.002 / (d - c);                              // 1/(d - c): slack for the recurrence against the rounded widths
+    double invd = 1.002 * rcp_full(d - c);                      // 1/(d - c): slack for the recurrence against the rounded widths (and the reciprocal's ulp)
     // The threshold is thrA / (d - c) + thrB with thrA = M4c rho^4 + noise(rho), thrB = rho (rho cF3 + cF2) + errV0, both
     // increasing in rho, and rho never grows (every c, d lies inside the bracket before): a threshold formed from an EARLIER
     // iteration's thrA, thrB is still a valid one.  So they are refreshed only for a lane whose comparison the kept pair does
@@ -399,8 +410,8 @@ __device__ __attribute__((noinline)) double exact_cost_aniso(double t, double fn
     const SinCos u = sincos_(t);
     const double s = u.s, c = u.c;                                                                    // (:728, :761)
     const double a = aniso(s, c, gam);
-    const double mx = moment(fn, a, g2, c, -sq(s));
-    const double my = moment(fn, a, g2, s, sq(c));
+    double mx, my;
+    moments(fn, a, g2, c, s, mx, my);
     return sq(mx - mix - impulse(cgx, a * fgx, step)) + sq(my - miy - impulse(cgy, a * fgy, step));
 }
 
@@ -472,8 +483,8 @@ __device__ __forceinline__ double ang_golden_aniso(const Ray<double>& r, const C
                                                    double fgy) {
     const double gam = k.gamma_s, g2 = k.g2m1_s, step = k.step;
     const double c0 = aniso(r.uy, r.ux, gam);
-    const double mix = moment(r.n, c0, g2, r.ux, -sq(r.uy));
-    const double miy = moment(r.n, c0, g2, r.uy, sq(r.ux));
+    double mix, miy;
+    moments(r.n, c0, g2, r.ux, r.uy, mix, miy);
     const double cgx = r.coef * r.gx, cgy = r.coef * r.gy;
     auto exact = [=](double t) { return exact_cost_aniso(t, fn, gam, g2, mix, miy, cgx, cgy, fgx, fgy, step); };
     // Fast form: with a^2 = gamma^2 s^2 + c^2 the reference's brackets are 1 - s^2 (gamma^2-1)/a^2 = 1/a^2 and
@@ -521,7 +532,7 @@ __device__ __forceinline__ double ang_golden_aniso(const Ray<double>& r, const C
     //   D3 M = n1 gamma^2 A^7 ( s [(1 - 2G s^2 + 4G c^2) a^2 + 5G c^2 (1 - 2G s^2)], -c [(1 + 3G - 6G s^2) a^2 - 5G s^2 (1 + 3G - 2G s^2)] )
     //   D a = G s c A     D2 a = G A [(c^2 - s^2) - G s^2 c^2 A^2]     D3 a = G s c A [-4 - 3G (c^2 - s^2) A^2 + 3 G^2 s^2 c^2 A^4]
     // (tools/check_aniso_derivatives.py compares them with mpmath's numerical derivatives.)
-    auto expand = [=](double s, double c) {
+    auto expand = [=](double s, double c, const bool third) {
         const double ss = s * s, cc = c * c, sc = s * c;
         const double a2 = fma_(gam2, ss, cc);
         double A = __builtin_amdgcn_rsq(a2);
@@ -532,19 +543,24 @@ __device__ __forceinline__ double ang_golden_aniso(const Ray<double>& r, const C
         const double u1 = fma_(-2.0, Gss, 1.0), u2 = fma_(3.0, g2, u1);            // 1 - 2G s^2, 1 + 3G - 2G s^2
         const double hx = fgx * hstep, hy = fgy * hstep;                            // g1 step/2
         const double a1 = g2 * sc * A, a2d = g2 * A * fma_(-Gss * cc, A2, dif);
-        const double a3 = a1 * fma_(3.0 * Gss * Gcc * A2, A2, fma_(-3.0 * g2 * dif, A2, -4.0));
+
         const double e0x = fn * c * A - mix - fma_(a, fgx, cgx) * hstep, e0y = kk * s * A - miy - fma_(a, fgy, cgy) * hstep;
-        const double k3 = kk * A3, k5 = kk * A5, k7 = kk * A7;
+        const double k3 = kk * A3, k5 = kk * A5;
         const double e1x = fma_(-a1, hx, -(k3 * s)), e1y = fma_(-a1, hy, k3 * c);
         const double e2x = fma_(-a2d, hx, -(k5 * c * u1)), e2y = fma_(-a2d, hy, -(k5 * s * u2));
-        const double m3x = k7 * s * fma_(fma_(4.0, Gcc, u1), a2, 5.0 * Gcc * u1);
-        const double m3y = -(k7 * c) * fma_(fma_(-4.0, Gss, u2), a2, -5.0 * Gss * u2);
-        const double e3x = fma_(-a3, hx, m3x), e3y = fma_(-a3, hy, m3y);
         GoldExpansion X;
         X.g0 = __builtin_fabs(e0x) + __builtin_fabs(e0y);
         X.F1 = 2.0 * fma_(e0y, e1y, e0x * e1x);
         X.F2 = 2.0 * (fma_(e1y, e1y, e1x * e1x) + fma_(e0y, e2y, e0x * e2x));
-        X.F3 = 2.0 * fma_(3.0, fma_(e1y, e2y, e1x * e2x), fma_(e0y, e3y, e0x * e3x));
+        X.F3 = 0.0;
+        if (third) {       // a compile-time constant at both call sites
+            const double k7 = kk * A7;
+            const double a3 = a1 * fma_(3.0 * Gss * Gcc * A2, A2, fma_(-3.0 * g2 * dif, A2, -4.0));
+            const double m3x = k7 * s * fma_(fma_(4.0, Gcc, u1), a2, 5.0 * Gcc * u1);
+            const double m3y = -(k7 * c) * fma_(fma_(-4.0, Gss, u2), a2, -5.0 * Gss * u2);
+            const double e3x = fma_(-a3, hx, m3x), e3y = fma_(-a3, hy, m3y);
+            X.F3 = 2.0 * fma_(3.0, fma_(e1y, e2y, e1x * e2x), fma_(e0y, e3y, e0x * e3x));
+        }
         return X;
     };
     // |D^k e| <= n1 D_k + (step/2) max|g1| A_k with D_k, A_k the suprema over all angles of the k-th derivatives of the unit
@@ -596,8 +612,7 @@ __device__ __forceinline__ void store_update(const Consts<double>& k, Ray<double
     const SinCos u = sincos_(fth);
     const double c = u.c, s = u.s;
     const double coef = aniso(s, c, k.gamma);
-    r.mx = moment(fn, coef, k.g2m1, c, -sq(s));
-    r.my = moment(fn, coef, k.g2m1, s, sq(c));
+    moments(fn, coef, k.g2m1, c, s, r.mx, r.my);
     r.hx0 = r.hx1; r.hy0 = r.hy1; r.hx1 = r.x; r.hy1 = r.y;
     r.x = fx; r.y = fy; r.th = fth; r.n = fn; r.gx = fgx; r.gy = fgy;
     r.ux = c; r.uy = s; r.coef = coef;
@@ -613,8 +628,7 @@ __device__ __forceinline__ void derive(const Consts<double>& k, Ray<double>& r) 
     r.coef = aniso(r.uy, r.ux, k.gamma);
     r.nray = r.coef * r.n;
     r.rn = 0;
-    r.mx = moment(r.n, r.coef, k.g2m1, r.ux, -sq(r.uy));
-    r.my = moment(r.n, r.coef, k.g2m1, r.uy, sq(r.ux));
+    moments(r.n, r.coef, k.g2m1, r.ux, r.uy, r.mx, r.my);
 }
 
 template <int METHOD, typename G>
