@@ -440,7 +440,22 @@ __device__ __forceinline__ double ang_golden_iso(const Ray<double>& r, double st
     const double Px = px + ix, Py = py + iy;
     // P turned by -theta with the carried (cos theta, sin theta): its angle is phi = psi - theta, |phi| << 1
     const double Pc = fma_(Py, r.uy, Px * r.ux), Ps = fma_(Py, r.ux, -(Px * r.uy));
-    const double phi = ::atan2(Ps, Pc);
+    // phi is small (the turn of one step) and enters the comparisons with an error allowance of its own (Ca): atan of the
+    // ratio by a five-term series for |t| < 2^-5 (error < 2^-53 |t|) instead of ocml's atan2; larger turns take atan2
+    double phi;
+    {
+        const double t = Ps * rcp_full(Pc);
+        const bool near = Pc > 0.0 && __builtin_fabs(t) < 0.03125;
+        auto series = [&]() {
+            const double z = t * t;
+            double p = fma_(z, 1.0 / 9.0, -1.0 / 7.0);
+            p = fma_(z, p, 1.0 / 5.0);
+            p = fma_(z, p, -1.0 / 3.0);
+            return fma_(t * z, p, t);
+        };
+        if (rt_ballot(!near) == 0ull) phi = series();
+        else phi = near ? series() : ::atan2(Ps, Pc);
+    }
     const double P2 = fma_(Ps, Ps, Pc * Pc);
     double rP = __builtin_amdgcn_rsq(P2);
     rP = fma_(rP * 0.5, fma_(-P2 * rP, rP, 1.0), rP);
