@@ -958,9 +958,9 @@ def test_random_rays_through_grid_ends_vs_oracle(scen, m, rb, gpu_fields, oracle
 
 @pytest.mark.parametrize("qx,qy", [(8, 8), (12, 10), (40, 17)])
 def test_small_custom_grids_vs_oracle(qx, qy, rb):
-    """interpolacion() on caller-sampled grids far smaller than the LDS tile and the interior fast path assume:
-    every cell then takes FITPACK's general not-a-knot arithmetic and the global gather.  Coefficients, point
-    lookups (inside and outside the grid) and short traces against the oracle."""
+    """interpolacion() on caller-sampled grids so small that every cell touches the not-a-knot ends (the regime rounds 1-2's
+    LDS tile and uniform-knot fast path excluded; the cell polynomials have no such case).  Coefficients, point lookups
+    (inside and outside the grid) and short traces against the oracle."""
     from oracle import rt_oracle as O
     rng = np.random.default_rng(qx * 100 + qy)
     x = np.linspace(-1.0, 2.0, qx); y = np.linspace(0.5, 2.5, qy)
@@ -1299,4 +1299,38 @@ def test_step_repeat_graph_equals_single_steps(scen, m, stride, rb, gpu_fields):
     d = make(); d.step(1, 37); d.step(3, 11)
     assert np.array_equal(c.final(), d.final()) and np.array_equal(c.d_ray(), d.d_ray())
     b.close(); c.close(); d.close()
+
+
+@pytest.mark.parametrize("qx,qy", [(8, 8), (9, 31), (64, 11), (120, 75)])
+def test_cell_polynomials_on_arbitrary_grids(qx, qy, rb):
+    """The polynomial table on caller-provided samples (rtmi_field_from_samples): the smallest grid the cubic fit takes (8 x 8:
+    every cell is a rim cell), long thin ones, a larger one; a smooth field with a kink.  The fast-form lookup against
+    FITPACK's arithmetic on the same device-built coefficients (rtmi_field_eval), and op1/2/6/8 trajectories of rays launched
+    anywhere in the box -- through the not-a-knot end cells, some leaving the grid -- against the oracle."""
+    from oracle import rt_oracle as O
+    rng = np.random.default_rng(1000 * qx + qy)
+    x = np.linspace(-1.0, 2.0, qx); y = np.linspace(0.5, 2.5, qy)
+    X, Y = np.meshgrid(x, y)
+    Z = 1.3 + 0.25 * np.sin(1.1 * X + 0.3) * np.cos(0.9 * Y) + 0.1 * np.abs(X - 0.4)
+    delta = 0.5 * ((x[1] - x[0]) + (y[1] - y[0]))
+    F = rb.Field.from_samples(x, y, Z, delta)
+    OF = O.Field.from_samples(x, y, Z, delta)
+    px = rng.uniform(x[0] - 0.3, x[-1] + 0.3, 20_000); py = rng.uniform(y[0] - 0.3, y[-1] + 0.3, 20_000)
+    fast, fit = F.lookup_fast(px, py), F.n_gradient(px, py)
+    scale = [np.abs(Z).max(), max(np.abs(F.arrays()[3]).max(), np.abs(F.arrays()[4]).max())]
+    for a, b, sc in zip(fast, fit, (scale[0], scale[1], scale[1])):
+        assert np.abs(a - b).max() < 5e-15 * sc
+    R = 192
+    x0 = rng.uniform(x[0] + 0.05, x[-1] - 0.05, R); y0 = rng.uniform(y[0] + 0.05, y[-1] - 0.05, R); th = rng.uniform(-np.pi, np.pi, R)
+    lim = (x[0] + 0.01, x[-1] - 0.01, y[0] + 0.01, y[-1] - 0.01)
+    for m in (1, 2, 6, 8):
+        b = rb.Batch(F, m, 0.004, 1500, lim, 1, th, x0, y0, record_stride=0)
+        b.run()
+        d, fin = b.d_ray(), b.final()
+        b.close()
+        o = O.trazar(OF, m, 1, 0.004, 1500, lim, x0, y0, th, record_stride=0)
+        same = d[2] == o["d_ray"][2]
+        assert same.mean() > 0.98                                       # a ray grazing the box may leave one step apart
+        assert relerr(fin[:, same], o["final"][:, same]) < 1e-9, m
+    F.close()
 
