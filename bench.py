@@ -306,17 +306,20 @@ def main():
     untimed = max(args.warmup, 4 if args.mode == "auto" else 1)
     for _ in range(untimed):
         one_pass()
+    k0 = batch.stats()                       # kernel time and launches so far (rtmi_stats.*_total survive the resets)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_pass()
     barrier()
     dt = time.perf_counter() - t0
-    st = batch.stats()                       # counters and kernel time of the LAST pass (reset clears them)
+    st = batch.stats()                       # counters of the LAST pass (reset clears them), totals of all
     assert st["live_rays"] == 0, "a pass ended with live rays"
     steps_per_pass = st["ray_steps"]
-    kern_ms = st["kernel_ms"]                # all advance launches of the pass together
-    launches = max(st["launches"], 1)
+    # advance-kernel time per pass: the mean over the K timed passes themselves (HIP events on the batch's stream, folded
+    # by the two stats calls around the timed region: no host sync per pass)
+    kern_ms = (st["kernel_ms_total"] - k0["kernel_ms_total"]) / args.steps
+    launches = max(int(round((st["launches_total"] - k0["launches_total"]) / args.steps)), 1)
     mode_used = st["launch_mode_used"] if args.chunk <= 0 else "plain"
     gathered = None
     parity_failed = False

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 4
+#define RTMI_ABI_VERSION 5
 
 typedef enum {
     RTMI_OK = 0,
@@ -228,6 +228,10 @@ typedef struct {
     uint32_t launches;       /* advance-kernel launches since create/reset */
     uint32_t vgprs, sgprs, lds_bytes;   /* of the advance kernel in use */
     uint32_t launch_mode_used;          /* rtmi_launch_mode of the last rtmi_run (RTMI_LAUNCH_PLAIN after rtmi_step) */
+    double kernel_ms_total;             /* the same sum over the batch's whole life: rtmi_batch_reset does not clear it, so a
+                                           caller that times many passes (reset + run each) gets the kernel time of all of
+                                           them from two stats calls, one before and one after, without a host sync per pass */
+    uint64_t launches_total;            /* advance-kernel launches since create */
 } rtmi_stats;
 /* Synchronises the stream, then fills *s. */
 int rtmi_batch_stats(rtmi_batch *b, rtmi_stats *s);

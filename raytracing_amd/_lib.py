@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RTMI_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants in one session)
 LIB_PATH = os.environ.get("RTMI_LIB_PATH") or os.path.join(_HERE, "librtmi.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 # rtmi_launch_mode (include/rtmi.h)
 LAUNCH_AUTO, LAUNCH_REFILL, LAUNCH_SLICED, LAUNCH_PLAIN = 0, 1, 2, 3
 LAUNCH_MODES = {"auto": LAUNCH_AUTO, "refill": LAUNCH_REFILL, "sliced": LAUNCH_SLICED, "plain": LAUNCH_PLAIN, "lane": LAUNCH_PLAIN}
@@ -44,7 +44,7 @@ class DeviceView(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("ray_steps", C.c_uint64), ("live_rays", C.c_uint64), ("kernel_ms", C.c_double),
                 ("launches", C.c_uint32), ("vgprs", C.c_uint32), ("sgprs", C.c_uint32), ("lds_bytes", C.c_uint32),
-                ("launch_mode_used", C.c_uint32)]
+                ("launch_mode_used", C.c_uint32), ("kernel_ms_total", C.c_double), ("launches_total", C.c_uint64)]
 
 
 # every symbol include/rtmi.h declares: name -> (restype, argtypes)

@@ -1266,7 +1266,10 @@ struct rtmi_batch {
     unsigned long long* h_counters = nullptr;  // pinned host [2]
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
     size_t ev_used = 0;
+    size_t pass_ev_start = 0;    // events[pass_ev_start ..] belong to the present pass (since the last reset); earlier ones to passes before
     double kernel_ms = 0;
+    double total_kernel_ms = 0;  // all advance launches since create (a reset does not clear it)
+    uint64_t total_launches = 0;
     uint32_t launches = 0;
     const void* kfn = nullptr;
     const void* kfn_refill = nullptr;
@@ -1478,7 +1481,9 @@ static int batch_init_state(rtmi_batch* b, bool clear_traj) {
     if (b->p.dtype == RTMI_F64) hipLaunchKernelGGL(k_init<double>, g, blk, 0, st, batch_dev<double>(b));
     else hipLaunchKernelGGL(k_init<float>, g, blk, 0, st, batch_dev<float>(b));
     HIP_TRY(hipGetLastError());
-    b->kernel_ms = 0; b->launches = 0; b->ev_used = 0; b->dirty_state = false;
+    // the events of the pass before stay on the list (they are folded into total_kernel_ms at the next stats call or when the
+    // list is full): a caller timing many passes reads the kernel time of all of them without a host sync per pass
+    b->kernel_ms = 0; b->launches = 0; b->pass_ev_start = b->ev_used; b->dirty_state = false;
     return RTMI_OK;
 }
 
@@ -1798,9 +1803,11 @@ static int fold_events(rtmi_batch* b) {
     for (size_t i = 0; i < b->ev_used; i++) {
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, b->events[i].first, b->events[i].second));
-        b->kernel_ms += ms;
+        b->total_kernel_ms += ms;
+        if (i >= b->pass_ev_start) b->kernel_ms += ms;
     }
     b->ev_used = 0;
+    b->pass_ev_start = 0;
     return RTMI_OK;
 }
 
@@ -1893,7 +1900,7 @@ RTMI_EXPORT int rtmi_step_repeat(rtmi_batch* b, int32_t nsteps, int32_t count) {
     HIP_TRY(hipEventRecord(evp->first, b->stream));
     HIP_TRY(hipGraphLaunch(b->graph_exec, b->stream));
     HIP_TRY(hipEventRecord(evp->second, b->stream));
-    b->launches += (uint32_t)count;
+    b->launches += (uint32_t)count; b->total_launches += (uint64_t)count;
     b->mode_used = RTMI_LAUNCH_PLAIN;
     return RTMI_OK;
 }
@@ -1913,7 +1920,7 @@ RTMI_EXPORT int rtmi_step(rtmi_batch* b, int32_t nsteps) {
     else launch_advance<float>(b, nsteps);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev.second, b->stream));
-    b->launches++;
+    b->launches++; b->total_launches++;
     b->mode_used = RTMI_LAUNCH_PLAIN;
     return RTMI_OK;
 }
@@ -1965,7 +1972,7 @@ static int run_sliced(rtmi_batch* b, std::pair<hipEvent_t, hipEvent_t>** evp) {
     else launch_sliced<float>(b, slice, capacity);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ev->second, b->stream));
-    b->launches++;
+    b->launches++; b->total_launches++;
     b->mode_used = RTMI_LAUNCH_SLICED;
     rc = read_counters(b);
     if (rc) return rc;
@@ -2005,7 +2012,7 @@ RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
         else launch_refill<float>(b);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipEventRecord(ev->second, b->stream));
-        b->launches++;
+        b->launches++; b->total_launches++;
         b->mode_used = RTMI_LAUNCH_REFILL;
         return read_counters(b);
     }
@@ -2338,6 +2345,8 @@ RTMI_EXPORT int rtmi_batch_stats(rtmi_batch* b, rtmi_stats* s) {
     s->live_rays = b->h_counters[1];
     s->kernel_ms = b->kernel_ms;
     s->launches = b->launches;
+    s->kernel_ms_total = b->total_kernel_ms;
+    s->launches_total = b->total_launches;
     hipFuncAttributes fa;
     s->vgprs = s->sgprs = s->lds_bytes = 0;
     s->launch_mode_used = (uint32_t)b->mode_used;

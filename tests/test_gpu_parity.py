@@ -1334,3 +1334,21 @@ def test_cell_polynomials_on_arbitrary_grids(qx, qy, rb):
         assert relerr(fin[:, same], o["final"][:, same]) < 1e-9, m
     F.close()
 
+
+def test_stats_totals_survive_reset(rb, gpu_fields):
+    """rtmi_stats.kernel_ms_total / launches_total: the advance kernels of every pass since create (bench.py's kernel time per
+    pass), while kernel_ms / launches restart with rtmi_batch_reset."""
+    th = np.linspace(0.1, 1.4, 3000)
+    b = rb.Batch(gpu_fields("vert_heterogeneous"), 6, rb.DELTA_S, 30228, LIMITS["vert_heterogeneous"], 1, th, -2.0, -2.0,
+                 record_stride=0)
+    per_pass = []
+    for _ in range(3):
+        b.reset(); b.run()
+        per_pass.append(b.stats()["kernel_ms"])
+    b.reset(); b.run(); b.reset(); b.run()                 # two passes without a stats call in between
+    st = b.stats()
+    assert st["launches"] == 1 and st["launches_total"] == 5
+    assert st["kernel_ms"] > 0 and abs(st["kernel_ms_total"] - (sum(per_pass) + 2 * st["kernel_ms"])) < 0.5 * st["kernel_ms_total"]
+    assert st["kernel_ms_total"] > sum(per_pass) + st["kernel_ms"]
+    b.close()
+
