@@ -72,6 +72,31 @@ def min_hbm_bytes(dtype, stride, ray_steps, rays, method, n_ray):
     return rows * (7 if n_ray else 6) * e + 2.0 * rays * (48 + (7 if method == 7 else 3) * e + 5)
 
 
+# quantities that share a scale, by the length of an array's quantity axis (the second to last: [.., quantity, ray]):
+#   9 final state  x y | theta | n | dn/dx dn/dy | p_x p_y | T        6 recorded row  x y | p_x p_y | T | theta
+#   3 d_ray        dist_real dist_sim | last row                     2 d_ray[:2]
+QUANTITY_GROUPS = {9: ((0, 1), (2,), (3,), (4, 5), (6, 7), (8,)), 6: ((0, 1), (2, 3), (4,), (5,)), 3: ((0, 1), (2,)), 2: ((0, 1),)}
+
+
+def parity_relerr(a, b):
+    """max |a - b| / scale with a scale PER QUANTITY: the largest |b| of that quantity (vector quantities -- position, momentum,
+    gradient -- as one) over the whole fixture.  "1e-9 relative" then means 1e-9 of p_x ~ 0.05 or T ~ 0.4 as much as of
+    x ~ 5; dividing by max(|b|, 1) instead would hold everything below 1 in magnitude to an ABSOLUTE 1e-9."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    if a.size == 0:
+        return 0.0
+    groups = QUANTITY_GROUPS[a.shape[-2]]
+    worst = 0.0
+    for g in groups:
+        sel = list(g)
+        bb, aa = np.take(b, sel, axis=-2), np.take(a, sel, axis=-2)
+        scale = float(np.max(np.abs(bb)))
+        diff = float(np.max(np.abs(aa - bb)))
+        if diff > 0.0:
+            worst = max(worst, diff / scale if scale > 0.0 else np.inf)
+    return worst
+
+
 def fan(scen, R_total, rank, world):
     lo, hi = SCEN[scen]["theta"]
     step = (hi - lo) / (R_total - 1)
@@ -111,7 +136,8 @@ def cpu_baseline(args, rb, budget_s, rays):
 def parity_check(args, rb, batch, th, stride, step, max_size, lim):
     """The batch that was just timed against the oracle: every args.parity_stride-th ray -- step counts (exactly), d_ray and
     final state, and with a dense record every recorded row of those rays, read from the device copy.  fp64: 1e-9 relative
-    (|a - b| / max(|b|, 1), the tolerance of tests/test_gpu_parity.py); fp32 has no reference and is only reported."""
+    (parity_relerr: per quantity, relative to that quantity's largest magnitude in the sample -- the measure of
+    tests/test_gpu_parity.py); fp32 has no reference and is only reported."""
     from oracle import rt_oracle as O
     sc = SCEN[args.scenario]
     sub = slice(0, len(th), args.parity_stride)
@@ -125,8 +151,7 @@ def parity_check(args, rb, batch, th, stride, step, max_size, lim):
     d = batch.d_ray()[:, sub]
     fin = batch.final()[:, sub]
 
-    def rel(a, b):
-        return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0))) if a.size else 0.0
+    rel = parity_relerr           # per-quantity scales
     steps_equal = bool(np.array_equal(d[2], o["d_ray"][2]))
     same = d[2] == o["d_ray"][2]
     err = max(rel(fin[:, same], o["final"][:, same]), rel(d[:2, same], o["d_ray"][:2, same]))
@@ -154,6 +179,47 @@ def trace_step(args, rb):
     if args.scenario == "fisheye":
         return 2 * np.pi / 303, rb.N * 304          # calibrated op6 step (RT_bench.py:1443, :1450)
     return rb.DELTA_S, int(np.ceil(c[4] / rb.DELTA_S) + 1)
+
+
+def launcher_command(argv, gpus, port, python=None):
+    """The N ranks of `python bench.py --gpus N ...` as one child command: torch.distributed.run, one process per GPU on this
+    node, rendezvous on 127.0.0.1, the SAME bench.py arguments (argv = sys.argv[1:], untouched)."""
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def run_ranks(argv, gpus):
+    """`python bench.py --gpus N` started plainly (no WORLD_SIZE in the environment), N > 1: start the N ranks as a CHILD
+    process tree -- never an exec of this process, and before anything here has touched a GPU -- wait for it, print rank 0's
+    ONE JSON line on stdout (everything else the ranks wrote goes to stderr) and return the child's exit status."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this pool's host driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or gpus) // gpus)))
+    cmd = launcher_command(argv, gpus, free_port())
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, text=True)
+    line = None
+    for out in child.stdout:
+        if out.startswith('{"metric"'):
+            line = out.rstrip("\n")
+        else:
+            sys.stderr.write(out)
+    rc = child.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited 0 without a JSON line\n")
+        rc = 1
+    return rc
 
 
 def main():
@@ -196,13 +262,18 @@ def main():
                          "multi-rank path on a box with fewer GPUs than ranks)")
     ap.add_argument("--all-on-device", type=int, default=None,
                     help="rehearsal only: every rank uses this HIP device instead of LOCAL_RANK")
+    ap.add_argument("--gather-rows", type=int, default=64,
+                    help="N>1 read-back: gather every this-many-th recorded row of every rank's trajectory to rank 0, device to "
+                         "device (0 = only d_ray and the end points)")
     ap.add_argument("--emulate-world", type=int, default=0,
                     help="single GPU, no torch.distributed: run the shard rank --emulate-rank would own in a world of this size")
     ap.add_argument("--emulate-rank", type=int, default=0)
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed even with one rank and run the N>1 collectives through it")
     ap.add_argument("--reference-order", action="store_true",
-                    help="rtmi_params.reference_order: op1/2/6/7/8 too in the reference's own operation order (op2/op6: its bits)")
+                    help="rtmi_params.reference_order = 1: op1/2/6/8 too in the reference's own operation order (op7 always is)")
+    ap.add_argument("--fused", action="store_true",
+                    help="rtmi_params.reference_order = 2: fused forms wherever there is one -- op7 too (outside 1e-9 on interface)")
     ap.add_argument("--parity-stride", type=int, default=512, help="parity_check: every this-many-th ray (0 = skip)")
     args = ap.parse_args()
     if args.method is None:
@@ -210,13 +281,17 @@ def main():
     if args.mode == "lane":
         args.mode = "plain"
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as `python bench.py --gpus N`: this process becomes the launcher of its own N ranks (nothing here has
+        # imported torch or touched a GPU yet); under torch.distributed.run WORLD_SIZE is set and this is one of the ranks
+        sys.exit(run_ranks(sys.argv[1:], args.gpus))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus must agree")
     if not torch.cuda.is_available():
         sys.exit("bench.py: no HIP device (raytracing_amd has no CPU path)")
     if args.all_on_device is not None:
@@ -268,7 +343,7 @@ def main():
                         launch_mode=args.mode, refill_min=args.refill_min, slice_steps=args.slice_steps,
                         field_path={"auto": 0, "global": 1, "lds": 2, "shared": 2}[args.field_path], sort_rays=args.sort,
                         lazy_clear=True,    # every pass re-runs the same launch conditions: same rows rewritten
-                        keep_n_ray=args.n_ray, reference_order=args.reference_order)
+                        keep_n_ray=args.n_ray, reference_order=2 if args.fused else int(args.reference_order))
 
     try:
         batch = make_batch(stride, rec_rows)
@@ -326,23 +401,50 @@ def main():
     if use_dist:
         dt = rd.max_over_ranks(dt, cdev)
         total_steps = rd.sum_over_ranks(steps_per_pass, cdev) * args.steps
-        # Read-back of the sharded layout (outside the timed region): d_ray = (dist_real, dist_sim, last row) and the
-        # end points, gathered to rank 0 device-to-device from zero-copy views of the library's SoA state.
+        # Read-back of the sharded layout (outside the timed region), device to device over the collective backend (nccl =
+        # RCCL over xGMI): d_ray = (dist_real, dist_sim, last row) and the end points from zero-copy views of the library's
+        # SoA state, and the trajectory itself -- every --gather-rows-th recorded row of s_ray[rows][6][R_local], a strided
+        # view of the record in HBM (the whole 151 GB record of every rank does not fit one GPU; a rank's own record stays
+        # where it is for the on-device consumers: metrics, isochrones, wavefronts).
         try:
             t_ = batch.device_tensors()
             loc = torch.stack((t_["dist_real"].double(), t_["dist_sim"].double(), t_["istep"].double(),
                                t_["x"].double(), t_["y"].double())).to(cdev)            # [5, R_local]
             Rmax = (R_total + world - 1) // world if not args.emulate_world else R_local
-            if loc.shape[1] < Rmax:                                                      # ragged strong split: pad
-                loc = torch.cat((loc, torch.full((5, Rmax - loc.shape[1]), float("nan"), dtype=loc.dtype, device=loc.device)), 1)
-            g = [torch.empty_like(loc) for _ in range(world)] if rank == 0 else None
-            dist.gather(loc.contiguous(), g, dst=0)
+            R_all = R_local if args.emulate_world else R_total
+
+            def gather_rays(t):                                                          # [.., R_local] -> [.., R_all] on rank 0
+                if t.shape[-1] < Rmax:                                                   # ragged strong split: pad
+                    t = torch.cat((t, torch.full(t.shape[:-1] + (Rmax - t.shape[-1],), float("nan"), dtype=t.dtype, device=t.device)), -1)
+                g = [torch.empty_like(t) for _ in range(world)] if rank == 0 else None
+                dist.gather(t.contiguous(), g, dst=0)
+                return rd.interleave(g, R_all) if rank == 0 else None                    # ray k*world + r  <-  rank r, slot k
+            allr = gather_rays(loc)
+            traj = None
+            if stride and args.gather_rows > 0 and "s_ray" in t_:
+                sub = t_["s_ray"][::args.gather_rows].to(cdev)                           # [rows / g, 6, R_local]
+                torch.cuda.synchronize()
+                barrier()
+                tg0 = time.perf_counter()
+                traj = gather_rays(sub)
+                torch.cuda.synchronize()
+                tg = time.perf_counter() - tg0
             if rank == 0:
-                allr = rd.interleave(g, R_local if args.emulate_world else R_total)                                      # ray k*world + r  <-  rank r, slot k
                 assert int(allr[2].sum().item()) * args.steps == total_steps
                 assert torch.isfinite(allr[3:5]).all()
                 gathered = {"rays": int(allr.shape[1]), "backend": args.backend, "world": world,
                             "bytes_per_rank": int(loc.numel() * loc.element_size())}
+                if traj is not None:
+                    # rank 0's own rays sit at positions 0, world, 2*world, ...: the same bits as its local view
+                    mine = traj[:, :, 0::world][:, :, :sub.shape[2]]
+                    assert torch.equal(mine, sub), "gathered trajectory rows differ from rank 0's own record"
+                    if args.dtype == "f64" and args.order == "fan" and not args.emulate_world:
+                        # row 0 holds the launch angles (:826): in ray order they are the whole fan again
+                        assert torch.equal(traj[0, 5], torch.from_numpy(fan(args.scenario, R_all, 0, 1)).to(traj.device)), \
+                            "row 0 of the gathered trajectory is not the launch fan"
+                    gathered["trajectory"] = {"rows": int(traj.shape[0]), "every": args.gather_rows, "shape": list(traj.shape),
+                                              "bytes_per_rank": int(sub.numel() * sub.element_size()), "seconds": tg,
+                                              "GB_per_s_into_rank0": sub.numel() * sub.element_size() * max(world - 1, 1) / tg / 1e9}
         except Exception as e:   # the timed result is already in hand; report and carry on
             print(f"bench.py: read-back gather failed: {e}", file=sys.stderr)
             gathered = {"error": str(e)}
@@ -358,7 +460,7 @@ def main():
         # the profiles were taken with every other option at its default: a run that changes one of them (ray order, sort,
         # field path, slice length, block size, refill threshold, a shard of a larger fan) has no profile of its own
         defaults = (args.order == "fan" and not args.sort and args.field_path == "auto" and args.slice_steps in (0, 512)
-                    and args.block == 0 and args.refill_min == 0 and part_world == 1 and not args.reference_order)
+                    and args.block == 0 and args.refill_min == 0 and part_world == 1 and not args.reference_order and not args.fused)
         prof = {}
         try:
             prof = (json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}) or {}) if defaults else {}
@@ -407,7 +509,7 @@ def main():
                                    f"rays, interleaved across ranks), op{args.method}, DELTA_S={step:.12g}, "
                                    f"box={tuple(float(v) for v in lim)}, record={args.record}",
                        "rays_total": R_total, "rays_rank0": R_local, "ray_steps_per_pass_rank0": int(steps_per_pass),
-                       "method": f"op{args.method}", "record": args.record, "n_ray_rows": bool(args.n_ray and stride), "launch_mode": args.mode, "launch_mode_used": mode_used, "reference_order": bool(args.reference_order),
+                       "method": f"op{args.method}", "record": args.record, "n_ray_rows": bool(args.n_ray and stride), "launch_mode": args.mode, "launch_mode_used": mode_used, "reference_order": 2 if args.fused else int(args.reference_order),
                        "ray_order": args.order, "sort_rays": bool(args.sort), "field_path": args.field_path,
                        "steps_per_launch": args.chunk or "all", "parallelism": f"ray-shard x{world}"},
             "roofline": roof,

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 5
+#define RTMI_ABI_VERSION 6
 
 typedef enum {
     RTMI_OK = 0,
@@ -50,6 +50,9 @@ typedef enum {
                                 whose rays differ much in length */
     RTMI_LAUNCH_PLAIN = 3    /* one lane per ray to completion, one block slot per 256 rays */
 } rtmi_launch_mode;
+
+/* rtmi_params.reference_order */
+typedef enum { RTMI_ORDER_DEFAULT = 0, RTMI_ORDER_REFERENCE = 1, RTMI_ORDER_FUSED = 2 } rtmi_order;
 
 typedef struct rtmi_field rtmi_field;   /* z + grd of interpolacion() (:435-464), resident in HBM */
 typedef struct rtmi_batch rtmi_batch;   /* one trazar() call's ray batch (:766-948), resident in HBM */
@@ -124,10 +127,14 @@ typedef struct {
                                 reference's call surface never sees it; dropping it saves 1/7 of the recorded bytes */
     int32_t slice_steps;     /* time-sliced schedule: DELTA_S steps per time slice of a bundle (0 -> 512); a bundle's first two
                                 slices are 4 and 2 times as long */
-    int32_t reference_order; /* 0 (default): op1/2/6/7/8 step in fused forms (~1e-13 from the reference per trajectory; op7, which
-                                differentiates positions, up to ~1e-9 on the interface scenario); 1 (fp64 only): they too run in the
-                                reference's own operation order, like op3/4/5/9/10/11 always do -- all five then give the
-                                reference's bits (numpy's arctan2 = SVML's is restated for op1/7/8) -- at about a quarter of the speed */
+    int32_t reference_order; /* rtmi_order.  RTMI_ORDER_DEFAULT (0): op1/2/6/8 step in fused forms (~1e-13 from the reference per
+                                trajectory); op7 -- whose new angle differentiates positions, so that last-bit differences of a
+                                fused update walk 8e-9 away from the reference on the interface scenario -- steps in the
+                                reference's own operation order, like op3/4/5/9/10/11 always do.  RTMI_ORDER_REFERENCE (1, fp64
+                                only): op1/2/6/8 too: all give the oracle's bits (the reference's, within 1 ulp where numpy's
+                                scalar pow(x, 2) is not x*x; numpy's arctan2 = SVML's is restated for op1/7/8) at a quarter to a
+                                third of the speed.  RTMI_ORDER_FUSED (2): fused forms wherever there is one, op7 included
+                                (3.4 times faster than its default; fp32 batches always run fused forms) */
 } rtmi_params;
 
 /* Upload R launch conditions (host pointers; x0/y0 per ray -- pos_x[k], -2 or the fisheye start, :809-813),
@@ -232,6 +239,10 @@ typedef struct {
                                            caller that times many passes (reset + run each) gets the kernel time of all of
                                            them from two stats calls, one before and one after, without a host sync per pass */
     uint64_t launches_total;            /* advance-kernel launches since create */
+    uint32_t auto_fallbacks;            /* RTMI_LAUNCH_AUTO only: time-sliced launches of this batch that gave up a bounded wait and
+                                           were finished by the plain kernel (results unaffected).  Expected 0: a non-zero count is a
+                                           scheduler defect signal, and the batch stays on the plain schedule afterwards */
+    uint32_t reserved_;
 } rtmi_stats;
 /* Synchronises the stream, then fills *s. */
 int rtmi_batch_stats(rtmi_batch *b, rtmi_stats *s);

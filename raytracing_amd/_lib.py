@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RTMI_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants in one session)
 LIB_PATH = os.environ.get("RTMI_LIB_PATH") or os.path.join(_HERE, "librtmi.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 # rtmi_launch_mode (include/rtmi.h)
 LAUNCH_AUTO, LAUNCH_REFILL, LAUNCH_SLICED, LAUNCH_PLAIN = 0, 1, 2, 3
 LAUNCH_MODES = {"auto": LAUNCH_AUTO, "refill": LAUNCH_REFILL, "sliced": LAUNCH_SLICED, "plain": LAUNCH_PLAIN, "lane": LAUNCH_PLAIN}
@@ -44,7 +44,8 @@ class DeviceView(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("ray_steps", C.c_uint64), ("live_rays", C.c_uint64), ("kernel_ms", C.c_double),
                 ("launches", C.c_uint32), ("vgprs", C.c_uint32), ("sgprs", C.c_uint32), ("lds_bytes", C.c_uint32),
-                ("launch_mode_used", C.c_uint32), ("kernel_ms_total", C.c_double), ("launches_total", C.c_uint64)]
+                ("launch_mode_used", C.c_uint32), ("kernel_ms_total", C.c_double), ("launches_total", C.c_uint64),
+                ("auto_fallbacks", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 # every symbol include/rtmi.h declares: name -> (restype, argtypes)
@@ -87,6 +88,32 @@ SYMBOLS = {
 _lib = None
 
 
+def _share_torchs_hip_runtime():
+    """One HIP runtime per process, whatever the import order.
+
+    librtmi.so asks for "libamdhip64.so.7" (RUNPATH /opt/rocm/lib); torch's ROCm wheel bundles a copy of the runtime with the
+    same SONAME, and its libraries ask for "libamdhip64.so" -- a name the loader satisfies from an already mapped object only
+    when that object is the same FILE.  So: torch first, librtmi second -> librtmi's request matches the SONAME of torch's copy,
+    one runtime (fine); librtmi first -> /opt/rocm's copy is mapped, torch later maps its own beside it, and the second HSA
+    runtime to open the device is refused ("No HIP GPUs are available"; tools/hip_runtime_probe.py shows both cases).
+    Mapping torch's copy (and nothing else of torch) before librtmi.so makes every order the first one: librtmi binds to it by
+    SONAME, torch finds the same file when it is imported.  Without torch installed librtmi.so uses /opt/rocm's runtime.
+    RTMI_NO_PRELOAD=1 skips this (the probe uses it)."""
+    import importlib.util
+    import sys
+    if os.environ.get("RTMI_NO_PRELOAD") or "torch" in sys.modules:      # torch imported: its runtime is mapped already
+        return
+    try:
+        spec = importlib.util.find_spec("torch")                           # locates the package, does not import it
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    hip = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(hip):
+        C.CDLL(hip, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load librtmi.so (built in-tree by __graft_entry__.build() / make -C raytracing_amd/csrc)."""
     global _lib
@@ -96,17 +123,7 @@ def lib():
                 f"{LIB_PATH} is missing: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()' or make -C raytracing_amd/csrc). "
                 "raytracing_amd has no CPU fallback.")
-        # torch's ROCm wheels bundle their own HIP runtime.  Two HIP runtimes can share a process only if torch's is
-        # the first to touch the device (afterwards librtmi's, from /opt/rocm, works beside it; the other way round
-        # torch reports "No HIP GPUs are available").  So when torch is already imported, let it look first.
-        import sys
-        if "torch" in sys.modules:
-            try:
-                t = sys.modules["torch"]
-                if t.cuda.is_available():
-                    t.cuda.init()          # is_available() alone does not create torch's HIP context
-            except Exception:
-                pass
+        _share_torchs_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol

@@ -45,6 +45,27 @@ __device__ __attribute__((noinline)) SinCos sincos_(double x) {
     else sincos_k(x, &r.s, &r.c);
     return r;
 }
+// sin and cos of one angle, glibc's bits, INLINE for the two ranges a golden-section bracket point lies in (theta -+ h with
+// h <= 0.6: 2^-26 <= |x| < 0.855469, the table step on x itself, and |x| < 2.426265, through pi/2 - |x|); anything else
+// calls sincos_().  Same operations as gl::sin / gl::cos: same bits.  For exact_lt_iso below, which pays this twice per
+// undecided comparison -- twelve to thirteen times per step where the index is constant (see there).
+__device__ __forceinline__ SinCos sincos_inline(double x) {
+    const unsigned k = gl::hi_word_(x);
+    SinCos r;
+    if (k - 0x3e500000u < 0x3feb6000u - 0x3e500000u) {
+        r.s = gl::table_sin(kSinCosTab, x, 0.0);
+        r.c = gl::table_cos(kSinCosTab, x, 0.0);
+    } else if (k - 0x3feb6000u < 0x400368fdu - 0x3feb6000u) {
+        const double y = gl::kHp0 - __builtin_fabs(x);
+        r.s = __builtin_copysign(gl::table_cos(kSinCosTab, y, gl::kHp1), x);
+        const double a = y + gl::kHp1;
+        const double da = (y - a) + gl::kHp1;
+        r.c = gl::table_sin(kSinCosTab, a, da);
+    } else {
+        r = sincos_(x);
+    }
+    return r;
+}
 // np.arctan2 as the reference's numpy evaluates it (AVX512_SKX builds: Intel SVML's __svml_atan28_ha; not libm's atan2 in the
 // last bit for 7 % of arguments) -- same text as oracle/rt_oracle.c np_arctan2, see there; tools/check_np_atan2.py: 0
 // mismatches against np.arctan2 on 1.6e7 argument pairs.  Its reciprocal starts from the VRCP14PD instruction, which is a
@@ -400,11 +421,21 @@ __device__ __forceinline__ double golden_filtered(FastA fast_a, double EA, Expan
     return (b + a) / 2.0;
 }
 
-// The two cost functions in the reference's arithmetic -- the rare path of golden_filtered, kept out of line.
-__device__ __attribute__((noinline)) double exact_cost_iso(double t, double fn, double px, double py, double ix, double iy) {
-    const SinCos u = sincos_(t);
-    return sq(fn * u.c - px - ix) + sq(fn * u.s - py - iy);                                           // (:595, :697)
+// One comparison of the isotropic search in the reference's arithmetic: cost(c) < cost(d) (:191 with :595 / :697), both
+// costs inline and side by side (two independent chains: the second hides the first's latency).  Where the index is constant
+// (both flanks of the interface scenario's sigmoid) the impulse vanishes, psi = theta, and the search's points fall
+// symmetrically about its minimum at every third iteration: 13 of a step's 37 comparisons are ties in exact arithmetic,
+// decided in the reference by the rounding of glibc's sin / cos at c and d -- and every one of them reaches the returned
+// bits (the brackets of the two outcomes differ in their last places).  So this runs 13 times per step there, not 1e-4
+// times: with the out-of-line cost (a call into a call, 14 registers spilled around it) such steps cost 3 666 vector
+// instructions and 2 268 scalar ones per wave against 1 629 / 700 elsewhere (profiles/r04_iface_op9_base_pmc_summary.txt).
+__device__ __forceinline__ bool exact_lt_iso(double c, double d, double fn, double px, double py, double ix, double iy) {
+    const SinCos uc = sincos_inline(c), ud = sincos_inline(d);
+    const double Fc = sq(fn * uc.c - px - ix) + sq(fn * uc.s - py - iy);
+    const double Fd = sq(fn * ud.c - px - ix) + sq(fn * ud.s - py - iy);
+    return Fc < Fd;
 }
+// The anisotropic cost in the reference's arithmetic -- the rare path of golden_filtered, kept out of line.
 __device__ __attribute__((noinline)) double exact_cost_aniso(double t, double fn, double gam, double g2, double mix, double miy,
                                                             double cgx, double cgy, double fgx, double fgy, double step) {
     const SinCos u = sincos_(t);
@@ -430,7 +461,7 @@ __device__ __attribute__((noinline)) double exact_cost_aniso(double t, double fn
 //                           Cb = (2 sqrt2 K1 |Delta| + 2 K2 Delta^2 + 2 K3) / (1.776 n'|P|)
 // (1.776 = 4 x min sin x / x on [0, 2] x min sin h / h on [0, 0.371]).  Delta is O(step^2): Cb / h stays below 1e-12 even in
 // the last iteration (h = 7e-9) and the comparison is decided by the sign of x in all but ~1e-4 of the steps; otherwise --
-// per lane, for that one comparison -- both costs are evaluated in the reference's arithmetic (exact_cost_iso) and compared
+// per lane, for that one comparison -- both costs are evaluated in the reference's arithmetic (exact_lt_iso) and compared
 // like the reference does.  Either way the outcome is the reference's, and a, b, c, d, advanced with its own unfused bracket
 // arithmetic, are its bits.  (Round 2 evaluated a fast cost with an error bound at every new point: ~90 instructions per
 // iteration, ~20 now.)
@@ -484,7 +515,7 @@ __device__ __forceinline__ double ang_golden_iso(const Ray<double>& r, double st
         const double q2 = ((c - th) + (d - th)) - phi2;          // 2 x; both differences are exact or rounded at their own size
         bool lt = q2 > 0.0;
         if (!(__builtin_fabs(q2) > 2.0 * fma_(Cb, invh, Ca)))    // also taken when anything is NaN
-            lt = exact_cost_iso(c, fn, px, py, ix, iy) < exact_cost_iso(d, fn, px, py, ix, iy);
+            lt = exact_lt_iso(c, d, fn, px, py, ix, iy);
         if (lt) b = d; else a = c;
         c = b - (b - a) * GR;
         d = a + (b - a) * GR;

@@ -101,7 +101,7 @@ inline PolyAxis poly_axis_build(const std::vector<double>& x, double origin, dou
 }
 
 // One cell's 36 coefficients from the B-spline coefficient arrays (row-major [qy][qx], y the row index, :455-457) and the two
-// axes' tables.  Plain fp64 fma in a fixed order: the same bits on the host (tools/check_polytab.cpp) and on the device.
+// axes' tables.  Plain fp64 fma in a fixed order: the same bits on the host (tests/native/polytab_check.cpp) and on the device.
 RT_PT_HD inline void poly_cell_convert(const double* Z, const double* cdx, const double* cdy, int qx, int qy, int jx, int jy,
                                     const double* Cx, const double* Lx, const double* Cy, const double* Ly, double out[36]) {
     const int lx = poly_interval(jx, qx), ly = poly_interval(jy, qy);

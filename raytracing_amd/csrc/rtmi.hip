@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstring>
 #include <exception>
+#include <mutex>
 #include <numeric>
 #include <new>
 #include <string>
@@ -38,11 +39,22 @@ static int fail(int code, const std::string& msg) {
     } while (0)
 
 // Suprema over t of |d^k/dt^k| (k = 1..4) of the unit momentum curve's components c/a, gamma^2 s/a and of a(t) =
-// sqrt(gamma^2 s^2 + c^2), by truncated Taylor arithmetic (order 4) at 8192 equally spaced angles, with 10 % on top for what
-// lies between the samples (neighbouring samples differ by a fraction of that).  Bounds for the remainder of the
-// golden-section search's third-order expansion (rt_exact.h, phase T); gamma is a property of the batch, so once per batch.
+// sqrt(gamma^2 s^2 + c^2), by truncated Taylor arithmetic (order 4) at equally spaced angles, with 10 % on top for what lies
+// between the samples.  Bounds for the remainder of the golden-section search's third-order expansion (rt_exact.h, phase T);
+// gamma is a property of the batch, so once per batch.
+// The curve's features are 1/G wide, G = max(gamma, 1/gamma) (the ellipse's sharp ends), so the sample count grows with G:
+// >= 430 samples across a feature -- what gamma = 3, the reference's anisotropy (RT_bench.py:286), has at 8192 and what the
+// op10/op11 bit-identity tests validate (gamma 0.05 .. 50, tests/test_gpu_exact.py); neighbouring samples then differ by a
+// fraction of the 10 %.  Beyond G = 64 nothing is claimed: the suprema are returned infinite, phase T's `ok` is false and
+// every comparison of the search runs the reference's own arithmetic (correct, slower).
 static void gold_sup_derivatives(double gamma, double out[8]) {
-    constexpr int K = 4, N = 8192;
+    const double G = std::max(gamma, 1.0 / gamma);
+    if (!(G <= 64.0)) {
+        for (int i = 0; i < 8; i++) out[i] = INFINITY;
+        return;
+    }
+    constexpr int K = 4;
+    const int N = 8192 * std::max(1, (int)std::ceil(G / 3.0));
     typedef double Jet[K + 1];
     auto mul = [](const Jet a, const Jet b, Jet o) {
         for (int i = 0; i <= K; i++) { double v = 0; for (int j = 0; j <= i; j++) v += a[j] * b[i - j]; o[i] = v; }
@@ -79,6 +91,15 @@ static void gold_sup_derivatives(double gamma, double out[8]) {
 static double libm_square(double x) {
     volatile double two = 2.0;
     return std::pow(x, two);
+}
+
+// Does this batch step op1/2/6/7/8 in the reference's own operation order (rt_exact.h)?  fp64 only.  RTMI_ORDER_REFERENCE: all
+// five.  RTMI_ORDER_DEFAULT: op7 alone -- it differentiates POSITIONS (11 P3 - 18 P2 + 9 P1 - 2 P0 over 6 DELTA_S), so the
+// last bits of the positions enter every new angle at 2e-12 and a fused position update (an ulp or two from the reference's)
+// random-walks away from it: 8.4e-9 on recorded rows of the interface scenario, past the 1e-9 the path is held to; only the
+// reference's own roundings reproduce its noise.  RTMI_ORDER_FUSED keeps op7 in the fused form (3.4 times faster, fp32 always).
+static bool ref_order(const rtmi_params& p) {
+    return p.dtype == RTMI_F64 && (p.reference_order == RTMI_ORDER_REFERENCE || (p.method == 7 && p.reference_order == RTMI_ORDER_DEFAULT));
 }
 
 // ------------------------------------------------------------------ handles
@@ -1286,6 +1307,7 @@ struct rtmi_batch {
     double gold_sup[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // gold_sup_derivatives(gamma_step) for op10/op11
     int lat_simds = 0, lat_waves_per_simd = 0;       // SIMDs of the device (CUs x 4); > 0 once known (pick_advance's latency rule)
     int mode_used = RTMI_LAUNCH_PLAIN;
+    uint32_t auto_fallbacks = 0; // RTMI_LAUNCH_AUTO: sliced launches that abandoned a wait and were finished by the plain kernel
     void* staging = nullptr;     // device scratch of the read / metric / set_state paths, grown on demand, freed with the batch
     size_t staging_bytes = 0;
     // rtmi_step_repeat: `count` launches of `nsteps` steps as one hipGraph (a chain of kernel nodes), kept while the same
@@ -1325,7 +1347,7 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     a.R = b->R; a.max_size = p.max_size; a.stride = p.record_stride; a.rec_rows = p.rec_rows;
     const size_t R = (size_t)b->R;
     a.st = (double*)b->state; a.has_hist = p.method == 7;
-    a.exact = p.dtype == RTMI_F64 && (rt::is_exact_method(p.method) || p.reference_order);
+    a.exact = p.dtype == RTMI_F64 && (rt::is_exact_method(p.method) || ref_order(p));
     a.iso = p.gamma == 1.0 && p.method < 10 && !a.exact;
     a.rot = rt::rotates_unit(p.method, p.dtype == RTMI_F64) && !a.exact;
     a.istep = b->istep; a.alive = b->alive;
@@ -1390,20 +1412,29 @@ __global__ void k_rcp14_init() {
         rt::ex::g_rcp14[k] = v;
     }
 }
+// (per device, once: a mutex around a per-device flag -- two host threads creating batches at the same time decode once, and a
+// failed decode is retried by the next create)
 static int ensure_rcp14_table(hipStream_t st) {
-    static bool done[64] = {false};
+    static std::mutex mu;
+    static std::vector<char> done;
     int dev = 0;
     HIP_TRY(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && done[dev]) return RTMI_OK;
+    std::lock_guard<std::mutex> lock(mu);
+    try {
+        if ((size_t)dev >= done.size()) done.resize((size_t)dev + 1, 0);
+    } catch (const std::exception& e) {
+        return fail(RTMI_ERR_ALLOC, std::string("rcp14 table: ") + e.what());
+    }
+    if (done[dev]) return RTMI_OK;
     hipLaunchKernelGGL(k_rcp14_init, dim3(1), dim3(1), 0, st);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
-    if (dev >= 0 && dev < 64) done[dev] = true;
+    done[dev] = 1;
     return RTMI_OK;
 }
-// the fp64 batch runs rt_exact.h's arithmetic: always for op3/4/5/9/10/11, for the others when reference_order is set
-static bool batch_exact(const rtmi_batch* b) { return b->p.dtype == RTMI_F64 && (rt::is_exact_method(b->p.method) || b->p.reference_order); }
-static int batch_kernel_index(const rtmi_batch* b) { return kernel_index(b->p.method, b->p.dtype == RTMI_F64 && b->p.reference_order); }
+// the fp64 batch runs rt_exact.h's arithmetic: always for op3/4/5/9/10/11, for the others when ref_order() says so
+static bool batch_exact(const rtmi_batch* b) { return b->p.dtype == RTMI_F64 && (rt::is_exact_method(b->p.method) || ref_order(b->p)); }
+static int batch_kernel_index(const rtmi_batch* b) { return kernel_index(b->p.method, ref_order(b->p)); }
 // field_path 0 (auto): which gather policy the step kernels are built with.
 static bool use_lds_tile(const rtmi_batch* b) {
     if (b->p.field_path == 1) return false;
@@ -1429,7 +1460,7 @@ static const void* pick_advance(const rtmi_batch* b) {
     const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
     // at most two waves per SIMD's worth of rays: the latency build (env RTMI_NO_LAT=1 keeps the throughput build, for A/B)
     if (lds && b->p.dtype == RTMI_F64 && (b->p.method == 2 || b->p.method == 6) && !b->vstep && uniform_rows_ok(b) &&
-        !b->p.reference_order && b->lat_waves_per_simd > 0 && (b->R + 63) / 64 <= (int64_t)2 * b->lat_simds && !getenv("RTMI_NO_LAT"))
+        !ref_order(b->p) && b->lat_waves_per_simd > 0 && (b->R + 63) / 64 <= (int64_t)2 * b->lat_simds && !getenv("RTMI_NO_LAT"))
         return advance_lat_fn(b->p.method, iso);
     // the VAR build: per-ray DELTA_S / max_size when set, and per-lane row bookkeeping always
     if (b->vstep || !uniform_rows_ok(b))
@@ -1524,8 +1555,8 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     ARG_TRY(p->lazy_clear == 0 || p->lazy_clear == 1, "rtmi_batch_create: lazy_clear must be 0 or 1");
     ARG_TRY(p->no_n_ray == 0 || p->no_n_ray == 1, "rtmi_batch_create: no_n_ray must be 0 or 1");
     ARG_TRY(!(p->no_n_ray && p->ext_n_ray), "rtmi_batch_create: no_n_ray set together with ext_n_ray");
-    ARG_TRY(p->reference_order == 0 || p->reference_order == 1, "rtmi_batch_create: reference_order must be 0 or 1");
-    ARG_TRY(!(p->reference_order && p->dtype != RTMI_F64), "rtmi_batch_create: reference_order needs an fp64 batch (the reference has no fp32)");
+    ARG_TRY(p->reference_order >= 0 && p->reference_order <= 2, "rtmi_batch_create: reference_order must be 0, 1 or 2 (RTMI_ORDER_*)");
+    ARG_TRY(!(p->reference_order == RTMI_ORDER_REFERENCE && p->dtype != RTMI_F64), "rtmi_batch_create: reference_order 1 needs an fp64 batch (the reference has no fp32)");
     DEVICE_TRY(f, "rtmi_batch_create");
     rtmi_batch* b = new (std::nothrow) rtmi_batch();
     if (!b) return fail(RTMI_ERR_ALLOC, "rtmi_batch_create: host allocation failed");
@@ -1541,7 +1572,7 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     int rc = RTMI_OK;
     auto body = [&]() -> int {
         const size_t Rz = (size_t)R;
-        const int naux = p->method == 7 ? 7 : (rt::rotates_unit(p->method, p->dtype == RTMI_F64) && !p->reference_order) ? 5 : 3;   // n gx gy + history | unit vector
+        const int naux = p->method == 7 ? 7 : (rt::rotates_unit(p->method, p->dtype == RTMI_F64) && !ref_order(*p)) ? 5 : 3;   // n gx gy + history | unit vector
         HIP_TRY(hipMalloc(&b->state, 6 * Rz * sizeof(double) + naux * Rz * b->esz));
         HIP_TRY(hipMalloc(&b->istep, Rz * sizeof(int)));
         HIP_TRY(hipMalloc(&b->alive, Rz));
@@ -2033,6 +2064,8 @@ RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
     if (rc == RTMI_ERR_STATE && pick == 0) {
         // the sliced launch gave up a wait (it reports instead of hanging); what it advanced is valid state: finish plainly
         b->auto_ms[0] = 1e30; b->auto_n[0] = 4;
+        b->auto_fallbacks++;           // countable (rtmi_stats.auto_fallbacks): a wait-bound trip is a scheduler defect signal
+        if (getenv("RTMI_DEBUG")) fprintf(stderr, "rtmi: RTMI_LAUNCH_AUTO: the sliced launch gave up a wait (%s); finishing with the plain kernel\n", g_err.c_str());
         return run_plain(b, &ev);
     }
     if (rc == RTMI_OK && fresh && ev) {
@@ -2347,6 +2380,8 @@ RTMI_EXPORT int rtmi_batch_stats(rtmi_batch* b, rtmi_stats* s) {
     s->launches = b->launches;
     s->kernel_ms_total = b->total_kernel_ms;
     s->launches_total = b->total_launches;
+    s->auto_fallbacks = b->auto_fallbacks;
+    s->reserved_ = 0;
     hipFuncAttributes fa;
     s->vgprs = s->sgprs = s->lds_bytes = 0;
     s->launch_mode_used = (uint32_t)b->mode_used;

@@ -71,6 +71,26 @@ def sum_over_ranks(value, device=None, group=None):
     return int(t.item())
 
 
+def agree_ok(ok, device=None, group=None):
+    """True on every rank iff `ok` is true on every rank (one all_reduce): called before a collective that a failed rank
+    would never enter, so that the others raise instead of waiting for it forever."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([0 if ok else 1], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item()) == 0
+
+
+def _to_callers_order(t, perm):
+    """Slot order -> the caller's ray order along the last axis (sort_rays: slot k holds the caller's ray perm[k])."""
+    if perm is None:
+        return t
+    import torch
+    out = torch.empty_like(t)
+    out[..., perm.long()] = t
+    return out
+
+
 def trazar_sharded(selected_func, scenario, show, step, divisor, user_choice, *, thetas=None, starts=None, record=None,
                    dtype=0, dst=0, group=None, device=None, **kw):
     """rt_bench.trazar (RT_bench.py:766-948) with the rays of ONE call split over the ranks of a torch.distributed group --
@@ -78,8 +98,14 @@ def trazar_sharded(selected_func, scenario, show, step, divisor, user_choice, *,
     r, r + world, ...: every rank gets the same mix of short and long rays).  Each rank builds the field on its own device
     (genZ + interpolacion, a few ms) and runs its shard; there is no collective on the data path.  The results -- d_ray,
     compute_times, errors and, when `record` is set ("full" or a stride), the recorded rows -- are gathered to `dst` in the
-    caller's ray order (over RCCL when the group's backend is nccl, device to device).  Returns what trazar returns on `dst`,
-    None on the other ranks.  Rays are independent, so the gathered arrays are bit-identical to an unsharded call.
+    caller's ray order.  With the nccl backend (RCCL over xGMI) the gather is device to device: the payload is assembled from
+    zero-copy views of the batch's HBM arrays (Batch.device_tensors(): the SoA state and the record `s_ray[rows][6][R_local]`),
+    nothing of the trajectory passes through the host before it reaches `dst`.  With gloo (CPU rehearsal) the same payload is
+    read back to the host first.  Returns what trazar returns on `dst`, None on the other ranks.  Rays are independent, so
+    the gathered arrays are bit-identical to an unsharded call.
+
+    A rank whose local trace fails (RtmiError, allocation) does not leave the others blocked in the gather: the ranks agree on
+    success with one all_reduce first and all raise.  A rank with no rays (world > number of rays) contributes padding.
 
     thetas / starts ((R, 2) or (2,)) replace the preset of `user_choice` like in trazar; the interface scenario's exit-angle
     errors need record="full"."""
@@ -92,41 +118,70 @@ def trazar_sharded(selected_func, scenario, show, step, divisor, user_choice, *,
     on_gpu = dist.get_backend(group) == "nccl"
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", rank))
-    _lib.check(_lib.lib().rtmi_set_device(int(device)))
-    c = rb.constants(user_choice)
-    theta_all = np.asarray(c[2][:c[1]] if thetas is None else thetas, dtype=np.float64)
-    R_total = len(theta_all)
+    cdev = torch.device("cuda", int(device)) if on_gpu else torch.device("cpu")
+    pl = rb.trazar_plan(user_choice, step, divisor, thetas, starts, kw.get("box"), kw.get("gamma"), kw.get("max_size"), record)
+    theta_all, R_total = pl["theta_v"], pl["ray_count"]
     th = np.ascontiguousarray(theta_all[rank::world])
+    R_local = len(th)
+    Rmax = (R_total + world - 1) // world
     st = None
     if starts is not None:
         st = np.asarray(starts, dtype=np.float64)
         st = st if st.ndim == 1 else np.ascontiguousarray(st[rank::world])
-    fld = rb.Field.build(scenario, c[5:9], rb.DELTA, dtype)
+    rows = pl["rec_rows"]
+    fdt = torch.float64 if dtype == rb.F64 else torch.float32
+    head = rows_t = None          # [5, R_local] fp64: d_ray (3), compute_times, errors; [rows*6, R_local] of the batch's dtype
+    fld = b = None
+    err = None
     try:
-        z, grd = rb.FieldSpline(fld, "n"), (rb.FieldSpline(fld, "dy"), rb.FieldSpline(fld, "dx"))
-        s_ray, d_ray, ctimes, errors = rb.trazar(selected_func, z, grd, False, step, divisor, user_choice, thetas=th, starts=st,
-                                                 record=record, **kw)
+        if R_local > 0:
+            _lib.check(_lib.lib().rtmi_set_device(int(device)))
+            fld = rb.Field.build(scenario, rb.constants(user_choice)[5:9], rb.DELTA, dtype)
+            z, grd = rb.FieldSpline(fld, "n"), (rb.FieldSpline(fld, "dy"), rb.FieldSpline(fld, "dx"))
+            _, d_ray, ctimes, errors, b = rb.trazar(selected_func, z, grd, False, step, divisor, user_choice, thetas=th, starts=st,
+                                                    record=record, return_batch=True, read_rows=not on_gpu, **kw)
+            if on_gpu:
+                t = b.device_tensors()
+                perm = t.get("perm")
+                d_dev = torch.stack((t["dist_real"], t["dist_sim"], t["istep"].to(torch.float64)))          # (:888-890)
+                small = torch.from_numpy(np.stack((ctimes, errors))).to(cdev)                                # 16 bytes per ray
+                head = torch.cat((_to_callers_order(d_dev, perm), small), 0)
+                if rows:
+                    rows_t = _to_callers_order(t["s_ray"].reshape(rows * 6, R_local), perm)                # a view unless sort_rays
+            else:
+                head = torch.from_numpy(np.concatenate([d_ray, ctimes[None], errors[None]], axis=0))
+                if rows:
+                    rows_t = torch.from_numpy(b.rows().reshape(rows * 6, R_local)).to(fdt)
+        else:
+            head = torch.empty((5, 0), dtype=torch.float64, device=cdev)
+            rows_t = torch.empty((rows * 6, 0), dtype=fdt, device=cdev) if rows else None
+    except Exception as e:      # agreed on below: no rank enters the gather unless all can
+        err = e
+    try:
+        if not agree_ok(err is None, cdev, group):
+            raise RuntimeError(f"trazar_sharded: the local trace failed on {'this rank' if err is not None else 'another rank'}"
+                               f" (rank {rank} of {world})") from err
+
+        def gather_padded(t):
+            if t.shape[1] < Rmax:                                            # ragged split: pad the short ranks
+                t = torch.cat((t, torch.full((t.shape[0], Rmax - t.shape[1]), float("nan"), dtype=t.dtype, device=t.device)), 1)
+            out = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
+            dist.gather(t.contiguous(), out, dst=dst, group=group)
+            return interleave(out, R_total) if rank == dst else None         # [.., R_total] in ray order
+        head_all = gather_padded(head)
+        rows_all = gather_padded(rows_t) if rows else None
+        if on_gpu:
+            torch.cuda.synchronize(cdev)                                     # the batch's memory is released below
     finally:
-        fld.close()
-    loc = np.concatenate([d_ray, ctimes[None], errors[None]] + ([s_ray.reshape(-1, len(th))] if s_ray is not None else []), axis=0)
-    Rmax = (R_total + world - 1) // world
-    t = torch.from_numpy(np.ascontiguousarray(loc))
-    if t.shape[1] < Rmax:                                            # ragged split: pad the short ranks
-        t = torch.cat((t, torch.full((t.shape[0], Rmax - t.shape[1]), float("nan"), dtype=t.dtype)), 1)
-    if on_gpu:
-        t = t.to(torch.device("cuda", int(device)))
-    out = [torch.empty_like(t) for _ in range(world)] if rank == dst else None
-    dist.gather(t.contiguous(), out, dst=dst, group=group)
+        if b is not None:
+            b.close()
+        if fld is not None:
+            fld.close()
     if rank != dst:
         return None
-    allr = interleave(out, R_total).cpu().numpy()                    # [5 (+ rows*6), R_total] in ray order
-    d_all, ct_all, err_all = allr[:3], allr[3], allr[4]
-    s_all = allr[5:].reshape(s_ray.shape[0], 6, R_total) if s_ray is not None else None
-    if show and s_all is not None and c[9]:
-        angsim, angreal = rb.snell_angles(s_all, d_all, theta_all)
-        for k in range(R_total):
-            i = int(d_all[2, k])
-            f = rb._format_num
-            print(f"Coords: [ {f(s_all[i, 0, k])} , {f(s_all[i, 1, k])} ] | SimAng: {f(angsim[k])} | "
-                  f"SnellAng: {f(angreal[k])} | Err: {f(err_all[k])} | InitAng: {f(theta_all[k] * 180 / np.pi)}")
+    head_np = head_all.cpu().numpy()
+    d_all, ct_all, err_all = head_np[:3], head_np[3], head_np[4]
+    s_all = rows_all.to(torch.float64).cpu().numpy().reshape(rows, 6, R_total) if rows else None
+    if show and s_all is not None and pl["op_interface"]:
+        rb.print_exit_table(s_all, d_all, err_all, theta_all)
     return s_all, d_all, ct_all, err_all

@@ -37,6 +37,7 @@ DELTA_S_DIVISOR_VERT_UPPER_LIMIT = 2                 # :96
 DELTA_S_DIVISOR_VERT_LOWER_LIMIT = 1 / 40            # :97
 
 F64, F32 = 0, 1
+ORDERS = {"default": 0, "reference": 1, "fused": 2}          # rtmi_order (rtmi_params.reference_order)
 
 
 # --------------------------------------------------------------------------- scenarios (:106-119)
@@ -311,8 +312,9 @@ class Batch:
         p.lazy_clear = int(bool(lazy_clear))
         p.no_n_ray = int(not keep_n_ray)
         p.slice_steps = int(slice_steps)
-        # reference_order: op1/2/6/7/8 too in the reference's own operation order (fp64): op2/op6 give its bits, slower
-        p.reference_order = int(bool(reference_order))
+        # rtmi_order: False / 0 default (op7 alone of the fused five steps in the reference's operation order); True / 1 all of
+        # op1/2/6/7/8 (fp64: the oracle's bits, slower); "fused" / 2 fused forms throughout, op7 included
+        p.reference_order = ORDERS[reference_order] if isinstance(reference_order, str) else int(reference_order)
         self.params = p
         self._h = C.c_void_p()
         check(lib().rtmi_batch_create(field._h, C.byref(p), self.R, dptr(x0), dptr(y0), dptr(th), stream,
@@ -440,9 +442,8 @@ class Batch:
         library memory and die with the batch."""
         import torch
         if not torch.cuda.is_available():
-            raise RuntimeError("torch sees no HIP device: when torch and raytracing_amd share a process, import torch "
-                               "(and let it initialise, e.g. torch.cuda.is_available()) BEFORE the first rtmi call -- "
-                               "torch bundles its own HIP runtime and must be the first to open the device")
+            raise RuntimeError("torch sees no HIP device (raytracing_amd._lib maps torch's own HIP runtime before librtmi.so so "
+                               "that the two share one; RTMI_NO_PRELOAD=1 or an RTMI_LIB_PATH build linked elsewhere defeats that)")
         v = self.view()
         ts = "<f8" if v.dtype == F64 else "<f4"
 
@@ -562,21 +563,10 @@ def moment_cv(s_ray, ray_count=None):
     return np.mean(cvs)
 
 
-def trazar(selected_func, z, grd, show, step, divisor, user_choice, *, thetas=None, starts=None, box=None,
-           gamma=None, max_size=None, record="full", return_batch=False, launch_mode="auto", reference_order=False):
-    """RT_bench.py:766-948 on the GPU.  Positional arguments and the returned
-    (s_ray[max_size,6,R], d_ray[3,R], compute_times[R], errors[R]) are the reference's.
-
-    Keyword extensions for synthetic batches: thetas / starts ((R,2) or (2,)) / box / gamma / max_size replace
-    the preset of `user_choice`; record = "full" (reference layout), an int stride, or None (s_ray is None).
-    compute_times holds the device propagation time split evenly over rays, so np.sum(compute_times) is the
-    quantity the reference's benchmark reads (:1526).  launch_mode: "auto" (rtmi_params' default: the library picks the
-    schedule), "plain", "refill", "sliced" or the rtmi_launch_mode integer -- same bits in all of them.  reference_order=True:
-    op1/2/6/7/8 too step in the reference's own operation order (rtmi_params.reference_order): op2/op6 then return the
-    reference's bits, at about a third of the speed.
-    """
+def trazar_plan(user_choice, step, divisor, thetas=None, starts=None, box=None, gamma=None, max_size=None, record="full"):
+    """What trazar's preamble settles before any ray moves (RT_bench.py:793-804): the launch conditions, the box, gamma,
+    max_size and the record stride, from the preset of `user_choice` and the keyword overrides.  Needs no device."""
     g, ray_count, theta_v, pos_x, s, limx_i, limx_s, limy_i, limy_s, op_if, op_fish, _, _ = constants(user_choice)
-    fld = _field_of(z, grd)
     if thetas is not None:
         theta_v = np.asarray(thetas, dtype=np.float64)
         ray_count = len(theta_v)
@@ -589,14 +579,35 @@ def trazar(selected_func, z, grd, show, step, divisor, user_choice, *, thetas=No
         px = np.asarray(pos_x, dtype=np.float64)
         x0 = px[:ray_count] if len(px) >= ray_count else np.full(ray_count, px[0])
         y0 = -2.0                                            # :812
-    if box is None:
-        box = (limx_i, limx_s, limy_i, limy_s)
-    if gamma is None:
-        gamma = g
     if max_size is None:
         max_size = N * divisor if op_fish else int(np.ceil(s / step) + 1)   # :796-799
     stride = 0 if record is None else (1 if record == "full" else int(record))
-    b = Batch(fld, selected_func, step, max_size, box, gamma, theta_v[:ray_count], x0, y0, record_stride=stride,
+    return dict(ray_count=int(ray_count), theta_v=np.asarray(theta_v, dtype=np.float64)[:ray_count], x0=x0, y0=y0,
+                box=(limx_i, limx_s, limy_i, limy_s) if box is None else box, gamma=g if gamma is None else gamma,
+                max_size=int(max_size), stride=stride, rec_rows=(int(max_size) + stride - 1) // stride if stride else 0,
+                op_interface=bool(op_if), op_fisheye=bool(op_fish))
+
+
+def trazar(selected_func, z, grd, show, step, divisor, user_choice, *, thetas=None, starts=None, box=None,
+           gamma=None, max_size=None, record="full", return_batch=False, launch_mode="auto", reference_order=False,
+           read_rows=True):
+    """RT_bench.py:766-948 on the GPU.  Positional arguments and the returned
+    (s_ray[max_size,6,R], d_ray[3,R], compute_times[R], errors[R]) are the reference's.
+
+    Keyword extensions for synthetic batches: thetas / starts ((R,2) or (2,)) / box / gamma / max_size replace
+    the preset of `user_choice`; record = "full" (reference layout), an int stride, or None (s_ray is None).
+    compute_times holds the device propagation time split evenly over rays, so np.sum(compute_times) is the
+    quantity the reference's benchmark reads (:1526).  launch_mode: "auto" (rtmi_params' default: the library picks the
+    schedule), "plain", "refill", "sliced" or the rtmi_launch_mode integer -- same bits in all of them.  reference_order=True:
+    op1/2/6/8 too step in the reference's own operation order (rtmi_params.reference_order; op7 always does): they then return
+    the oracle's bits (the reference's, within 1 ulp where numpy's scalar pow(x, 2) is not x*x), at about a third of the speed.
+    read_rows=False (with return_batch=True): leave the recorded rows on the device (s_ray is returned as None; take them
+    from Batch.device_tensors() / Batch.rows()).
+    """
+    pl = trazar_plan(user_choice, step, divisor, thetas, starts, box, gamma, max_size, record)
+    fld = _field_of(z, grd)
+    ray_count, theta_v, stride = pl["ray_count"], pl["theta_v"], pl["stride"]
+    b = Batch(fld, selected_func, step, pl["max_size"], pl["box"], pl["gamma"], theta_v, pl["x0"], pl["y0"], record_stride=stride,
               sort_rays="auto", keep_n_ray=False,          # n_ray is internal to the reference's trazar (:803), never returned
               launch_mode=launch_mode, reference_order=reference_order)
     t1 = time.perf_counter()
@@ -605,22 +616,27 @@ def trazar(selected_func, z, grd, show, step, divisor, user_choice, *, thetas=No
     t2 = time.perf_counter()
     st_ = b.stats()
     d_ray = b.d_ray()
-    s_ray = b.rows() if stride else None
+    s_ray = b.rows() if stride and read_rows else None
     compute_times = np.full(ray_count, (st_["kernel_ms"] * 1e-3 if st_["kernel_ms"] > 0 else t2 - t1) / ray_count)
     errors = np.zeros(ray_count)
-    if op_if and stride == 1:
+    if pl["op_interface"] and stride == 1:
         errors = b.metric("snell")          # (:896-919) evaluated on the device
-        if show:   # the reference's per-ray table (:921-945)
-            angsim, angreal = snell_angles(s_ray, d_ray, theta_v)
-            for k in range(ray_count):
-                i = int(d_ray[2, k])
-                f = _format_num
-                print(f"Coords: [ {f(s_ray[i, 0, k])} , {f(s_ray[i, 1, k])} ] | SimAng: {f(angsim[k])} | "
-                      f"SnellAng: {f(angreal[k])} | Err: {f(errors[k])} | InitAng: {f(theta_v[k] * 180 / np.pi)}")
+        if show and s_ray is not None:   # the reference's per-ray table (:921-945)
+            print_exit_table(s_ray, d_ray, errors, theta_v)
     if return_batch:
         return s_ray, d_ray, compute_times, errors, b
     b.close()
     return s_ray, d_ray, compute_times, errors
+
+
+def print_exit_table(s_ray, d_ray, errors, theta_v):
+    """The reference's per-ray table of the interface scenario (RT_bench.py:921-945)."""
+    angsim, angreal = snell_angles(s_ray, d_ray, theta_v)
+    f = _format_num
+    for k in range(s_ray.shape[2]):
+        i = int(d_ray[2, k])
+        print(f"Coords: [ {f(s_ray[i, 0, k])} , {f(s_ray[i, 1, k])} ] | SimAng: {f(angsim[k])} | "
+              f"SnellAng: {f(angreal[k])} | Err: {f(errors[k])} | InitAng: {f(theta_v[k] * 180 / np.pi)}")
 
 
 def search_delta(option, z, grd, step, divisor, user_choice):

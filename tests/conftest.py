@@ -17,14 +17,6 @@ TRAJ_SCEN = {"interface": "interface", "fisheye": "fisheye", "vert": "vert_heter
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a HIP device (run on the MI355X box)")
-    # torch's ROCm wheel bundles its own HIP runtime, which has to be the first to open the device when torch and librtmi
-    # share a process (raytracing_amd/_lib.py): let it look now, so that any subset or order of the tests can use torch views
-    try:
-        import torch
-        if torch.cuda.is_available():
-            torch.cuda.init()
-    except Exception:
-        pass
 
 
 def golden(name):

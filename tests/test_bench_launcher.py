@@ -1,0 +1,64 @@
+"""bench.py started plainly with --gpus N > 1 launches its own N ranks (a child torch.distributed.run, never an exec) and
+forwards rank 0's JSON line and the exit status.  CPU: the command line and the forwarding; GPU: two ranks on one MI355X."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_launcher_command_forwards_every_argument():
+    argv = ["--gpus", "4", "--steps", "7", "--warmup", "3", "--total-rays", "1048576", "--record", "stride:16", "--backend", "gloo"]
+    cmd = bench.launcher_command(argv, 4, 29999, python="PY")
+    assert cmd[:3] == ["PY", "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    i = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[i + 1:] == argv                      # the ranks get the caller's arguments, in order, untouched
+    assert bench.free_port() > 0
+
+
+def _env_without_rank_variables():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return env
+
+
+@pytest.mark.timeout(300)
+def test_plain_start_with_two_gpus_spawns_two_ranks_and_forwards_their_status():
+    """No GPU here: both ranks stop at "no HIP device" -- which shows that the plain command reached two ranks (it used to
+    exit with "launch with torch.distributed.run" before starting anything) and that their failure is the parent's status."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("CPU-side test of the launcher (the GPU box runs the real thing below)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1", "--cpu-seconds", "0"],
+                       capture_output=True, text=True, env=_env_without_rank_variables(), timeout=280)
+    assert r.returncode != 0
+    assert r.stderr.count("no HIP device") >= 2, r.stderr[-2000:]
+    assert "launch with torch.distributed.run" not in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_plain_start_with_two_gpus_runs_two_ranks_on_the_gpu_box():
+    """`python3 bench.py --gpus 2 ...` as a plain subprocess: rc 0 and ONE JSON line with n_gpus 2 (both ranks share the box's
+    one MI355X; gloo carries the collectives because RCCL wants one GPU per rank)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--all-on-device", "0",
+                        "--rays", "65536", "--steps", "2", "--cpu-seconds", "0", "--gather-rows", "256"],
+                       capture_output=True, text=True, env=_env_without_rank_variables(), timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
+    assert out["config"]["rays_total"] == 2 * 65536
+    g = out["config"]["dist"]["gather"]
+    assert g["world"] == 2 and g["rays"] == 2 * 65536 and "error" not in g
+    assert g["trajectory"]["shape"] == [12, 6, 2 * 65536]          # every 256th of 3 072 rows, both ranks' rays in ray order
+    assert out["parity_check"]["ok"]

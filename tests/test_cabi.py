@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     L = C.CDLL(_lib.LIB_PATH)
     for name in declared_symbols():
         assert hasattr(L, name), name
-    assert _lib.lib().rtmi_abi_version() == _lib.ABI_VERSION == 5
+    assert _lib.lib().rtmi_abi_version() == _lib.ABI_VERSION == 6
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -48,11 +48,75 @@ def _worker(rank, world, port, tmp):
                     assert res[0] is None
             else:
                 assert res is None
+        # a rank without rays (more ranks than rays) contributes padding, the gather still answers in ray order
+        one = np.array([0.7])
+        res = rd.trazar_sharded(rb.op6, "vert_heterogeneous", False, rb.DELTA_S, 91, "3", thetas=one, record=64, device=0)
+        if rank == 0:
+            fld = rb.Field.build("vert_heterogeneous")
+            ref = rb.trazar(rb.op6, rb.FieldSpline(fld, "n"), (rb.FieldSpline(fld, "dy"), rb.FieldSpline(fld, "dx")), False, rb.DELTA_S, 91, "3",
+                            thetas=one, record=64)
+            fld.close()
+            assert res[0].shape == ref[0].shape and np.array_equal(res[0], ref[0]) and np.array_equal(res[1], ref[1])
+        # a rank whose local trace fails: every rank raises instead of one of them waiting in the gather forever
+        real = rb.trazar
+        if rank == 1:
+            def broken(*a, **k):
+                raise rb._lib.RtmiError(-3, "injected failure")
+            rb.trazar = broken
+        try:
+            rd.trazar_sharded(rb.op6, "vert_heterogeneous", False, rb.DELTA_S, 91, "3", thetas=np.linspace(0, 1, 8), device=0)
+            raised = False
+        except RuntimeError as e:
+            raised = "local trace failed" in str(e)
+        finally:
+            rb.trazar = real
+        assert raised, f"rank {rank} did not raise"
         if rank == 0:
             open(os.path.join(tmp, "ok"), "w").write("ok")
         dist.barrier()
     finally:
         dist.destroy_process_group()
+
+
+def _worker_rccl(rank, world, port, tmp):
+    """One rank, backend nccl (RCCL): trazar_sharded's device-to-device payload -- zero-copy views of the batch's HBM arrays
+    through dist.gather -- against the plain call.  (One GPU carries one RCCL rank; the N > 1 case is the same code.)"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.init()
+    torch.cuda.set_device(0)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from raytracing_amd import dist as rd
+        from raytracing_amd import rt_bench as rb
+        rng = np.random.default_rng(5)
+        cases = [("vert_heterogeneous", "3", rb.op6, np.linspace(0, np.pi / 2, 1001), "full", rb.F64),
+                 ("vert_heterogeneous", "3", rb.op6, rng.permutation(np.linspace(0, np.pi / 2, 4096)), 16, rb.F64),   # sort_rays kicks in: perm
+                 ("vert_heterogeneous", "3", rb.op7, np.linspace(0, np.pi / 2, 300), None, rb.F64),
+                 ("vert_heterogeneous", "3", rb.op6, np.linspace(0, np.pi / 2, 777), 8, rb.F32),
+                 ("interface", "1", rb.op6, None, "full", rb.F64)]
+        for scen, choice, op, th, record, dtype in cases:
+            res = rd.trazar_sharded(op, scen, False, rb.DELTA_S, 91, choice, thetas=th, record=record, dtype=dtype, device=0)
+            fld = rb.Field.build(scen, dtype=dtype)
+            z, grd = rb.FieldSpline(fld, "n"), (rb.FieldSpline(fld, "dy"), rb.FieldSpline(fld, "dx"))
+            ref = rb.trazar(op, z, grd, False, rb.DELTA_S, 91, choice, thetas=th, record=record)
+            fld.close()
+            assert np.array_equal(res[1], ref[1]) and np.array_equal(res[3], ref[3]), scen
+            if record is not None:
+                assert res[0].shape == ref[0].shape and np.array_equal(res[0], ref[0]), (scen, record)
+            else:
+                assert res[0] is None
+        open(os.path.join(tmp, "ok"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_trazar_sharded_device_gather_over_rccl(tmp_path):
+    mp.spawn(_worker_rccl, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "ok").exists()
 
 
 @pytest.mark.timeout(600)

@@ -176,6 +176,50 @@ def test_reference_order_mode(scen, m, rb, fields):
         assert err < 1e-15, (mode, err)                      # the reference itself (0 except where x*x differs from pow)
 
 
+@pytest.mark.parametrize("gam", [0.05, 0.3, 12.0, 50.0, 200.0])
+@pytest.mark.parametrize("m", [10, 11])
+def test_extreme_anisotropy_is_the_oracles_bits(m, gam, rb, fields):
+    """The golden-section certificates of op10/op11 bound the search's third-order remainder with suprema of the momentum
+    curve's derivatives, sampled per batch (gold_sup_derivatives): the curve's features are 1/max(gamma, 1/gamma) wide, so the
+    sampling is refined with it (gamma 0.05 .. 50 here) and beyond 64 the certificates are off and every comparison runs the
+    reference's arithmetic (gamma 200).  Every ray the oracle's bits either way."""
+    from oracle import rt_oracle as O
+    F, OF = fields("anisotropy")
+    lim = LIMITS["anisotropy"]
+    th = np.linspace(0, np.pi / 2, 64)
+    ms = 400
+    o = O.trazar(OF, m, gam, rb.DELTA_S, ms, lim, -2.0, -2.0, th, record_stride=0, nthreads=8)
+    b = rb.Batch(F, m, rb.DELTA_S, ms, lim, gam, th, -2.0, -2.0, record_stride=0)
+    b.run()
+    d, fin = b.d_ray(), b.final()
+    b.close()
+    assert _bits_equal(d, o["d_ray"]) and _bits_equal(fin, o["final"]), (m, gam, np.abs(fin - o["final"]).max())
+
+
+@pytest.mark.parametrize("scen", ["vert_heterogeneous", "fisheye", "interface"])
+def test_op7_steps_in_reference_order_by_default(scen, rb, fields):
+    """op7's new angle differentiates positions (RT_bench.py:370-372), so position bits matter: a default batch
+    (rtmi_params.reference_order = 0) gives the ORACLE's bits for op7 like reference_order = 1 does; the fused form is the
+    opt-in RTMI_ORDER_FUSED (2) -- close (1e-7) but not held to 1e-9."""
+    from oracle import rt_oracle as O
+    F, OF = fields(scen)
+    name = {"vert_heterogeneous": "traj_vert_op7", "fisheye": "traj_fisheye_op7_fan9", "interface": "traj_interface_op7_16"}[scen]
+    t = golden(name)
+    x0, y0, th = traj_inputs(t, scen)
+    step, ms, lim = float(t["step"]), int(t["max_size"]), t["box"]
+    o = O.trazar(OF, 7, 1, step, ms, lim, x0, y0, th, record_stride=1, nthreads=8)
+    b = rb.Batch(F, 7, step, ms, lim, 1, th, x0, y0, record_stride=1)
+    b.run()
+    assert _bits_equal(b.d_ray(), o["d_ray"]) and _bits_equal(b.final(), o["final"]) and _bits_equal(b.rows(), o["s_ray"])
+    b.close()
+    b = rb.Batch(F, 7, step, ms, lim, 1, th, x0, y0, record_stride=0, reference_order="fused")
+    b.run()
+    d, fin = b.d_ray(), b.final()
+    b.close()
+    assert np.array_equal(d[2], o["d_ray"][2])
+    assert np.abs(fin[:3] - o["final"][:3]).max() < 1e-7 and not _bits_equal(fin, o["final"])
+
+
 def test_reference_order_needs_fp64(rb):
     from raytracing_amd._lib import RtmiError
     F = rb.Field.build("vert_heterogeneous", LIMITS["vert_heterogeneous"], rb.DELTA, rb.F32)
