@@ -248,6 +248,51 @@ typedef struct {
 int rtmi_batch_stats(rtmi_batch *b, rtmi_stats *s);
 void rtmi_batch_destroy(rtmi_batch *b);
 
+/* ---------------------------------------------------------------- one call's rays over the GPUs of a node
+ * The reference's outer loop over rays (RT_bench.py:807) carries nothing from ray to ray, and the only parallelism it has is
+ * a pool of replica processes that pickle whole results back (:1317-1318, :1521-1523).  rtmi_shard is one trazar() call whose
+ * rays are dealt to `ndev` devices round-robin (ray k -> devices[k % ndev]: every device gets the same mix of short and long
+ * rays); each device builds the field itself (rtmi_field_build) and runs its rays (rtmi_batch_create / rtmi_run): no
+ * collective on the data path.  One host thread drives every GPU (the library starts one worker per device for the runs).
+ * The read-back functions gather to devices[0] DEVICE TO DEVICE -- RCCL's ncclGather over xGMI between the communicators
+ * of ncclCommInitAll, or peer copies -- and answer in the caller's ray order; results are the bits of an unsharded batch.
+ * (One process per GPU is the other way to spread a call: raytracing_amd/dist.py over torch.distributed.) */
+typedef struct rtmi_shard rtmi_shard;
+typedef enum {
+    RTMI_SHARD_AUTO = 0,   /* RCCL when librccl.so.1 loads and the devices are distinct, else copies */
+    RTMI_SHARD_RCCL = 1,   /* ncclCommInitAll + ncclGather; an error if that is not possible */
+    RTMI_SHARD_COPY = 2    /* hipMemcpyPeerAsync into devices[0] (also: the same device listed several times, to rehearse an
+                              N-way split on one GPU) */
+} rtmi_shard_transport;
+/* Arguments as rtmi_field_build + rtmi_batch_create; x0 / y0 / theta0 [R] are the whole call's launch conditions.
+ * p->ext_s_ray / ext_n_ray must be NULL.  R >= ndev. */
+int rtmi_shard_create(int scenario, double xi, double xs, double yi, double ys, double delta, const rtmi_params *p, int64_t R,
+                      const double *x0, const double *y0, const double *theta0, const int *devices, int ndev, int transport,
+                      rtmi_shard **out);
+/* rtmi_run / rtmi_batch_reset on every device at once; returns when all have finished. */
+int rtmi_shard_run(rtmi_shard *s);
+int rtmi_shard_reset(rtmi_shard *s);
+/* d_ray[3][R], final[9][R] as rtmi_read_d_ray / rtmi_read_final, of the whole call (host, fp64). */
+int rtmi_shard_read_d_ray(rtmi_shard *s, double *d_ray);
+int rtmi_shard_read_final(rtmi_shard *s, double *final9);
+/* Recorded rows row0, row0 + every, ... (nrows of them) of every ray, gathered on devices[0]: *rows_dev = DEVICE pointer to
+ * fp64 [nrows][6][R], valid until the next rtmi_shard_* call on s (for consumers that stay on the GPU); rtmi_shard_read_rows
+ * copies the same to the host. */
+int rtmi_shard_gather_rows(rtmi_shard *s, int64_t row0, int64_t nrows, int64_t every, double **rows_dev);
+int rtmi_shard_read_rows(rtmi_shard *s, int64_t row0, int64_t nrows, int64_t every, double *s_ray);
+typedef struct {
+    int32_t ndev, transport;     /* transport in use: RTMI_SHARD_RCCL or RTMI_SHARD_COPY */
+    int64_t R;
+    uint64_t ray_steps, live_rays;   /* summed over the devices */
+    double run_seconds;          /* wall time of the last rtmi_shard_run (all devices, host clock) */
+    double kernel_ms_max;        /* the slowest device's advance-kernel time since its last reset */
+    uint32_t auto_fallbacks, reserved_;
+} rtmi_shard_stats;
+int rtmi_shard_info(rtmi_shard *s, rtmi_shard_stats *st);
+/* Shard i's batch (owned by s) and its device: every rtmi_batch function applies (make *device current first). */
+int rtmi_shard_batch(rtmi_shard *s, int i, rtmi_batch **b, int *device);
+void rtmi_shard_destroy(rtmi_shard *s);
+
 /* Diagnostic: the library's libm-identical fp64 sin and cos (the functions op3/4/5/9/10/11 step with; they reproduce
  * glibc 2.35's sin()/cos(), i.e. numpy's np.sin/np.cos, bit for bit for |x| < 105414350) evaluated on the device
  * for n host values.  s[n], c[n]: host, fp64. */

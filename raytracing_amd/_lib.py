@@ -48,6 +48,12 @@ class Stats(C.Structure):
                 ("auto_fallbacks", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
+class ShardStats(C.Structure):
+    _fields_ = [("ndev", C.c_int32), ("transport", C.c_int32), ("R", C.c_int64), ("ray_steps", C.c_uint64), ("live_rays", C.c_uint64),
+                ("run_seconds", C.c_double), ("kernel_ms_max", C.c_double), ("auto_fallbacks", C.c_uint32), ("reserved_", C.c_uint32)]
+
+
+SHARD_AUTO, SHARD_RCCL, SHARD_COPY = 0, 1, 2
 # every symbol include/rtmi.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "rtmi_abi_version": (C.c_int, []),
@@ -81,6 +87,17 @@ SYMBOLS = {
     "rtmi_batch_view": (C.c_int, [C.c_void_p, C.POINTER(DeviceView)]),
     "rtmi_batch_stats": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "rtmi_batch_destroy": (None, [C.c_void_p]),
+    "rtmi_shard_create": (C.c_int, [C.c_int] + [C.c_double] * 5 + [C.POINTER(Params), C.c_int64, _dp, _dp, _dp, _ip, C.c_int, C.c_int,
+                                    C.POINTER(C.c_void_p)]),
+    "rtmi_shard_run": (C.c_int, [C.c_void_p]),
+    "rtmi_shard_reset": (C.c_int, [C.c_void_p]),
+    "rtmi_shard_read_d_ray": (C.c_int, [C.c_void_p, _dp]),
+    "rtmi_shard_read_final": (C.c_int, [C.c_void_p, _dp]),
+    "rtmi_shard_gather_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_void_p)]),
+    "rtmi_shard_read_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, _dp]),
+    "rtmi_shard_info": (C.c_int, [C.c_void_p, C.POINTER(ShardStats)]),
+    "rtmi_shard_batch": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]),
+    "rtmi_shard_destroy": (None, [C.c_void_p]),
     "rtmi_debug_sincos": (C.c_int, [C.c_int64, _dp, _dp, _dp]),
     "rtmi_debug_field_lookup": (C.c_int, [C.c_void_p, C.c_int64] + [_dp] * 5),
 }

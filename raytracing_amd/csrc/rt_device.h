@@ -226,6 +226,11 @@ template <typename T> struct FieldDev {
     // fast-form step methods evaluate (PolyGather below); zn / g serve the reference-order methods and rtmi_field_eval
     const T* poly;
     int ncx;     // cells per grid row, qx - 1
+    // flat: 0, or the distance (in elements) from the FLAT-CELL MAP to poly: flatn[cell] = poly[cell - flat] holds the constant
+    // index of a cell where the medium is constant (rt::poly_cell_flat), all-ones bits elsewhere.  Such a cell's lookup is
+    // (flatn, 0, 0) and never touches its 36 coefficients; 8 (fp64) cells of a grid row share a cache line of the map, where
+    // every cell of the table proper is five lines of its own.  0 when no cell of the grid is flat: one scalar test per lookup.
+    int flat;
     // rdx / rdy: [q][8] fp64, per cell index of an axis the correctly rounded reciprocals of the seven knot differences
     // FITPACK's fpbspl divides by there (rt_exact.h, axis_exact); nullptr in fp32 fields (the reference-order path is fp64)
     const double *rdx, *rdy;
@@ -817,6 +822,28 @@ template <typename T, int SC> __device__ __forceinline__ T poly_bilinear(Quad<T>
 // The arithmetic is poly_bicubic / poly_bilinear on the same numbers either way: the result does not depend on the policy,
 // on the wave mates or on which round served the lane.
 constexpr int kPolyLane = 0, kPolyScalar = 1, kPolyCached = 2;
+// The flat-cell map (FieldDev::flat).  An entry is the cell's constant index, or all-ones bits (a NaN) for an ordinary cell.
+template <typename T> struct FlatBits;
+template <> struct FlatBits<double> { typedef unsigned long long type; };
+template <> struct FlatBits<float> { typedef unsigned type; };
+template <typename T> __device__ __forceinline__ bool flat_entry(typename FlatBits<T>::type b) { return b != ~(typename FlatBits<T>::type)0; }
+// per lane (vector load): the lanes of an incoherent wave, the one-lane-per-point lookups
+template <typename T> __device__ __forceinline__ bool flat_lane(const FieldDev<T>& F, int cell, T& c) {
+    typedef typename FlatBits<T>::type B;
+    const B b = reinterpret_cast<const B*>(F.poly)[(long)cell - (long)F.flat];
+    c = __builtin_bit_cast(T, b);
+    return flat_entry<T>(b);
+}
+// for a wave-uniform cell, through the scalar cache
+template <typename T> __device__ __forceinline__ bool flat_uniform(const FieldDev<T>& F, int cu, T& c) {
+    typedef typename FlatBits<T>::type B;
+    typedef const B __attribute__((address_space(4)))* SP;
+    SP q = (SP)(F.poly) + ((long)cu - (long)F.flat);
+    asm volatile("" : "+s"(q));
+    const B b = *q;
+    c = __builtin_bit_cast(T, b);
+    return flat_entry<T>(b);
+}
 template <typename T, int MODE> struct PolyGather {
     static constexpr bool SCALAR = MODE == kPolyScalar;
     static constexpr bool CACHED = MODE == kPolyCached;
@@ -851,7 +878,15 @@ template <typename T, int MODE> struct PolyGather {
         gy = poly_bicubic<T, 1>(row, 4, u, v);
 #endif
     }
+    // one lane, its own cell: the flat-cell rule first (a flat cell's coefficients are never read), else the polynomial
     static __device__ __forceinline__ void eval_lane(const FieldDev<T>& F, int cell, T u, T v, T& n, T& gx, T& gy) {
+        if (F.flat) {
+            T cf;
+            if (flat_lane(F, cell, cf)) { n = cf; gx = T(0); gy = T(0); return; }
+        }
+        eval_lane_poly(F, cell, u, v, n, gx, gy);
+    }
+    static __device__ __forceinline__ void eval_lane_poly(const FieldDev<T>& F, int cell, T u, T v, T& n, T& gx, T& gy) {
         const Quad<T>* p = reinterpret_cast<const Quad<T>*>(F.poly + (size_t)cell * kPolyStride);
         if constexpr (CACHED) {
             // this build has the registers: all nine rows in flight, one memory latency (the cells of a wave that straddles a
@@ -895,6 +930,15 @@ template <typename T, int MODE> struct PolyGather {
         n = poly_bilinear<T, 2>(rows[N == 9 ? 8 : 0], u, v);
     }
     template <int N> static __device__ __forceinline__ void load_rows(Quad<T> (&rows)[N], const FieldDev<T>& F, int cu) {
+        if (F.flat) {       // a flat cell is kept as the polynomial (b0, 0, ...): eval_rows then gives (b0, 0, 0) exactly
+            T cf;
+            if (flat_uniform(F, cu, cf)) {
+#pragma unroll
+                for (int k = 0; k < N; k++) rows[k] = Quad<T>{T(0), T(0), T(0), T(0)};
+                rows[N == 9 ? 8 : 0].x = cf;
+                return;
+            }
+        }
         // every lane loads the same 288 bytes (one address per instruction: a broadcast in the texture path)
         typedef const Quad<T> __attribute__((address_space(1)))* GlobalRows;
         GlobalRows p = (GlobalRows)(F.poly + (size_t)cu * kPolyStride);
@@ -928,6 +972,10 @@ template <typename T, int MODE> struct PolyGather {
             ScalarRows p = (ScalarRows)(F.poly + (size_t)cu * kPolyStride);
             asm volatile("" : "+s"(p));
             if ((rt_ballot(c.cell != cu) & live) == 0ull) {
+                if (F.flat) {
+                    T cf;
+                    if (flat_uniform(F, cu, cf)) { n = cf; gx = T(0); gy = T(0); return; }     // scalar branch: the map entry is wave-uniform
+                }
                 eval_scalar(p, c.u, c.v, n, gx, gy);
                 return;
             }
@@ -942,7 +990,9 @@ template <typename T, int MODE> struct PolyGather {
                     p = (ScalarRows)(F.poly + (size_t)cu * kPolyStride);
                     asm volatile("" : "+s"(p));
                     if (c.cell == cu) {
-                        eval_scalar(p, c.u, c.v, n, gx, gy);
+                        T cf;
+                        if (F.flat && flat_uniform(F, cu, cf)) { n = cf; gx = T(0); gy = T(0); }
+                        else eval_scalar(p, c.u, c.v, n, gx, gy);
                         todo = false;
                     }
                 }

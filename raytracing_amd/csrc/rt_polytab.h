@@ -135,4 +135,19 @@ RT_PT_HD inline void poly_cell_convert(const double* Z, const double* cdx, const
         }
 }
 
+// A FLAT cell: the medium is constant there as far as a ray can tell -- every one of the 32 coefficients of the two gradient
+// polynomials is at most thr in magnitude (thr = 2^-80 of the largest gradient-spline coefficient of the grid: the global
+// spline of a piecewise-constant medium decays geometrically away from the transitions but never reaches zero; 2^-80 of the
+// field's gradient scale moves an angle by 1e-30 per step) and n's polynomial varies by less than 2^-50 of its constant term
+// across the cell (the rounding residue of the bilinear weights of equal samples).  The lookup then answers (b0, 0, 0) without
+// touching the cell's 36 coefficients (rt::PolyGather): both flanks of the interface scenario's sigmoid, i.e. most of its steps.
+// The rule is part of the lookup's definition -- every path applies it -- so results do not depend on which path served a lane.
+constexpr double kPolyFlatRel = 0x1p-80, kPolyFlatN = 0x1p-50;
+RT_PT_HD inline bool poly_cell_flat(const double c[36], double thr) {
+    for (int i = 0; i < 32; i++)
+        if (!(__builtin_fabs(c[i]) <= thr)) return false;
+    const double t = kPolyFlatN * __builtin_fabs(c[32]);
+    return __builtin_fabs(c[33]) <= t && __builtin_fabs(c[34]) <= t && __builtin_fabs(c[35]) <= t;
+}
+
 }  // namespace rt

@@ -113,6 +113,9 @@ struct rtmi_field {
     // packed, dtype-typed arrays the trace kernels gather from
     void *zn = nullptr, *g = nullptr;
     void* poly = nullptr;        // [(qy-1)*(qx-1)][rt::kPolyStride] of dtype: one polynomial per cell (rt_polytab.h)
+    void* poly_base = nullptr;   // the allocation: the flat-cell map ([flat_pad] of dtype, rt::FieldDev::flat), then the table
+    long flat_pad = 0;           // elements from the map's start to the table's
+    long flat_cells = 0;         // cells the map marks flat (0: the kernels never look at it)
     double* rdiv = nullptr;      // [qx][8] then [qy][8]: reciprocals of the knot differences fpbspl divides by (rt_exact.h)
     hipStream_t stream = nullptr;
 };
@@ -148,6 +151,7 @@ template <typename T> static rt::FieldDev<T> field_dev(const rtmi_field* f, int 
     F.inv_hy = (T)(1.0 / f->hy);
     F.poly = (const T*)f->poly;
     F.ncx = f->qx - 1;
+    F.flat = f->flat_cells > 0 ? (int)f->flat_pad : 0;
     F.rdx = f->rdiv;
     F.rdy = f->rdiv ? f->rdiv + (size_t)f->qx * 8 : nullptr;
     return F;
@@ -292,17 +296,39 @@ template <typename T> __global__ void k_pack(const double* Z, const double* cdy,
     g[2 * i + 1] = (T)cdy[i];  // d/dy spline = grd[0] (:155)
 }
 
-// The per-cell polynomial table (rt_polytab.h): one thread per cell, fp64 conversion, stored in the field's dtype.
+// The per-cell polynomial table (rt_polytab.h): one thread per cell, fp64 conversion, stored in the field's dtype; and the
+// flat-cell map in front of it (rt::poly_cell_flat; thr from the grid's largest gradient-spline coefficient, k_absmax).
 template <typename T>
 __global__ void k_polytab(const double* Z, const double* cdx, const double* cdy, int qx, int qy, const double* Cx, const double* Lx,
-                          const double* Cy, const double* Ly, T* out) {
+                          const double* Cy, const double* Ly, T* out, T* flatn, const unsigned long long* gmax_bits,
+                          unsigned long long* nflat) {
     const int jx = blockIdx.x * blockDim.x + threadIdx.x, jy = blockIdx.y;
-    if (jx >= qx - 1 || jy >= qy - 1) return;
-    double c[36];
-    rt::poly_cell_convert(Z, cdx, cdy, qx, qy, jx, jy, Cx, Lx, Cy, Ly, c);
-    T* o = out + ((size_t)jy * (qx - 1) + jx) * rt::kPolyStride;
-    for (int i = 0; i < 36; i++) o[i] = (T)c[i];
-    for (int i = 36; i < rt::kPolyStride; i++) o[i] = T(0);
+    bool flat = false;
+    if (jx < qx - 1 && jy < qy - 1) {
+        double c[36];
+        rt::poly_cell_convert(Z, cdx, cdy, qx, qy, jx, jy, Cx, Lx, Cy, Ly, c);
+        const size_t cell = (size_t)jy * (qx - 1) + jx;
+        T* o = out + cell * rt::kPolyStride;
+        for (int i = 0; i < 36; i++) o[i] = (T)c[i];
+        for (int i = 36; i < rt::kPolyStride; i++) o[i] = T(0);
+        flat = rt::poly_cell_flat(c, __builtin_bit_cast(double, *gmax_bits) * rt::kPolyFlatRel);
+        typedef typename rt::FlatBits<T>::type B;
+        reinterpret_cast<B*>(flatn)[cell] = flat ? __builtin_bit_cast(B, (T)c[32]) : ~(B)0;
+    }
+    const unsigned long long votes = rt_ballot(flat);                 // one atomic per wave
+    if ((threadIdx.x & 63) == 0 && votes) atomicAdd(nflat, (unsigned long long)__popcll(votes));
+}
+// max |v| over two arrays as the bit pattern of a non-negative double (ordered like the integers)
+__global__ void k_absmax(const double* a, const double* b, size_t n, unsigned long long* out) {
+    unsigned long long m = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, fabs(a[i])), v = __builtin_bit_cast(unsigned long long, fabs(b[i]));
+        m = u > m ? u : m;
+        m = v > m ? v : m;                    // (a NaN coefficient orders above everything: no cell is flat then)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long w = __shfl_xor(m, o, 64); m = w > m ? w : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
 // FAST: the fast-form step methods' lookup (the cell's polynomial, one lane per point); else FITPACK's arithmetic on the
@@ -479,14 +505,31 @@ static int field_finish_impl(rtmi_field* f, double delta) {
             HIP_TRY(hipMemcpyAsync(dLx, PX.L.data(), PX.L.size() * sizeof(double), hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(dCy, PY.C.data(), PY.C.size() * sizeof(double), hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(dLy, PY.L.data(), PY.L.size() * sizeof(double), hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMalloc(&f->poly, ncell * rt::kPolyStride * esz));
-            const dim3 pg((qx - 1 + 63) / 64, qy - 1), pb(64);
-            if (f->dtype == RTMI_F64)
-                hipLaunchKernelGGL(k_polytab<double>, pg, pb, 0, st, f->dZ, f->dCdx, f->dCdy, qx, qy, dCx, dLx, dCy, dLy, (double*)f->poly);
-            else
-                hipLaunchKernelGGL(k_polytab<float>, pg, pb, 0, st, f->dZ, f->dCdx, f->dCdy, qx, qy, dCx, dLx, dCy, dLy, (float*)f->poly);
-            HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(st));  // the host tables go out of scope
+            // one allocation: the flat-cell map (one entry per cell, padded to 32 entries), then the table
+            f->flat_pad = (long)((ncell + 31) / 32 * 32);
+            HIP_TRY(hipMalloc(&f->poly_base, ((size_t)f->flat_pad + ncell * rt::kPolyStride) * esz));
+            f->poly = (char*)f->poly_base + (size_t)f->flat_pad * esz;
+            unsigned long long* dcnt = nullptr;      // [0] bits of max |gradient-spline coefficient|, [1] flat cells
+            HIP_TRY(hipMalloc(&dcnt, 2 * sizeof(unsigned long long)));
+            unsigned long long hcnt[2] = {0, 0};
+            hipError_t e = hipMemsetAsync(dcnt, 0, sizeof(hcnt), st);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(k_absmax, dim3(256), dim3(256), 0, st, f->dCdx, f->dCdy, nz, dcnt);
+                const dim3 pg((qx - 1 + 63) / 64, qy - 1), pb(64);
+                if (f->dtype == RTMI_F64)
+                    hipLaunchKernelGGL(k_polytab<double>, pg, pb, 0, st, f->dZ, f->dCdx, f->dCdy, qx, qy, dCx, dLx, dCy, dLy, (double*)f->poly,
+                                       (double*)f->poly_base, dcnt, dcnt + 1);
+                else
+                    hipLaunchKernelGGL(k_polytab<float>, pg, pb, 0, st, f->dZ, f->dCdx, f->dCdy, qx, qy, dCx, dLx, dCy, dLy, (float*)f->poly,
+                                       (float*)f->poly_base, dcnt, dcnt + 1);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipMemcpyAsync(hcnt, dcnt, sizeof(hcnt), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);  // the host tables go out of scope
+            (void)hipFree(dcnt);
+            HIP_TRY(e);
+            f->flat_cells = getenv("RTMI_NO_FLAT") ? 0 : (long)hcnt[1];     // RTMI_NO_FLAT=1: A/B without the map
+            if (getenv("RTMI_DEBUG")) fprintf(stderr, "rtmi: field %d x %d: %ld of %zu cells flat\n", qx, qy, (long)hcnt[1], ncell);
         }
         HIP_TRY(hipStreamSynchronize(st));  // host vectors / LU buffers go out of scope
         return RTMI_OK;
@@ -522,7 +565,7 @@ RTMI_EXPORT int rtmi_device_count(int* count) {
 RTMI_EXPORT void rtmi_field_destroy(rtmi_field* f) {
     if (!f) return;
     (void)hipFree(f->dZ); (void)hipFree(f->dCdy); (void)hipFree(f->dCdx); (void)hipFree(f->zn); (void)hipFree(f->g);
-    (void)hipFree(f->poly);
+    (void)hipFree(f->poly_base);
     (void)hipFree(f->rdiv);
     delete f;
 }
@@ -2117,6 +2160,23 @@ RTMI_EXPORT int rtmi_read_final(rtmi_batch* b, double* final9) {
     if (e == hipSuccess) e = hipMemcpyAsync(final9, d, nb, hipMemcpyDeviceToHost, b->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(b->stream);
     if (e != hipSuccess) return fail(RTMI_ERR_HIP, std::string("rtmi_read_final: ") + hipGetErrorString(e));
+    return RTMI_OK;
+}
+
+int rtmi_internal_pack_device(rtmi_batch* b, int what, double* dst, void* stream) {
+    ARG_TRY(b && dst, "rtmi_internal_pack_device: null");
+    DEVICE_TRY(b->field, "rtmi_shard read-back");
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 g((unsigned)((b->R + 255) / 256)), blk(256);
+    if (what == 0) {
+        if (b->p.dtype == RTMI_F64) hipLaunchKernelGGL(k_pack_d_ray<double>, g, blk, 0, st, batch_dev<double>(b), dst);
+        else hipLaunchKernelGGL(k_pack_d_ray<float>, g, blk, 0, st, batch_dev<float>(b), dst);
+    } else {
+        if (b->p.dtype == RTMI_F64) hipLaunchKernelGGL(k_pack_final<double>, g, blk, 0, st, batch_dev<double>(b), dst);
+        else hipLaunchKernelGGL(k_pack_final<float>, g, blk, 0, st, batch_dev<float>(b), dst);
+    }
+    HIP_TRY(hipGetLastError());
     return RTMI_OK;
 }
 

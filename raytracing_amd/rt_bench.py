@@ -476,6 +476,77 @@ class Batch:
             pass
 
 
+class Shard:
+    """One trazar() call's rays over several GPUs of this node from ONE process (rtmi_shard, include/rtmi.h): rays dealt to
+    `devices` round-robin, each device builds the field and runs its rays, the read-back gathers to devices[0] device to device
+    (transport "auto" | "rccl" | "copy").  Listing one device several times rehearses the split on a single GPU (copies)."""
+
+    def __init__(self, scenario, method, step, max_size, box, gamma, thetas, x0, y0, devices, limits=None, delta=DELTA, dtype=F64,
+                 record_stride=1, rec_rows=0, transport="auto", gamma_step=None, launch_mode="auto", reference_order=False,
+                 keep_n_ray=False):
+        sc = SCENARIOS[scenario] if isinstance(scenario, str) else scenario
+        if limits is None:
+            limits = constants(USER_CHOICE[scenario])[5:9]
+        th = np.ascontiguousarray(thetas, dtype=np.float64)
+        self.R = len(th)
+        x0 = np.ascontiguousarray(np.broadcast_to(np.asarray(x0, dtype=np.float64), (self.R,)))
+        y0 = np.ascontiguousarray(np.broadcast_to(np.asarray(y0, dtype=np.float64), (self.R,)))
+        p = Params()
+        p.method = _method_id(method); p.dtype = dtype
+        p.gamma = float(gamma); p.gamma_step = float(gamma if gamma_step is None else gamma_step)
+        p.step = float(step); p.max_size = int(max_size); p.record_stride = int(record_stride); p.rec_rows = int(rec_rows)
+        for i in range(4):
+            p.box[i] = float(box[i])
+        p.launch_mode = LAUNCH_MODES[launch_mode] if isinstance(launch_mode, str) else int(launch_mode)
+        p.no_n_ray = int(not keep_n_ray)
+        p.reference_order = ORDERS[reference_order] if isinstance(reference_order, str) else int(reference_order)
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        self.devices = [int(d) for d in dev]
+        self._h = C.c_void_p()
+        check(lib().rtmi_shard_create(sc.code, *[float(v) for v in limits], float(delta), C.byref(p), self.R, dptr(x0), dptr(y0), dptr(th),
+                                      dev.ctypes.data_as(_lib._ip), len(dev), {"auto": 0, "rccl": 1, "copy": 2}[transport],
+                                      C.byref(self._h)))
+
+    def run(self):
+        check(lib().rtmi_shard_run(self._h))
+
+    def reset(self):
+        check(lib().rtmi_shard_reset(self._h))
+
+    def d_ray(self):
+        d = np.empty((3, self.R))
+        check(lib().rtmi_shard_read_d_ray(self._h, dptr(d)))
+        return d
+
+    def final(self):
+        out = np.empty((9, self.R))
+        check(lib().rtmi_shard_read_final(self._h, dptr(out)))
+        return out
+
+    def rows(self, row0, nrows, every=1):
+        s = np.empty((nrows, 6, self.R))
+        check(lib().rtmi_shard_read_rows(self._h, int(row0), int(nrows), int(every), dptr(s)))
+        return s
+
+    def info(self):
+        st = _lib.ShardStats()
+        check(lib().rtmi_shard_info(self._h, C.byref(st)))
+        out = {k: getattr(st, k) for k, _ in _lib.ShardStats._fields_ if k != "reserved_"}
+        out["transport"] = {1: "rccl", 2: "copy"}.get(out["transport"], out["transport"])
+        return out
+
+    def close(self):
+        if self._h:
+            lib().rtmi_shard_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def device_sincos(x):
     """The library's libm-identical fp64 sin and cos (rtmi_debug_sincos), evaluated on the device -> (sin, cos)."""
     x = np.ascontiguousarray(x, dtype=np.float64)

@@ -12,11 +12,17 @@ extern "C" int polytab_build(const double* x, int qx, const double* y, int qy, c
                              const double* cdy, double inv_hx, double inv_hy, double* out) {
     const rt::PolyAxis AX = rt::poly_axis_build(std::vector<double>(x, x + qx), x[0], inv_hx);
     const rt::PolyAxis AY = rt::poly_axis_build(std::vector<double>(y, y + qy), y[0], inv_hy);
+    // the flat-cell rule of the lookup (rt::poly_cell_flat): threshold from the largest gradient-spline coefficient, like
+    // the library's field build; the verdict is kept in the entry's first unused slot here (the library keeps a map of its own)
+    double gmax = 0.0;
+    for (size_t i = 0; i < (size_t)qx * qy; i++) gmax = std::fmax(gmax, std::fmax(std::fabs(cdx[i]), std::fabs(cdy[i])));
+    const double thr = gmax * rt::kPolyFlatRel;
     for (int jy = 0; jy < qy - 1; jy++)
         for (int jx = 0; jx < qx - 1; jx++) {
             double* o = out + ((size_t)jy * (qx - 1) + jx) * rt::kPolyStride;
             rt::poly_cell_convert(Z, cdx, cdy, qx, qy, jx, jy, AX.C.data(), AX.L.data(), AY.C.data(), AY.L.data(), o);
             for (int i = 36; i < rt::kPolyStride; i++) o[i] = 0.0;
+            o[36] = rt::poly_cell_flat(o, thr) ? 1.0 : 0.0;
         }
     return 0;
 }
@@ -48,6 +54,7 @@ extern "C" void polytab_eval(const double* tab, int qx, int qy, double ax, doubl
         for (int k = 0; k < 4; k++) r[k] = horner3(p + 16 + 4 * k, u);
         gy[i] = horner3(r, v);
         n[i] = std::fma(std::fma(p[35], u, p[34]), v, std::fma(p[33], u, p[32]));
+        if (p[36] != 0.0) { n[i] = p[32]; gx[i] = 0.0; gy[i] = 0.0; }      // a flat cell answers (b0, 0, 0)
     }
 }
 

@@ -50,9 +50,9 @@ def test_ctypes_structs_match_the_header(tmp_path):
     """sizeof of the ctypes mirrors == sizeof of the C structs (gcc on include/rtmi.h)."""
     import subprocess
     src = tmp_path / "sz.c"
-    src.write_text('#include "rtmi.h"\n#include <stdio.h>\nint main(void){printf("%zu %zu %zu\\n", sizeof(rtmi_params), '
-                   'sizeof(rtmi_stats), sizeof(rtmi_device_view)); return 0;}\n')
+    src.write_text('#include "rtmi.h"\n#include <stdio.h>\nint main(void){printf("%zu %zu %zu %zu\\n", sizeof(rtmi_params), '
+                   'sizeof(rtmi_stats), sizeof(rtmi_device_view), sizeof(rtmi_shard_stats)); return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
     sizes = [int(v) for v in subprocess.check_output([str(exe)]).split()]
-    assert sizes == [C.sizeof(_lib.Params), C.sizeof(_lib.Stats), C.sizeof(_lib.DeviceView)]
+    assert sizes == [C.sizeof(_lib.Params), C.sizeof(_lib.Stats), C.sizeof(_lib.DeviceView), C.sizeof(_lib.ShardStats)]

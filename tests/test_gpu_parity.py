@@ -11,6 +11,7 @@ import os
 import numpy as np
 import pytest
 
+from bench import parity_relerr
 from conftest import LIMITS, golden, sub_rows, traj_fixtures, traj_inputs
 
 pytestmark = pytest.mark.gpu
