@@ -468,6 +468,15 @@ def main():
             prof = {}
         if not isinstance(prof, dict):        # round-1 format: a bare byte count
             prof = {"hbm_bytes": prof, "source": "profiles/r01_f_head_pmc_summary.txt"}
+        # the profile describes a BUILD: its counters are borrowed only while the kernel that just ran is the one that was
+        # profiled -- same kernel, same register count (profile_summary.py records both; entries of before round 4 carry neither
+        # and are taken as they are)
+        kernel_name = {"refill": "k_trace_refill", "sliced": "k_advance_sliced"}.get(mode_used, "k_advance")
+        stale = None
+        if prof and (prof.get("vgprs") not in (None, st["vgprs"]) or prof.get("kernel") not in (None, kernel_name)):
+            stale = (f"{prof.get('source')} was measured on {prof.get('kernel')} with {prof.get('vgprs')} VGPRs; this build ran "
+                     f"{kernel_name} with {st['vgprs']}: not used")
+            prof = {}
         measured = prof.get("hbm_bytes") if args.chunk <= 0 else None
         model = min_hbm_bytes(args.dtype, stride, steps_per_pass, R_local, args.method, args.n_ray)
         hbm_bytes = measured if measured else model
@@ -480,6 +489,8 @@ def main():
                                          "source": "profiles/r02_f_hbm_write_ceiling.txt (tools/hbm_fill.hip)"}
         roof = dict(hbm, bound="hbm", traffic=measured, traffic_source=prof.get("source") if measured else None,
                     traffic_key=key if measured else None)
+        if stale:
+            roof["traffic_stale"] = stale
         roof.pop("write_only_ceiling", None)
         # vector-ALU issue time from the profiled instruction counts: a 64-lane fp64 instruction holds a SIMD for 4 cycles
         # (16 lanes/clk), any other VALU instruction for 2 (SIMD-32); against 1024 SIMDs at the 2.4 GHz peak clock
@@ -493,7 +504,7 @@ def main():
             roof["valu_issue"] = valu
             if frac > roof["frac"]:
                 roof.update(bound="valu", achieved=valu["achieved"], peak=valu["peak"], unit=valu["unit"], frac=frac)
-        roof.update(kernel={"refill": "k_trace_refill", "sliced": "k_advance_sliced"}.get(mode_used, "k_advance"), kernel_ms=kern_ms / launches,
+        roof.update(kernel=kernel_name, kernel_ms=kern_ms / launches,
                     kernel_ms_per_pass=kern_ms, launches_per_pass=launches, ray_steps_per_pass=int(steps_per_pass),
                     vgprs=st["vgprs"], hbm=hbm,
                     alg_model={"bytes_per_ray_step": balg, "GB_per_s": balg * steps_per_pass / ksec / 1e9,

@@ -1112,17 +1112,21 @@ def test_set_per_ray_only_on_a_fresh_batch_and_reset_clears_rows(rb, gpu_fields)
 
 # ------------------------------------------------------------------ BASELINE configs at FULL size on one GPU
 def test_cfg5_anisotropy_full_1m_rays(rb, gpu_fields, oracle_fields):
-    """cfg5 whole: anisotropy (gamma = 3), op11, 1 048 576 rays fp64 on ONE MI355X.  p_x (the ray parameter of a
-    vertically heterogeneous medium) conserved over the whole fan, the device step counter against sum(d_ray[2]), and
-    every 8192nd ray against the oracle: the oracle's bits (golden-section method, reference-order arithmetic)."""
+    """cfg5 whole: anisotropy (gamma = 3), op11, 1 048 576 rays fp64 on ONE MI355X, every 16th row recorded (9.7 GB).  p_x (the
+    ray parameter of a vertically heterogeneous medium) conserved over the whole fan, the device step counter against
+    sum(d_ray[2]), and every 256th ray -- 4 096 rays: d_ray, final state and every recorded row -- against the oracle: the
+    oracle's bits (golden-section method, reference-order arithmetic; rows past a ray's last one zero)."""
     from oracle import rt_oracle as O
     R = 1 << 20
     th = np.linspace(0, np.pi / 2, R)
     lim = LIMITS["anisotropy"]
     ms = int(np.ceil(80 / rb.DELTA_S) + 1)
-    b = rb.Batch(gpu_fields("anisotropy"), 11, rb.DELTA_S, ms, lim, 3, th, -2.0, -2.0, record_stride=0)
+    rows = 3072 // 16
+    b = rb.Batch(gpu_fields("anisotropy"), 11, rb.DELTA_S, ms, lim, 3, th, -2.0, -2.0, record_stride=16, rec_rows=rows, keep_n_ray=False)
     b.run()
     d, fin, st = b.d_ray(), b.final(), b.stats()
+    sub = slice(0, R, 256)
+    got = b.device_tensors()["s_ray"][:, :, sub].cpu().numpy()        # 192 x 6 x 4096 of the record in HBM
     b.close()
     assert st["ray_steps"] == int(d[2].sum()) and st["live_rays"] == 0
     assert 1100 <= d[2].min() and d[2].max() <= 2900
@@ -1130,9 +1134,36 @@ def test_cfg5_anisotropy_full_1m_rays(rb, gpu_fields, oracle_fields):
     coef0 = np.sqrt((3 * np.sin(th)) ** 2 + np.cos(th) ** 2)
     px0 = n0 * coef0 * np.cos(th) * (1 + (-np.sin(th) ** 2) * 8 / coef0 ** 2)
     assert np.max(np.abs(fin[6] - px0)) / n0 < 5e-4
-    sub = slice(0, R, 8192)
-    o = O.trazar(oracle_fields("anisotropy"), 11, 3, rb.DELTA_S, ms, lim, -2.0, -2.0, th[sub], record_stride=0, nthreads=16)
+    o = O.trazar(oracle_fields("anisotropy"), 11, 3, rb.DELTA_S, ms, lim, -2.0, -2.0, th[sub], record_stride=16, rec_rows=rows, nthreads=16)
     assert np.array_equal(d[:, sub], o["d_ray"]) and np.array_equal(fin[:, sub], o["final"])
+    assert got.shape == o["s_ray"].shape and np.array_equal(got, o["s_ray"])
+
+
+def test_cfg3_fisheye_full_1m_rays_every_row(rb, gpu_fields, oracle_fields):
+    """cfg3 whole with the reference's full record: fisheye, 1 048 576 rays from (1, 0), op6, the calibrated DELTA_S = 2 pi / 303,
+    s_ray[3040][6][R] = 153 GB on ONE MI355X, the library's default schedule.  Every recorded row of every 512th ray (2 048
+    rays x 3 040 rows) against the oracle at 1e-9 per quantity, rows past a ray's last one zero (np.zeros, RT_bench.py:802), step
+    counts equal, the device counter against sum(d_ray[2])."""
+    from oracle import rt_oracle as O
+    R = 1 << 20
+    th = np.linspace(np.pi / 4, 3 * np.pi / 4, R)
+    lim = LIMITS["fisheye"]
+    step, ms = 2 * np.pi / 303, rb.N * 304
+    b = rb.Batch(gpu_fields("fisheye"), 6, step, ms, lim, 1, th, 1.0, 0.0, record_stride=1, keep_n_ray=False)
+    b.run()
+    d, st = b.d_ray(), b.stats()
+    sub = slice(0, R, 512)
+    got = b.device_tensors()["s_ray"][:, :, sub].cpu().numpy()
+    b.close()
+    assert st["ray_steps"] == int(d[2].sum()) and st["live_rays"] == 0 and got.shape == (ms, 6, 2048)
+    o = O.trazar(oracle_fields("fisheye"), 6, 1, step, ms, lim, 1.0, 0.0, th[sub], record_stride=1, nthreads=16)
+    assert np.array_equal(d[2][sub], o["d_ray"][2])
+    err = relerr(got, o["s_ray"])
+    print(f"cfg3 full record: {got.shape[0]} rows x 6 x {got.shape[2]} rays vs oracle: max rel err {err:.2e}")
+    assert err < REL and relerr(d[:2, sub], o["d_ray"][:2]) < REL
+    last = d[2][sub].astype(int)
+    for k in range(got.shape[2]):
+        assert not got[last[k] + 1:, :, k].any()
 
 
 def test_cfg4_fp32_full_8m_rays(rb, gpu_fields):

@@ -63,7 +63,8 @@ def main():
         lines.append(f"{'counter':28s} {'n':>3s} {'per launch':>16s} {'per wave-step':>14s}")
         for k in sorted(vals):
             lines.append(f"{k:28s} {ns[k]:3d} {vals[k]:16.6g} {vals[k] / wsteps:14.2f}")
-        entry = {"source": f"profiles/{tag}_pmc_summary.txt"}
+        # what the counters were measured ON: bench.py uses the entry only for the same kernel at the same register count
+        entry = {"source": f"profiles/{tag}_pmc_summary.txt", "kernel": roof.get("kernel"), "vgprs": roof.get("vgprs")}
         if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
             hbm = (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024
             entry["hbm_bytes"] = hbm
