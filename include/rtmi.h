@@ -210,7 +210,10 @@ int rtmi_isochrones(rtmi_batch *b, int32_t ntimes, const double *times, double *
  *   nodes[ntimes][7][R]      per sorted position j < count: y, x, ray angle, dx/dy, normal angle, |ray angle - normal angle|,
  *                            ray index (caller's order); NaN at j >= count, and in the derived columns when count < 2
  *   fine[ntimes][2][nfine]   x, y of the interpolated wavefront (NaN when count < 2); nfine = 0 skips it (fine may be NULL)
- * Needs record_stride 1.  Points with equal y make scipy raise; here they give NaN in the derived columns. */
+ * Needs record_stride 1.  Points with equal y make scipy raise; here they give NaN in the derived columns.
+ * All `ntimes` wavefronts are made in ONE pass (one sort of every point by y, a stable regrouping per traveltime, one PCHIP
+ * stage, one copy to the host): the 45 frames of the reference's animation (travel_time = 0.01 + 0.01 frame, :1066-1102) are
+ * one call. */
 int rtmi_wavefronts(rtmi_batch *b, int32_t ntimes, const double *times, int32_t nfine, int64_t *count, double *nodes,
                     double *fine);
 

@@ -66,6 +66,14 @@ __device__ __forceinline__ SinCos sincos_inline(double x) {
     }
     return r;
 }
+// Which methods take their step's sin / cos inline: measured per method (profiles/r04_ab_inline_sincos.txt) -- the curvature and
+// golden-section methods gain 1-6 %, op1/2/6/7/8 in reference order lose 11-42 % (their kernels are smaller and were not
+// short of registers before).  Same operations either way: same bits.
+constexpr bool inline_sincos(int method) { return method == 3 || method == 4 || method == 5 || method >= 9; }
+template <bool INL> __device__ __forceinline__ SinCos sincos_sel(double x) {
+    if constexpr (INL) return sincos_inline(x);
+    else return sincos_(x);
+}
 // np.arctan2 as the reference's numpy evaluates it (AVX512_SKX builds: Intel SVML's __svml_atan28_ha; not libm's atan2 in the
 // last bit for 7 % of arguments) -- same text as oracle/rt_oracle.c np_arctan2, see there; tools/check_np_atan2.py: 0
 // mismatches against np.arctan2 on 1.6e7 argument pairs.  Its reciprocal starts from the VRCP14PD instruction, which is a
@@ -248,11 +256,11 @@ __device__ __forceinline__ bool adv_curv(const Ray<double>& r, const Consts<doub
     }
     const double dc = curv * k.step;
     if (r.gx * r.uy - r.gy * r.ux > 0) {   // np.cross (:360)
-        const SinCos t = sincos_(r.th - dc);
+        const SinCos t = sincos_inline(r.th - dc);
         fx = r.x + (r.uy - t.s) / curv;                 // r.uy == sin(theta), r.ux == cos(theta): same function, same bits
         fy = r.y + (t.c - r.ux) / curv;
     } else {
-        const SinCos t = sincos_(r.th + dc);
+        const SinCos t = sincos_inline(r.th + dc);
         fx = r.x + (t.s - r.uy) / curv;
         fy = r.y + (-t.c + r.ux) / curv;
     }
@@ -260,9 +268,10 @@ __device__ __forceinline__ bool adv_curv(const Ray<double>& r, const Consts<doub
 }
 
 // ---------------------------------------------------------------- angle determination (:370-407)
+template <bool INL>
 __device__ __forceinline__ double ang_rk2(const Ray<double>& r, double step, double fn, double fgx, double fgy) {
     const double k1 = step * (r.ux * r.gy - r.uy * r.gx) / r.n;
-    const SinCos t = sincos_(r.th + k1);
+    const SinCos t = sincos_sel<INL>(r.th + k1);
     const double k2 = step * (t.c * fgy - t.s * fgx) / fn;
     return r.th + (k1 + k2) / 2.0;
 }
@@ -631,7 +640,7 @@ template <int METHOD>
 __device__ __forceinline__ double op_angle(const Consts<double>& k, const Ray<double>& r, bool flag, double fx, double fy,
                                            double fn, double fgx, double fgy, int i) {
     if constexpr (METHOD == 1 || METHOD == 8) return ex::ang_cost(r, k.step, fgx, fgy);
-    else if constexpr (METHOD == 2 || METHOD == 6) return ex::ang_rk2(r, k.step, fn, fgx, fgy);
+    else if constexpr (METHOD == 2 || METHOD == 6) return ex::ang_rk2<inline_sincos(METHOD)>(r, k.step, fn, fgx, fgy);
     else if constexpr (METHOD == 7) {
         // finite_diff (:370-372) over [P0, P1, P2, P3] = [h0, h1, (x, y), f], left to right like the reference; rows 1 and 2
         // use the first- and second-order backward differences (:843, :856)
@@ -641,7 +650,7 @@ __device__ __forceinline__ double op_angle(const Consts<double>& k, const Ray<do
         else { vx = 11.0 * fx - 18.0 * r.x + 9.0 * r.hx1 - 2.0 * r.hx0; vy = 11.0 * fy - 18.0 * r.y + 9.0 * r.hy1 - 2.0 * r.hy0; }
         return atan2_(vy, vx);
     }
-    else if constexpr (METHOD == 3) return flag ? ex::ang_rk2(r, k.step, fn, fgx, fgy) : r.th;
+    else if constexpr (METHOD == 3) return flag ? ex::ang_rk2<inline_sincos(METHOD)>(r, k.step, fn, fgx, fgy) : r.th;
     else if constexpr (METHOD == 4) return flag ? ex::ang_cost(r, k.step, fgx, fgy) : r.th;
     else if constexpr (METHOD == 5) return flag ? ex::ang_golden_iso(r, k.step, fn, fgx, fgy) : r.th;
     else if constexpr (METHOD == 9) return ex::ang_golden_iso(r, k.step, fn, fgx, fgy);
@@ -650,12 +659,13 @@ __device__ __forceinline__ double op_angle(const Consts<double>& k, const Ray<do
 }
 
 // store_update_results (:783-790) + the row bookkeeping of the loop body (:871-875)
+template <bool INL>
 __device__ __forceinline__ void store_update(const Consts<double>& k, Ray<double>& r, double fx, double fy, double fth,
                                              double fn, double fgx, double fgy) {
     const double dist = norm2(r.x - fx, r.y - fy);
     r.dsim += dist;
     r.dreal += k.step;
-    const SinCos u = sincos_(fth);
+    const SinCos u = sincos_sel<INL>(fth);
     const double c = u.c, s = u.s;
     const double coef = aniso(s, c, k.gamma);
     moments(fn, coef, k.g2m1, c, s, r.mx, r.my);
@@ -684,7 +694,7 @@ __device__ __forceinline__ bool ray_step(const FieldDev<double>& F, const Consts
     const bool flag = ex::op_advance<METHOD>(k, r, fx, fy);
     ex::n_gradient(F, gather, active, fx, fy, fn, fgx, fgy);
     const double fth = ex::op_angle<METHOD>(k, r, flag, fx, fy, fn, fgx, fgy, i);
-    ex::store_update(k, r, fx, fy, fth, fn, fgx, fgy);
+    ex::store_update<inline_sincos(METHOD)>(k, r, fx, fy, fth, fn, fgx, fgy);
     return (METHOD == 7 && i <= 2) || !outside(k, r);     // no boundary test in op7's bootstrap rows
 }
 

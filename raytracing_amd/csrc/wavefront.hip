@@ -3,16 +3,20 @@
 // :987-1003) are sorted by y (np.argsort, :1016), scipy's PchipInterpolator x(y) is built through them (:1020), and its
 // derivative at the points (:1021-1022), the tangent / normal angles (:1025-1026), |ray angle - normal angle| (:1032) and
 // the interpolant on nfine equally spaced y (:1043-1044) are evaluated.  One lane per point; the sort is rocPRIM's radix
-// sort through hipCUB (library code: this stage is a consumer of the hot path, not part of it).
+// sort through hipCUB (library code: this stage is a consumer of the hot path, not part of it).  Every traveltime of a call is
+// handled in one pass -- the reference's animation (:1066-1102) re-does the whole extraction per frame, 45 times.
 // Third-party arithmetic restated: scipy.interpolate.PchipInterpolator (scipy 1.15.3 in the build image):
 // _find_derivatives (Fritsch-Butland weighted harmonic mean, three-point end rule), CubicHermiteSpline's power-basis
 // coefficients, PPoly's Horner evaluation and .derivative().
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
+#include <vector>
 
 #include "../../include/rtmi.h"
 #include "rtmi_internal.h"
@@ -43,33 +47,46 @@ __device__ double pchip_deriv(const double* t, const double* v, long j, long n) 
     return 1.0 / ((w1 / ma + w2 / mb) / (w1 + w2));
 }
 
-// keys for the sort: y of the rays that reach this traveltime, +inf for the others (they sort last); counts the valid ones
+// All the kernels below work on a CHUNK of traveltimes at once (blockIdx.y = traveltime within the chunk): the reference's movie
+// path (RT_bench.py:1066-1102) asks for 45 wavefronts of one trajectory set, frame after frame; here they are one pass.
+// keys for the sort: y of the rays that reach the traveltime, +inf for the others (they sort last); counts the valid ones.
+// vals: the item's index t*R + k.
 __global__ void k_keys(const double* iso, long R, double* keys, int* vals, unsigned long long* count) {
-    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= R) return;
-    const double y = iso[R + k];                 // iso: [3][R] = x, y, theta of one traveltime
-    const bool ok = y == y;
-    keys[k] = ok ? y : HUGE_VAL;
-    vals[k] = (int)k;
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    bool ok = false;
+    if (k < R) {
+        const double y = iso[((size_t)t * 3 + 1) * R + k];                 // iso: [nt][3][R] = x, y, theta per traveltime
+        ok = y == y;
+        keys[(size_t)t * R + k] = ok ? y : HUGE_VAL;
+        vals[(size_t)t * R + k] = (int)(t * R + k);
+    }
     const unsigned long long m = __ballot(ok);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, (unsigned long long)__popcll(m));
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(count + t, (unsigned long long)__popcll(m));
 }
-// sorted order -> ys, xs, angle, ray index rows of `nodes` ([7][R]); NaN beyond the valid count
-__global__ void k_gather(const double* iso, long R, const int* order, const unsigned long long* count, double* nodes) {
+// second sort key: the traveltime an item belongs to (a stable sort on it regroups the y-sorted items per traveltime)
+__global__ void k_frame_keys(const int* vals, long R, long n, unsigned* fk) {
     const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < n) fk[j] = (unsigned)(vals[j] / R);
+}
+// sorted order -> ys, xs, angle, ray index rows of `nodes` ([nt][7][R]); NaN beyond the valid count
+__global__ void k_gather(const double* iso, long R, const int* order, const unsigned long long* count, double* nodes) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
     if (j >= R) return;
-    const bool ok = (unsigned long long)j < *count;
-    const int k = order[j];
-    nodes[j] = ok ? iso[R + k] : NAN;            // y
-    nodes[R + j] = ok ? iso[k] : NAN;            // x
-    nodes[2 * R + j] = ok ? iso[2 * R + k] : NAN;   // ray angle
-    nodes[6 * R + j] = ok ? (double)k : NAN;     // ray index (caller's order)
+    const bool ok = (unsigned long long)j < count[t];
+    const long k = (long)order[(size_t)t * R + j] - t * R;
+    const double* it = iso + (size_t)t * 3 * R;
+    double* nd = nodes + (size_t)t * 7 * R;
+    nd[j] = ok ? it[R + k] : NAN;                // y
+    nd[R + j] = ok ? it[k] : NAN;                // x
+    nd[2 * R + j] = ok ? it[2 * R + k] : NAN;    // ray angle
+    nd[6 * R + j] = ok ? (double)k : NAN;        // ray index (caller's order)
 }
 // derivative of the interpolant at its own points, angles (:1021-1026, :1032)
-__global__ void k_nodes(long R, const unsigned long long* count, double* nodes, double* deriv) {
-    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long n = (long)*count;
+__global__ void k_nodes(long R, const unsigned long long* count, double* nodes_all, double* deriv_all) {
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x, t = blockIdx.y;
+    const long n = (long)count[t];
     if (j >= R) return;
+    double* nodes = nodes_all + (size_t)t * 7 * R;
     double d = NAN, slope = NAN, normal = NAN, diff = NAN;
     if (j < n && n >= 2) {
         const double *y = nodes, *x = nodes + R;
@@ -88,16 +105,20 @@ __global__ void k_nodes(long R, const unsigned long long* count, double* nodes, 
         normal = tangent - M_PI / 2;                          // (:1026)
         diff = fabs(nodes[2 * R + j] - normal);               // (:1032) with the ray angle of the SAME sorted point
     }
-    deriv[j] = d;
+    deriv_all[(size_t)t * R + j] = d;
     nodes[3 * R + j] = slope;
     nodes[4 * R + j] = normal;
     nodes[5 * R + j] = diff;
 }
-// the interpolant on nfine equally spaced y between the first and the last point (:1043-1044)
-__global__ void k_fine(long R, const unsigned long long* count, const double* nodes, const double* deriv, int nfine, double* fine) {
+// the interpolant on nfine equally spaced y between the first and the last point (:1043-1044, :1096-1097)
+__global__ void k_fine(long R, const unsigned long long* count, const double* nodes_all, const double* deriv_all, int nfine, double* fine_all) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    const long t = blockIdx.y;
     if (q >= nfine) return;
-    const long n = (long)*count;
+    const long n = (long)count[t];
+    const double* nodes = nodes_all + (size_t)t * 7 * R;
+    const double* deriv = deriv_all + (size_t)t * R;
+    double* fine = fine_all + (size_t)t * 2 * nfine;
     double xf = NAN, yf = NAN;
     if (n >= 2) {
         const double *y = nodes, *x = nodes + R;
@@ -135,38 +156,66 @@ extern "C" __attribute__((visibility("default"))) int rtmi_wavefronts(rtmi_batch
     hipStream_t st = nullptr;
     int rc = rtmi_internal_isochrones_device(b, ntimes, times, &iso, &R, (void**)&st);
     if (rc) return rc;
+    // Traveltimes are processed in chunks of `tc` (all of them, unless that needs more than ~1 GB of work arrays: 92 bytes per
+    // point): per chunk ONE stable radix sort of every point by y, one more by the traveltime it belongs to (which regroups the
+    // y-sorted points per wavefront: each has exactly R of them, the rays that do not reach it at the end with y = +inf), the
+    // PCHIP stage for all wavefronts at once, one copy to the host.
+    const size_t Rz = (size_t)R;
+    int tc = (int)std::max<size_t>(1, std::min<size_t>((size_t)ntimes, ((size_t)1 << 30) / (92 * Rz)));
+    if (const char* e = getenv("RTMI_WF_CHUNK")) tc = std::max(1, std::min((int)ntimes, atoi(e)));   // tests: force several chunks
+    while ((size_t)tc * Rz >= ((size_t)1 << 31)) tc /= 2;              // item indices are 32-bit
+    const size_t N = (size_t)tc * Rz;
     double *keys = nullptr, *keys2 = nullptr, *dn = nullptr, *dd = nullptr, *df = nullptr;
     int *vals = nullptr, *vals2 = nullptr;
+    unsigned *fk = nullptr, *fk2 = nullptr;
     unsigned long long* dcount = nullptr;
+    std::vector<unsigned long long> hcount;
     void* tmp = nullptr;
-    size_t tmp_bytes = 0;
-    const size_t Rz = (size_t)R;
-    const dim3 blk(256), grd((unsigned)((Rz + 255) / 256));
-    WF_TRY(hipMalloc(&keys, Rz * 8)); WF_TRY(hipMalloc(&keys2, Rz * 8));
-    WF_TRY(hipMalloc(&vals, Rz * 4)); WF_TRY(hipMalloc(&vals2, Rz * 4));
-    WF_TRY(hipMalloc(&dn, 7 * Rz * 8)); WF_TRY(hipMalloc(&dd, Rz * 8));
-    WF_TRY(hipMalloc(&dcount, 8));
-    if (nfine) WF_TRY(hipMalloc(&df, 2 * (size_t)nfine * 8));
-    WF_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (int)R, 0, 64, st));
-    WF_TRY(hipMalloc(&tmp, tmp_bytes));
-    for (int it = 0; it < ntimes; it++) {
-        const double* iso_t = iso + (size_t)it * 3 * Rz;
-        WF_TRY(hipMemsetAsync(dcount, 0, 8, st));
-        hipLaunchKernelGGL(k_keys, grd, blk, 0, st, iso_t, R, keys, vals, dcount);
-        WF_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (int)R, 0, 64, st));
-        hipLaunchKernelGGL(k_gather, grd, blk, 0, st, iso_t, R, vals2, dcount, dn);
+    size_t tmp1 = 0, tmp2 = 0;
+    const dim3 blk(256);
+    int fbits = 1;
+    while ((1 << fbits) < tc) fbits++;
+    try {
+        hcount.resize((size_t)tc);
+    } catch (const std::exception&) {
+        rc = rtmi_internal_fail(RTMI_ERR_ALLOC, "rtmi_wavefronts: host allocation failed");
+        goto done;
+    }
+    WF_TRY(hipMalloc(&keys, N * 8)); WF_TRY(hipMalloc(&keys2, N * 8));
+    WF_TRY(hipMalloc(&vals, N * 4)); WF_TRY(hipMalloc(&vals2, N * 4));
+    WF_TRY(hipMalloc(&fk, N * 4)); WF_TRY(hipMalloc(&fk2, N * 4));
+    WF_TRY(hipMalloc(&dn, 7 * N * 8)); WF_TRY(hipMalloc(&dd, N * 8));
+    WF_TRY(hipMalloc(&dcount, (size_t)tc * 8));
+    if (nfine) WF_TRY(hipMalloc(&df, (size_t)tc * 2 * (size_t)nfine * 8));
+    WF_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp1, keys, keys2, vals, vals2, (int)N, 0, 64, st));
+    WF_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp2, fk, fk2, vals2, vals, (int)N, 0, fbits, st));
+    WF_TRY(hipMalloc(&tmp, std::max(tmp1, tmp2)));
+    for (int t0 = 0; t0 < ntimes; t0 += tc) {
+        const int nt = std::min(tc, ntimes - t0);
+        const size_t n = (size_t)nt * Rz;
+        const double* iso_c = iso + (size_t)t0 * 3 * Rz;
+        const dim3 grd((unsigned)((Rz + 255) / 256), (unsigned)nt);
+        WF_TRY(hipMemsetAsync(dcount, 0, (size_t)nt * 8, st));
+        hipLaunchKernelGGL(k_keys, grd, blk, 0, st, iso_c, R, keys, vals, dcount);
+        WF_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp1, keys, keys2, vals, vals2, (int)n, 0, 64, st));           // every point by y
+        if (nt > 1) {
+            hipLaunchKernelGGL(k_frame_keys, dim3((unsigned)((n + 255) / 256)), blk, 0, st, vals2, R, (long)n, fk);
+            WF_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp2, fk, fk2, vals2, vals, (int)n, 0, fbits, st));          // stable: regrouped per traveltime
+        }
+        const int* order = nt > 1 ? vals : vals2;
+        hipLaunchKernelGGL(k_gather, grd, blk, 0, st, iso_c, R, order, dcount, dn);
         hipLaunchKernelGGL(k_nodes, grd, blk, 0, st, R, dcount, dn, dd);
-        if (nfine) hipLaunchKernelGGL(k_fine, dim3((nfine + 255) / 256), blk, 0, st, R, dcount, dn, dd, (int)nfine, df);
+        if (nfine) hipLaunchKernelGGL(k_fine, dim3((nfine + 255) / 256, (unsigned)nt), blk, 0, st, R, dcount, dn, dd, (int)nfine, df);
         WF_TRY(hipGetLastError());
-        unsigned long long c = 0;
-        WF_TRY(hipMemcpyAsync(&c, dcount, 8, hipMemcpyDeviceToHost, st));
-        WF_TRY(hipMemcpyAsync(nodes + (size_t)it * 7 * Rz, dn, 7 * Rz * 8, hipMemcpyDeviceToHost, st));
-        if (nfine) WF_TRY(hipMemcpyAsync(fine + (size_t)it * 2 * nfine, df, 2 * (size_t)nfine * 8, hipMemcpyDeviceToHost, st));
+        WF_TRY(hipMemcpyAsync(hcount.data(), dcount, (size_t)nt * 8, hipMemcpyDeviceToHost, st));
+        WF_TRY(hipMemcpyAsync(nodes + (size_t)t0 * 7 * Rz, dn, 7 * n * 8, hipMemcpyDeviceToHost, st));
+        if (nfine) WF_TRY(hipMemcpyAsync(fine + (size_t)t0 * 2 * nfine, df, (size_t)nt * 2 * (size_t)nfine * 8, hipMemcpyDeviceToHost, st));
         WF_TRY(hipStreamSynchronize(st));
-        count[it] = (int64_t)c;
+        for (int i = 0; i < nt; i++) count[t0 + i] = (int64_t)hcount[i];
     }
 done:
     (void)hipFree(iso); (void)hipFree(keys); (void)hipFree(keys2); (void)hipFree(vals); (void)hipFree(vals2);
+    (void)hipFree(fk); (void)hipFree(fk2);
     (void)hipFree(dn); (void)hipFree(dd); (void)hipFree(df); (void)hipFree(dcount); (void)hipFree(tmp);
     return rc;
 }

@@ -1232,6 +1232,45 @@ def test_wavefronts_vs_scipy_on_reference_trajectories(fixture, m, gam, rb, gpu_
     assert seen >= 8
 
 
+def test_wavefronts_movie_frames_in_one_call(rb, gpu_fields, monkeypatch):
+    """The reference's animation (RT_bench.py:1066-1102): 45 frames, travel_time = 0.01 + 0.01 frame, per frame the isochrone
+    points sorted by y, PchipInterpolator x(y), 100 points of the curve.  One rtmi_wavefronts call makes all 45 (one sort of all
+    points, regrouped per frame); compared with scipy doing what the reference's update(frame) does on the same isochrone
+    points, with one call per frame, and with the chunked pass (RTMI_WF_CHUNK) -- the same numbers each way."""
+    from scipy.interpolate import PchipInterpolator
+    g = golden("wavefronts_vert_op6")
+    b = rb.Batch(gpu_fields("vert_heterogeneous"), 6, float(g["step"]), int(g["max_size"]), g["box"], 1, g["theta"], -2.0, -2.0,
+                 record_stride=1)
+    b.run()
+    times = 0.01 + 0.01 * np.arange(45)
+    wf = b.wavefronts(times)
+    iso = b.isochrones(times)
+    single = [b.wavefronts([t])[0] for t in times[::7]]
+    monkeypatch.setenv("RTMI_WF_CHUNK", "7")
+    chunked = b.wavefronts(times)
+    monkeypatch.delenv("RTMI_WF_CHUNK")
+    b.close()
+    assert len(wf) == 45
+    drawn = 0
+    for it, w in enumerate(wf):
+        ok = ~np.isnan(iso[it, 0])
+        assert w["count"] == ok.sum()
+        for key in ("y", "x", "dxdy", "normal", "angle_diff", "x_fine", "y_fine", "ray"):
+            assert np.array_equal(w[key], chunked[it][key], equal_nan=True), (it, key)
+        if it % 7 == 0:
+            for key in ("y", "x", "dxdy", "x_fine", "y_fine", "ray"):
+                assert np.array_equal(w[key], single[it // 7][key], equal_nan=True), (it, key)
+        if w["count"] < 2:
+            continue
+        xy = np.stack((iso[it, 0, ok], iso[it, 1, ok]), 1)                  # valid_ray_coord (:1082)
+        srt = xy[np.argsort(xy[:, 1])]                                       # (:1092-1093)
+        y_fine = np.linspace(srt[:, 1].min(), srt[:, 1].max(), 100)          # (:1096)
+        x_fine = PchipInterpolator(srt[:, 1], srt[:, 0])(y_fine)             # (:1094, :1097)
+        assert np.abs(w["y_fine"] - y_fine).max() < 1e-13 and np.abs(w["x_fine"] - x_fine).max() < 1e-10, it
+        drawn += 1
+    assert drawn >= 40
+
+
 def test_wavefronts_large_fan_properties(rb, gpu_fields):
     """The same stage on a 65 536-ray fan with the rays in shuffled order (the sort has real work to do): y strictly
     increasing, ray indices a permutation of the rays that reach the traveltime, rays normal to the wavefront."""
