@@ -128,13 +128,15 @@ typedef struct {
     int32_t slice_steps;     /* time-sliced schedule: DELTA_S steps per time slice of a bundle (0 -> 512); a bundle's first two
                                 slices are 4 and 2 times as long */
     int32_t reference_order; /* rtmi_order.  RTMI_ORDER_DEFAULT (0): op1/2/6/8 step in fused forms (~1e-13 from the reference per
-                                trajectory); op7 -- whose new angle differentiates positions, so that last-bit differences of a
-                                fused update walk 8e-9 away from the reference on the interface scenario -- steps in the
-                                reference's own operation order, like op3/4/5/9/10/11 always do.  RTMI_ORDER_REFERENCE (1, fp64
-                                only): op1/2/6/8 too: all give the oracle's bits (the reference's, within 1 ulp where numpy's
-                                scalar pow(x, 2) is not x*x; numpy's arctan2 = SVML's is restated for op1/7/8) at a quarter to a
-                                third of the speed.  RTMI_ORDER_FUSED (2): fused forms wherever there is one, op7 included
-                                (3.4 times faster than its default; fp32 batches always run fused forms) */
+                                trajectory).  op7's new angle differentiates POSITIONS (:370-372), so their last bits matter: it takes
+                                the reference-order step -- the advancement's operation order, numpy's arctan2, glibc's sin / cos --
+                                on the fused field lookup (n and grad n reach a position only through a 1e-6 term): <= 4e-11 from the
+                                reference on every scenario, 1.5 times the fused cost.  RTMI_ORDER_REFERENCE (1, fp64 only):
+                                op1/2/6/7/8 in the reference's operation order throughout, field lookup included, like
+                                op3/4/5/9/10/11 always are: the oracle's bits (the reference's, within 1 ulp where numpy's scalar
+                                pow(x, 2) is not x*x), at a quarter to a third of the fused speed.  RTMI_ORDER_FUSED (2): fused forms
+                                wherever there is one, op7 too (up to 8e-9 from the reference on the interface scenario); fp32
+                                batches always run fused forms */
 } rtmi_params;
 
 /* Upload R launch conditions (host pointers; x0/y0 per ray -- pos_x[k], -2 or the fisheye start, :809-813),

@@ -692,7 +692,8 @@ __device__ __forceinline__ bool ray_step(const FieldDev<double>& F, const Consts
                                          Ray<double>& r, int i) {
     double fx, fy, fn, fgx, fgy;
     const bool flag = ex::op_advance<METHOD>(k, r, fx, fy);
-    ex::n_gradient(F, gather, active, fx, fy, fn, fgx, fgy);
+    if constexpr (IsPoly<G>::value) rt::n_gradient(F, gather, active, fx, fy, fn, fgx, fgy);   // kFastField: the cell's polynomial
+    else ex::n_gradient(F, gather, active, fx, fy, fn, fgx, fgy);
     const double fth = ex::op_angle<METHOD>(k, r, flag, fx, fy, fn, fgx, fgy, i);
     ex::store_update<inline_sincos(METHOD)>(k, r, fx, fy, fth, fn, fgx, fgy);
     return (METHOD == 7 && i <= 2) || !outside(k, r);     // no boundary test in op7's bootstrap rows

@@ -101,6 +101,9 @@ static double libm_square(double x) {
 static bool ref_order(const rtmi_params& p) {
     return p.dtype == RTMI_F64 && (p.reference_order == RTMI_ORDER_REFERENCE || (p.method == 7 && p.reference_order == RTMI_ORDER_DEFAULT));
 }
+// ... and op7's default takes that step on the FAST field lookup (rt::kFastField, rt_device.h: the positions still round like the
+// reference's but for an ulp's shift once in 1e4 .. 1e6 steps): 1e-13 from the reference instead of its bits, 1.5 times faster.
+static bool fast_field_order(const rtmi_params& p) { return p.dtype == RTMI_F64 && p.method == 7 && p.reference_order == RTMI_ORDER_DEFAULT; }
 
 // ------------------------------------------------------------------ handles
 struct rtmi_field {
@@ -844,7 +847,7 @@ template <typename T> __device__ __forceinline__ void idle_ray(const BatchDev<T>
 // Gather policy of a step kernel.  Reference-order methods (rt_exact.h: FITPACK's sums on the B-spline window): the LDS tile
 // (LDS) or global gathers.  Fast-form methods and every fp32 batch: the cell's polynomial (rt::PolyGather), through the scalar
 // cache for a coherent wave (LDS) or with per-lane loads.  RTMI_POLY 0 builds the fast forms on the B-spline window as well.
-template <typename T, int METHOD> constexpr bool uses_poly() { return RTMI_POLY && !rt::IsExact<T, METHOD>::value; }
+template <typename T, int METHOD> constexpr bool uses_poly() { return RTMI_POLY && (!rt::IsExact<T, METHOD>::value || (METHOD & rt::kFastField) != 0); }
 template <typename T, int METHOD, bool LDS> constexpr bool uses_tile() { return LDS && !uses_poly<T, METHOD>(); }
 template <typename T, int METHOD, bool LDS, int PH = RTMI_TILE_PHASES, bool POLY = uses_poly<T, METHOD>()> struct GatherOf { using type = rt::GlobalGather<T>; };
 template <typename T, int METHOD, int PH> struct GatherOf<T, METHOD, true, PH, false> { using type = rt::LdsGather<T, PH>; };
@@ -1405,10 +1408,14 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
 // kernel variant tables: [kernel method][iso][lds].  Kernel methods: the step methods 1..11, then op1/2/6/7/8 in the reference's
 // operation order (METHOD = method | rt::kRefOrder, fp64 only: the fp32 tables alias the ordinary builds there).
 // Anisotropic-only methods (op10/op11) have no ISO build.
-constexpr int kKernelMethods = 16;
-constexpr int kmethod_of(int idx) { return idx < 11 ? idx + 1 : (idx == 11 ? 1 : idx == 12 ? 2 : idx == 13 ? 6 : idx == 14 ? 7 : 8) | rt::kRefOrder; }
-static int kernel_index(int method, bool ref_order) {
+// Index 16: op7's default -- the reference-order step on the fast field lookup (rt::kFastField).
+constexpr int kKernelMethods = 17;
+constexpr int kmethod_of(int idx) {
+    return idx < 11 ? idx + 1 : idx == 16 ? (7 | rt::kRefOrder | rt::kFastField) : (idx == 11 ? 1 : idx == 12 ? 2 : idx == 13 ? 6 : idx == 14 ? 7 : 8) | rt::kRefOrder;
+}
+static int kernel_index(int method, bool ref_order, bool fast_field) {
     if (!ref_order || rt::is_exact_method(method)) return method - 1;
+    if (fast_field) return 16;
     return method == 1 ? 11 : method == 2 ? 12 : method == 6 ? 13 : method == 7 ? 14 : 15;
 }
 template <typename T> constexpr int km(int idx) { return sizeof(T) == 4 ? rt::base_method(kmethod_of(idx)) : kmethod_of(idx); }
@@ -1424,7 +1431,7 @@ constexpr bool iso_ok(int m) { return rt::base_method(m) < 10; }
 #define RTMI_SLICED_(T, I) \
     {{(const void*)k_advance_sliced<T, km<T>(I), false, false>, (const void*)k_advance_sliced<T, km<T>(I), false, true>}, \
      {(const void*)k_advance_sliced<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), false>, (const void*)k_advance_sliced<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), true>}}
-#define RTMI_ALL16_(X, T) X(T, 0), X(T, 1), X(T, 2), X(T, 3), X(T, 4), X(T, 5), X(T, 6), X(T, 7), X(T, 8), X(T, 9), X(T, 10), X(T, 11), X(T, 12), X(T, 13), X(T, 14), X(T, 15)
+#define RTMI_ALL16_(X, T) X(T, 0), X(T, 1), X(T, 2), X(T, 3), X(T, 4), X(T, 5), X(T, 6), X(T, 7), X(T, 8), X(T, 9), X(T, 10), X(T, 11), X(T, 12), X(T, 13), X(T, 14), X(T, 15), X(T, 16)
 template <typename T> static const void* sliced_fn(int ki, bool iso, bool lds) {
     static const void* const tab[kKernelMethods][2][2] = {RTMI_ALL16_(RTMI_SLICED_, T)};
     return tab[ki][iso ? 1 : 0][lds ? 1 : 0];
@@ -1477,7 +1484,7 @@ static int ensure_rcp14_table(hipStream_t st) {
 }
 // the fp64 batch runs rt_exact.h's arithmetic: always for op3/4/5/9/10/11, for the others when ref_order() says so
 static bool batch_exact(const rtmi_batch* b) { return b->p.dtype == RTMI_F64 && (rt::is_exact_method(b->p.method) || ref_order(b->p)); }
-static int batch_kernel_index(const rtmi_batch* b) { return kernel_index(b->p.method, ref_order(b->p)); }
+static int batch_kernel_index(const rtmi_batch* b) { return kernel_index(b->p.method, ref_order(b->p), fast_field_order(b->p)); }
 // field_path 0 (auto): which gather policy the step kernels are built with.
 static bool use_lds_tile(const rtmi_batch* b) {
     if (b->p.field_path == 1) return false;
@@ -1486,7 +1493,7 @@ static bool use_lds_tile(const rtmi_batch* b) {
     // per SIMD 12.5 vs 15.0 ms without recording and 19 vs 24 ms with the full record, op1/7/8 and fp32 by 0-2 %, a
     // shuffled fan 44 vs 50 ms; the reference-order fp64 methods (op3/4/5/9/10/11: 2-74 cost evaluations per step, more
     // live state) are 2-15 % faster on global gathers.
-    return !batch_exact(b);
+    return !batch_exact(b) || fast_field_order(b->p);
 }
 // rows can go out through the wave-uniform descriptor path: rays in lockstep (no rtmi_batch_set_state since the last
 // reset) and 6 quantities x R values within 31-bit byte offsets

@@ -2,11 +2,11 @@
 """Parity sweep on the GPU box: every step method on every scenario it applies to, device (librtmi through the C ABI) against
 the CPU oracle, on two batches each -- a fan of 4 096 rays from the scenario's launch point and 2 048 rays with random launch
 points and directions anywhere in the box.  One line per case: rays with identical step counts, largest relative difference
-of the final state and of every 64th recorded row (|a-b| / max(|b|, 1)), and for the reference-order methods whether the
-whole result is the oracle's bits.  The oracle itself is pinned to the reference by tests/test_oracle_golden.py (its "pow" build
+of the final state and of every 64th recorded row (bench.parity_relerr: per quantity, relative to that quantity's largest
+magnitude in the batch), and for the reference-order methods whether the whole result is the oracle's bits.  The oracle itself is pinned to the reference by tests/test_oracle_golden.py (its "pow" build
 reproduces all 31 reference trajectory fixtures bit for bit).  This is a checker run (tests/ material), not product code.
 
-  python3 tools/parity_sweep.py > profiles/r03_parity_sweep.txt
+  python3 tools/parity_sweep.py [--methods 7,9] > profiles/r04_parity_sweep.txt
 """
 import os
 import sys
@@ -17,6 +17,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracing_amd import rt_bench as rb          # noqa: E402
 from oracle import rt_oracle as O                   # noqa: E402
+from bench import parity_relerr                     # noqa: E402
 
 LIM = {"interface": (-2, 20, -2, 4), "fisheye": (-1.5, 1.5, -1.5, 1.5), "vert_heterogeneous": (-2, 5, -2.5, 1),
        "anisotropy": (-2, 5, -2.5, 1)}
@@ -24,16 +25,20 @@ EXACT = (3, 4, 5, 9, 10, 11)
 
 
 def rel(a, b):
-    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0))) if a.size else 0.0
+    return parity_relerr(a, b)
 
 
 def main():
+    only = None
+    if "--methods" in sys.argv:
+        only = {int(v) for v in sys.argv[sys.argv.index("--methods") + 1].split(",")}
     threads = min(O.max_threads(), os.cpu_count() or 1)
     rng = np.random.default_rng(2026)
     print(f"# device vs oracle ({threads} host threads); tolerance of the north star: 1e-9 relative, step counts exactly")
-    print("# op column: R = rtmi_params.reference_order (op1/2/6/7/8 in the reference's operation order too)")
+    print("# op column: R = rtmi_params.reference_order 1 (op1/2/6/7/8 in the reference's operation order too); F = 2 (op7 in its fused form;")
+    print("#            op7's default is the reference-order step on the fast field lookup)")
     print(f"{'scenario':19s} {'op':>4s} {'batch':7s} {'rays':>5s} {'ray-steps':>10s} {'same steps':>10s} {'final':>9s} {'rows/64':>9s} {'bits':>5s}")
-    worst = worst_exact = 0.0
+    worst = worst_exact = worst_fused7 = 0.0
     all_bits = True
     t0 = time.time()
     for scen in ("vert_heterogeneous", "fisheye", "interface", "anisotropy"):
@@ -52,12 +57,14 @@ def main():
         xr = rng.uniform(lim[0] + 0.05, lim[1] - 0.05, 2048); yr = rng.uniform(lim[2] + 0.05, lim[3] - 0.05, 2048)
         thr = rng.uniform(-np.pi, np.pi, 2048)
         for m in methods:
+            if only is not None and m not in only:
+                continue
             for tag, x0, y0, th, msz in (("fan", x0f, y0f, thf, ms), ("random", xr, yr, thr, 3000)):
                 R = len(th)
                 if m in (5, 9, 10, 11) and scen == "interface" and tag == "fan":
                     th, R = th[::4], len(th[::4])          # the golden-section methods on 30 000-row rays: keep the oracle's share short
                 o = O.trazar(OF, m, gam, step, msz, lim, x0, y0, th, record_stride=64, nthreads=threads)
-                for ref_order in ((False, True) if m in (1, 2, 6, 7, 8) else (False,)):
+                for ref_order in ((0, 1, 2) if m == 7 else (0, 1) if m in (1, 2, 6, 8) else (0,)):
                     b = rb.Batch(F, m, step, msz, lim, gam, th, x0, y0, record_stride=64, reference_order=ref_order)
                     b.run()
                     d, fin, rows = b.d_ray(), b.final(), b.rows()
@@ -66,17 +73,20 @@ def main():
                     ef = rel(fin[:, same], o["final"][:, same])
                     er = rel(rows[:, :, same], o["s_ray"][:, :, same])
                     bits = bool(np.array_equal(fin, o["final"]) and np.array_equal(rows, o["s_ray"]) and np.array_equal(d, o["d_ray"]))
-                    want_bits = m in EXACT or ref_order
-                    print(f"{scen:19s} {m:3d}{'R' if ref_order else ' '} {tag:7s} {R:5d} {int(d[2].sum()):10d} {int(same.sum()):10d} {ef:9.1e} {er:9.1e} "
+                    want_bits = m in EXACT or ref_order == 1
+                    print(f"{scen:19s} {m:3d}{' RF'[ref_order]} {tag:7s} {R:5d} {int(d[2].sum()):10d} {int(same.sum()):10d} {ef:9.1e} {er:9.1e} "
                           f"{'yes' if bits else ('NO' if want_bits else '-'):>5s}", flush=True)
                     if want_bits:
                         worst_exact = max(worst_exact, ef, er)
                         all_bits &= bits
+                    elif ref_order == 2:
+                        worst_fused7 = max(worst_fused7, ef, er)
                     else:
                         worst = max(worst, ef, er)
         F.close()
     print(f"# reference-order rows (op3/4/5/9/10/11 always, op1/2/6/7/8 with R): the oracle's bits in every case: {all_bits} "
-          f"(largest difference {worst_exact:.1e}); fused default of op1/2/6/7/8: largest difference {worst:.1e}; {time.time() - t0:.0f} s")
+          f"(largest difference {worst_exact:.1e}); default of op1/2/6/7/8: largest difference {worst:.1e}; op7 fused (F, opt-in): {worst_fused7:.1e}; "
+          f"{time.time() - t0:.0f} s")
 
 if __name__ == "__main__":
     main()
