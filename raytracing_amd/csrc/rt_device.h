@@ -15,6 +15,9 @@
 #ifndef RTMI_POLY_BATCH
 #define RTMI_POLY_BATCH 1     // scalar loads of a lookup: 0 row by row, 1 one spline + n then the other (measured best), 2 all at once (spills SGPRs)
 #endif
+#ifndef RTMI_FLAT_MAP
+#define RTMI_FLAT_MAP 1     // 0 compiles the flat-cell map's tests out of the lookups (A/B of what they cost a field without flat cells)
+#endif
 #ifndef RTMI_POLY
 #define RTMI_POLY 1     // 1: the fast-form step methods look the field up as one polynomial per cell (PolyGather); 0: B-spline sums
 #endif
@@ -703,8 +706,8 @@ template <typename T, int PHASES = RTMI_TILE_PHASES> struct LdsGather {
 // n_gradient(vector, grd, z) (:141-156): bilinear n, bicubic dn/dx and dn/dy at (x, y) -> (n, [gx, gy]).
 // `active` tells the gather policy whether this lane's lookup matters (idle lanes still execute it).
 template <typename G> struct IsPoly { static constexpr bool value = false; };
-template <typename T, int MODE> struct PolyGather;
-template <typename T, int MODE> struct IsPoly<PolyGather<T, MODE>> { static constexpr bool value = true; };
+template <typename T, int MODE, bool FLAT> struct PolyGather;
+template <typename T, int MODE, bool FLAT> struct IsPoly<PolyGather<T, MODE, FLAT>> { static constexpr bool value = true; };
 template <typename T, typename G>
 __device__ __forceinline__ void n_gradient(const FieldDev<T>& F, G& gather, bool active, T x, T y, T& n, T& gx, T& gy) {
     if constexpr (IsPoly<G>::value) {
@@ -844,7 +847,11 @@ template <typename T> __device__ __forceinline__ bool flat_uniform(const FieldDe
     c = __builtin_bit_cast(T, b);
     return flat_entry<T>(b);
 }
-template <typename T, int MODE> struct PolyGather {
+// FLAT false: built for fields WITHOUT flat cells (the host knows: rtmi_field::flat_cells) -- the map's tests are not even
+// compiled in.  Left in as run-time tests on a scalar they cost the fisheye fan 4.5 % and the vert fan 1.4 % (register allocation
+// of kernels that sit at their budget, not the two scalar instructions: profiles/r04_ab_flat_tests_cost.txt), so the two hot
+// kernels (k_advance and k_advance_sliced on the wave-shared path) exist in both forms and the host picks.
+template <typename T, int MODE, bool FLAT = true> struct PolyGather {
     static constexpr bool SCALAR = MODE == kPolyScalar;
     static constexpr bool CACHED = MODE == kPolyCached;
     static constexpr int NA = CACHED ? 9 : 1;     // rows held
@@ -880,7 +887,7 @@ template <typename T, int MODE> struct PolyGather {
     }
     // one lane, its own cell: the flat-cell rule first (a flat cell's coefficients are never read), else the polynomial
     static __device__ __forceinline__ void eval_lane(const FieldDev<T>& F, int cell, T u, T v, T& n, T& gx, T& gy) {
-        if (F.flat) {
+        if (RTMI_FLAT_MAP && FLAT && F.flat) {
             T cf;
             if (flat_lane(F, cell, cf)) { n = cf; gx = T(0); gy = T(0); return; }
         }
@@ -930,7 +937,7 @@ template <typename T, int MODE> struct PolyGather {
         n = poly_bilinear<T, 2>(rows[N == 9 ? 8 : 0], u, v);
     }
     template <int N> static __device__ __forceinline__ void load_rows(Quad<T> (&rows)[N], const FieldDev<T>& F, int cu) {
-        if (F.flat) {       // a flat cell is kept as the polynomial (b0, 0, ...): eval_rows then gives (b0, 0, 0) exactly
+        if (RTMI_FLAT_MAP && FLAT && F.flat) {       // a flat cell is kept as the polynomial (b0, 0, ...): eval_rows then gives (b0, 0, 0) exactly
             T cf;
             if (flat_uniform(F, cu, cf)) {
 #pragma unroll
@@ -972,7 +979,7 @@ template <typename T, int MODE> struct PolyGather {
             ScalarRows p = (ScalarRows)(F.poly + (size_t)cu * kPolyStride);
             asm volatile("" : "+s"(p));
             if ((rt_ballot(c.cell != cu) & live) == 0ull) {
-                if (F.flat) {
+                if (RTMI_FLAT_MAP && FLAT && F.flat) {
                     T cf;
                     if (flat_uniform(F, cu, cf)) { n = cf; gx = T(0); gy = T(0); return; }     // scalar branch: the map entry is wave-uniform
                 }
@@ -991,7 +998,7 @@ template <typename T, int MODE> struct PolyGather {
                     asm volatile("" : "+s"(p));
                     if (c.cell == cu) {
                         T cf;
-                        if (F.flat && flat_uniform(F, cu, cf)) { n = cf; gx = T(0); gy = T(0); }
+                        if (RTMI_FLAT_MAP && FLAT && F.flat && flat_uniform(F, cu, cf)) { n = cf; gx = T(0); gy = T(0); }
                         else eval_scalar(p, c.u, c.v, n, gx, gy);
                         todo = false;
                     }

@@ -849,13 +849,14 @@ template <typename T> __device__ __forceinline__ void idle_ray(const BatchDev<T>
 // cache for a coherent wave (LDS) or with per-lane loads.  RTMI_POLY 0 builds the fast forms on the B-spline window as well.
 template <typename T, int METHOD> constexpr bool uses_poly() { return RTMI_POLY && (!rt::IsExact<T, METHOD>::value || (METHOD & rt::kFastField) != 0); }
 template <typename T, int METHOD, bool LDS> constexpr bool uses_tile() { return LDS && !uses_poly<T, METHOD>(); }
-template <typename T, int METHOD, bool LDS, int PH = RTMI_TILE_PHASES, bool POLY = uses_poly<T, METHOD>()> struct GatherOf { using type = rt::GlobalGather<T>; };
-template <typename T, int METHOD, int PH> struct GatherOf<T, METHOD, true, PH, false> { using type = rt::LdsGather<T, PH>; };
-template <typename T, int METHOD, bool LDS, int PH> struct GatherOf<T, METHOD, LDS, PH, true> {
-    using type = rt::PolyGather<T, !LDS ? rt::kPolyLane : PH == 1 ? rt::kPolyCached : rt::kPolyScalar>;   // PH 1: k_advance_lat
+// NOFLAT: the field has no flat cell (rt::PolyGather's FLAT false: the flat-cell map's tests compiled out).
+template <typename T, int METHOD, bool LDS, int PH = RTMI_TILE_PHASES, bool NOFLAT = false, bool POLY = uses_poly<T, METHOD>()> struct GatherOf { using type = rt::GlobalGather<T>; };
+template <typename T, int METHOD, int PH, bool NOFLAT> struct GatherOf<T, METHOD, true, PH, NOFLAT, false> { using type = rt::LdsGather<T, PH>; };
+template <typename T, int METHOD, bool LDS, int PH, bool NOFLAT> struct GatherOf<T, METHOD, LDS, PH, NOFLAT, true> {
+    using type = rt::PolyGather<T, !LDS ? rt::kPolyLane : PH == 1 ? rt::kPolyCached : rt::kPolyScalar, !NOFLAT>;   // PH 1: k_advance_lat
 };
 template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::GlobalGather<T>&, T*) {}
-template <typename T, bool LDS, int MODE> __device__ __forceinline__ void gather_init(rt::PolyGather<T, MODE>& g, T*) { g.init(); }
+template <typename T, bool LDS, int MODE, bool FLAT> __device__ __forceinline__ void gather_init(rt::PolyGather<T, MODE, FLAT>& g, T*) { g.init(); }
 // LDS of a step kernel in units of T: the reference-order methods' tile; the polynomial lookup needs none.  (An L2 prefetch of
 // the cells ahead -- global_load_lds into a per-wave sink whenever the wave's cell changes -- was measured: interface 23.6 ->
 // 23.0 ms, but fisheye, a new cell every step, 8.3 -> 9.1, vert_heterogeneous 8.8 -> 9.0, fp32 48.7 -> 49.6: not kept.)
@@ -1028,7 +1029,7 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
     }
 }
 
-template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool COH = false, int PH = RTMI_TILE_PHASES>
+template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool COH = false, int PH = RTMI_TILE_PHASES, bool NOFLAT = false>
 __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, long blk, int nsteps);
 
 // Which 256-ray bundle a hardware block takes.  Blocks are dealt to the eight XCDs round-robin (block h runs on XCD h % 8,
@@ -1057,11 +1058,11 @@ __device__ __forceinline__ unsigned xcd_grouped_block(unsigned h, unsigned nbloc
 // row by row), the fp64 global-gather variants three (137-168 VGPRs, gathers in two halves); none of them spills.
 // Every lane runs every iteration until no lane of its wave is active; a ray's state is stored the moment it
 // terminates (or when the launch's step budget ends), so idle lanes never write.
-template <typename T, int METHOD, bool ISO, bool LDS, bool VAR>
+template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool NOFLAT = false>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? RTMI_F32_WAVES : LDS ? (light_method(METHOD) ? RTMI_TILE_WAVES : heavy_method(METHOD) ? 2 : 3) : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES))
 void k_advance(BatchDev<T> a, int nsteps) {
     __shared__ __attribute__((aligned(16))) T lds[kernel_lds_elems<T, METHOD, LDS>()];
-    advance_bundle<T, METHOD, ISO, LDS, VAR>(a, lds, (long)xcd_grouped_block(blockIdx.x, gridDim.x) * blockDim.x, nsteps);
+    advance_bundle<T, METHOD, ISO, LDS, VAR, false, RTMI_TILE_PHASES, NOFLAT>(a, lds, (long)xcd_grouped_block(blockIdx.x, gridDim.x) * blockDim.x, nsteps);
 }
 // The kernel built for FEW waves: a batch of <= 2 waves per SIMD (cfg2's 65 536 rays: one) has nothing to hide a step's
 // dependent chain behind -- 1 800 cycles per step at one wave per SIMD against 545 of issue -- so this build spends registers
@@ -1073,9 +1074,9 @@ __global__ __launch_bounds__(256, 2) void k_advance_lat(BatchDev<T> a, int nstep
     __shared__ __attribute__((aligned(16))) T lds[uses_tile<T, METHOD, true>() ? 4 * rt::LdsGather<T, 1>::ELEMS : 2];
     advance_bundle<T, METHOD, ISO, true, false, false, 1>(a, lds, (long)blockIdx.x * blockDim.x, nsteps);
 }
-template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool COH, int PH>
+template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool COH, int PH, bool NOFLAT>
 __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, long blk, int nsteps) {
-    typename GatherOf<T, METHOD, LDS, PH>::type gather;
+    typename GatherOf<T, METHOD, LDS, PH, NOFLAT>::type gather;
     gather_init<T, LDS>(gather, lds);
     const long k = blk + threadIdx.x;
     rt::Ray<T> r;
@@ -1129,7 +1130,7 @@ __device__ __forceinline__ unsigned long long realtime_ticks() { return __builti
 // coherence point, s_waitcnt vmcnt(0) and the block barrier; this keeps the optimizer from moving state accesses across the
 // entry load / entry store (s_waitcnt is not a memory operation to it, and the barrier's fence is workgroup scope).
 __device__ __forceinline__ void compiler_fence() { __atomic_signal_fence(__ATOMIC_SEQ_CST); }
-template <typename T, int METHOD, bool ISO, bool LDS>
+template <typename T, int METHOD, bool ISO, bool LDS, bool NOFLAT = false>
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? RTMI_F32_SLICED_WAVES : LDS ? (light_method(METHOD) ? RTMI_TILE_WAVES : heavy_method(METHOD) ? 2 : 3) : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES))
 void k_advance_sliced(BatchDev<T> a, int slice, unsigned long long capacity, unsigned long long* ctl, unsigned long long timeout_ticks) {
     __shared__ __attribute__((aligned(16))) T lds[kernel_lds_elems<T, METHOD, LDS>()];
@@ -1193,7 +1194,7 @@ void k_advance_sliced(BatchDev<T> a, int slice, unsigned long long capacity, uns
             const unsigned k = (unsigned)(e >> 32);           // slices this bundle has had
             const int nsteps = k == 0u ? 4 * slice : k == 1u ? 2 * slice : slice;
             compiler_fence();
-            const bool alive = advance_bundle<T, METHOD, ISO, LDS, false, true>(a, lds, bundle * 256, nsteps);
+            const bool alive = advance_bundle<T, METHOD, ISO, LDS, false, true, RTMI_TILE_PHASES, NOFLAT>(a, lds, bundle * 256, nsteps);
             compiler_fence();                                // no state store of the bundle moves below the entry store
             __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): this lane's state stores are acknowledged
             const int any = __builtin_amdgcn_readfirstlane(__syncthreads_or(alive));
@@ -1423,6 +1424,13 @@ constexpr bool iso_ok(int m) { return rt::base_method(m) < 10; }
 #define RTMI_ADV_(T, I) \
     {{(const void*)k_advance<T, km<T>(I), false, false, false>, (const void*)k_advance<T, km<T>(I), false, true, false>}, \
      {(const void*)k_advance<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), false, false>, (const void*)k_advance<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), true, false>}}
+// the wave-shared builds for a field without flat cells (NOFLAT; only the polynomial lookup has the map's tests): [kernel method][iso]
+#define RTMI_ADVNF_(T, I) \
+    {(const void*)k_advance<T, km<T>(I), false, true, false, uses_poly<T, km<T>(I)>()>, \
+     (const void*)k_advance<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), true, false, uses_poly<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1)>()>}
+#define RTMI_SLICEDNF_(T, I) \
+    {(const void*)k_advance_sliced<T, km<T>(I), false, true, uses_poly<T, km<T>(I)>()>, \
+     (const void*)k_advance_sliced<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), true, uses_poly<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1)>()>}
 #define RTMI_ADVVAR_(T, I) \
     {(const void*)k_advance<T, km<T>(I), false, false, true>, (const void*)k_advance<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), false, true>}
 #define RTMI_REFILL_(T, I) \
@@ -1432,13 +1440,15 @@ constexpr bool iso_ok(int m) { return rt::base_method(m) < 10; }
     {{(const void*)k_advance_sliced<T, km<T>(I), false, false>, (const void*)k_advance_sliced<T, km<T>(I), false, true>}, \
      {(const void*)k_advance_sliced<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), false>, (const void*)k_advance_sliced<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), true>}}
 #define RTMI_ALL16_(X, T) X(T, 0), X(T, 1), X(T, 2), X(T, 3), X(T, 4), X(T, 5), X(T, 6), X(T, 7), X(T, 8), X(T, 9), X(T, 10), X(T, 11), X(T, 12), X(T, 13), X(T, 14), X(T, 15), X(T, 16)
-template <typename T> static const void* sliced_fn(int ki, bool iso, bool lds) {
+template <typename T> static const void* sliced_fn(int ki, bool iso, bool lds, bool noflat) {
     static const void* const tab[kKernelMethods][2][2] = {RTMI_ALL16_(RTMI_SLICED_, T)};
-    return tab[ki][iso ? 1 : 0][lds ? 1 : 0];
+    static const void* const tabnf[kKernelMethods][2] = {RTMI_ALL16_(RTMI_SLICEDNF_, T)};
+    return lds && noflat ? tabnf[ki][iso ? 1 : 0] : tab[ki][iso ? 1 : 0][lds ? 1 : 0];
 }
-template <typename T> static const void* advance_fn(int ki, bool iso, bool lds) {
+template <typename T> static const void* advance_fn(int ki, bool iso, bool lds, bool noflat) {
     static const void* const tab[kKernelMethods][2][2] = {RTMI_ALL16_(RTMI_ADV_, T)};
-    return tab[ki][iso ? 1 : 0][lds ? 1 : 0];
+    static const void* const tabnf[kKernelMethods][2] = {RTMI_ALL16_(RTMI_ADVNF_, T)};
+    return lds && noflat ? tabnf[ki][iso ? 1 : 0] : tab[ki][iso ? 1 : 0][lds ? 1 : 0];
 }
 // per-ray DELTA_S / max_size builds (global gather only): [kernel method][iso]
 template <typename T> static const void* advance_var_fn(int ki, bool iso) {
@@ -1451,6 +1461,8 @@ template <typename T> static const void* refill_fn(int ki, bool iso, bool lds) {
 }
 #undef RTMI_SLICED_
 #undef RTMI_ADV_
+#undef RTMI_ADVNF_
+#undef RTMI_SLICEDNF_
 #undef RTMI_ADVVAR_
 #undef RTMI_REFILL_
 #undef RTMI_ALL16_
@@ -1515,7 +1527,8 @@ static const void* pick_advance(const rtmi_batch* b) {
     // the VAR build: per-ray DELTA_S / max_size when set, and per-lane row bookkeeping always
     if (b->vstep || !uniform_rows_ok(b))
         return b->p.dtype == RTMI_F64 ? advance_var_fn<double>(batch_kernel_index(b), iso) : advance_var_fn<float>(batch_kernel_index(b), iso);
-    return b->p.dtype == RTMI_F64 ? advance_fn<double>(batch_kernel_index(b), iso, lds) : advance_fn<float>(batch_kernel_index(b), iso, lds);
+    const bool noflat = b->field->flat_cells == 0;      // no flat cell in this field: the builds without the map's tests
+    return b->p.dtype == RTMI_F64 ? advance_fn<double>(batch_kernel_index(b), iso, lds, noflat) : advance_fn<float>(batch_kernel_index(b), iso, lds, noflat);
 }
 // queue entries beyond the implicit first NB: every bundle is pushed back once per slice it survives
 static unsigned long long sliced_capacity(const rtmi_batch* b, int slice) {
@@ -1542,7 +1555,8 @@ static unsigned long long sliced_timeout_ticks(const rtmi_batch* b, int slice) {
 static bool sliced_feasible(const rtmi_batch* b) { return sliced_capacity(b, sliced_steps(b)) <= (1ull << 25); }
 static const void* pick_sliced(const rtmi_batch* b) {
     const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
-    return b->p.dtype == RTMI_F64 ? sliced_fn<double>(batch_kernel_index(b), iso, lds) : sliced_fn<float>(batch_kernel_index(b), iso, lds);
+    const bool noflat = b->field->flat_cells == 0;
+    return b->p.dtype == RTMI_F64 ? sliced_fn<double>(batch_kernel_index(b), iso, lds, noflat) : sliced_fn<float>(batch_kernel_index(b), iso, lds, noflat);
 }
 static const void* pick_refill(const rtmi_batch* b) {
     const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
