@@ -62,6 +62,14 @@ def _worker(rank, world, port, tmp):
             ts = torch.cat((ts, torch.full((ts.shape[0], Rmax - ts.shape[1]), float("nan"), dtype=ts.dtype)), 1)
         gs = [torch.empty_like(ts) for _ in range(world)] if rank == 0 else None
         dist.gather(ts.contiguous(), gs, dst=0)
+        # --- the agreement before a collective (trazar_sharded: a failed rank must not leave the others in the gather) and the
+        #     slot-order -> caller's-order map of a sort_rays batch
+        assert rd.agree_ok(True) is True
+        assert rd.agree_ok(rank != 1) is False                              # rank 1 "failed": every rank learns it
+        perm = torch.tensor([2, 0, 3, 1], dtype=torch.int32)
+        slots = torch.arange(8.0).reshape(2, 4)                             # slot k holds the caller's ray perm[k]
+        assert torch.equal(rd._to_callers_order(slots, perm), torch.tensor([[1.0, 3.0, 0.0, 2.0], [5.0, 7.0, 4.0, 6.0]]))
+        assert rd._to_callers_order(slots, None) is slots
         if rank == 0:
             whole, wsteps = _trace(full)
             assert np.array_equal(rd.interleave(gs, R_TOTAL).numpy(), whole)        # strong split: same bits, ray order
