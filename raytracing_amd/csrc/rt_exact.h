@@ -48,7 +48,8 @@ __device__ __attribute__((noinline)) SinCos sincos_(double x) {
 // sin and cos of one angle, glibc's bits, INLINE for the two ranges a golden-section bracket point lies in (theta -+ h with
 // h <= 0.6: 2^-26 <= |x| < 0.855469, the table step on x itself, and |x| < 2.426265, through pi/2 - |x|); anything else
 // calls sincos_().  Same operations as gl::sin / gl::cos: same bits.  For exact_lt_iso below, which pays this twice per
-// undecided comparison -- twelve to thirteen times per step where the index is constant (see there).
+// undecided comparison -- thirteen times per step where the index is constant (see there) -- and for the step's own sin / cos
+// of the methods that gain from having them inline (sincos_sel, inline_sincos).
 __device__ __forceinline__ SinCos sincos_inline(double x) {
     const unsigned k = gl::hi_word_(x);
     SinCos r;
