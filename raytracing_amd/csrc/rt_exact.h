@@ -45,6 +45,29 @@ __device__ __attribute__((noinline)) SinCos sincos_(double x) {
     else sincos_k(x, &r.s, &r.c);
     return r;
 }
+// glibc's sin/cos table (3.5 KB) in LDS for the inline evaluations below: the reference-order kernels stream 18 KB of field
+// coefficients per wave-step through the vector L1, which keeps evicting the table's lines (52 of an interface x op9 step's
+// 86 vector-memory instructions are table reads).  Staged once per block by stage_sincos_tab() (rtmi.hip calls it at the top of
+// every kernel body that can reach sincos_inline); the out-of-line sincos_ / sin_ / cos_ keep reading the table in memory.
+#ifndef RTMI_LDS_SINCOS
+#define RTMI_LDS_SINCOS 1
+#endif
+__device__ __forceinline__ RT_LDS double* sincos_tab_lds() {
+    __shared__ double t[4 * RT_SINCOS_TAB_ENTRIES];
+    return (RT_LDS double*)t;
+}
+__device__ __forceinline__ void stage_sincos_tab() {       // every thread of the block
+#if RTMI_LDS_SINCOS
+    RT_LDS double* t = sincos_tab_lds();
+    for (int i = (int)threadIdx.x; i < 4 * RT_SINCOS_TAB_ENTRIES; i += (int)blockDim.x) t[i] = kSinCosTab[i];
+    __syncthreads();
+#endif
+}
+#if RTMI_LDS_SINCOS
+#define RT_EX_SINCOS_TAB ((const RT_LDS double*)sincos_tab_lds())
+#else
+#define RT_EX_SINCOS_TAB kSinCosTab
+#endif
 // sin and cos of one angle, glibc's bits, INLINE for the two ranges a golden-section bracket point lies in (theta -+ h with
 // h <= 0.6: 2^-26 <= |x| < 0.855469, the table step on x itself, and |x| < 2.426265, through pi/2 - |x|); anything else
 // calls sincos_().  Same operations as gl::sin / gl::cos: same bits.  For exact_lt_iso below, which pays this twice per
@@ -54,14 +77,14 @@ __device__ __forceinline__ SinCos sincos_inline(double x) {
     const unsigned k = gl::hi_word_(x);
     SinCos r;
     if (k - 0x3e500000u < 0x3feb6000u - 0x3e500000u) {
-        r.s = gl::table_sin(kSinCosTab, x, 0.0);
-        r.c = gl::table_cos(kSinCosTab, x, 0.0);
+        r.s = gl::table_sin(RT_EX_SINCOS_TAB, x, 0.0);
+        r.c = gl::table_cos(RT_EX_SINCOS_TAB, x, 0.0);
     } else if (k - 0x3feb6000u < 0x400368fdu - 0x3feb6000u) {
         const double y = gl::kHp0 - __builtin_fabs(x);
-        r.s = __builtin_copysign(gl::table_cos(kSinCosTab, y, gl::kHp1), x);
+        r.s = __builtin_copysign(gl::table_cos(RT_EX_SINCOS_TAB, y, gl::kHp1), x);
         const double a = y + gl::kHp1;
         const double da = (y - a) + gl::kHp1;
-        r.c = gl::table_sin(kSinCosTab, a, da);
+        r.c = gl::table_sin(RT_EX_SINCOS_TAB, a, da);
     } else {
         r = sincos_(x);
     }

@@ -72,13 +72,13 @@ RT_HD double taylor_sin(double a, double da) {
 }
 
 // sin(x + dx) for 0.126 <= |x| <= 0.86 (dx: low part, |dx| << ulp-scale of x); sign of x is restored at the end
-RT_HD double table_sin(const double* tab, double x, double dx) {
+template <typename TP> RT_HD double table_sin(TP tab, double x, double dx) {
     const double ax = __builtin_fabs(x);
     if (ax < 0.126) return taylor_sin(x, dx);
     if (x <= 0) dx = -dx;
     const double u = kBig + ax;
     const double r = ax - (u - kBig);
-    const double* e = tab + 4 * (int)(unsigned)bits_(u);
+    const TP e = tab + 4 * (int)(unsigned)bits_(u);
     const double xx = r * r;
     const double s = r + fma_(r * xx, fma_(xx, kSn5, kSn3), dx);
     const double c = fma_(r, dx, xx * fma_(xx, fma_(xx, kCs6, kCs4), kCs2));
@@ -90,12 +90,12 @@ RT_HD double table_sin(const double* tab, double x, double dx) {
 }
 
 // cos(x + dx), |x| <= 0.86
-RT_HD double table_cos(const double* tab, double x, double dx) {
+template <typename TP> RT_HD double table_cos(TP tab, double x, double dx) {
     const double ax = __builtin_fabs(x);
     if (x < 0) dx = -dx;
     const double u = kBig + ax;
     const double r = (ax - (u - kBig)) + dx;
-    const double* e = tab + 4 * (int)(unsigned)bits_(u);
+    const TP e = tab + 4 * (int)(unsigned)bits_(u);
     const double xx = r * r;
     const double s = fma_(r * xx, fma_(xx, kSn5, kSn3), r);
     const double c = xx * fma_(xx, fma_(xx, kCs6, kCs4), kCs2);
@@ -121,7 +121,7 @@ RT_HD int reduce(double x, double* a, double* da) {
     return (int)(unsigned)bits_(t) & 3;
 }
 
-RT_HD double by_quadrant(const double* tab, double a, double da, int n) {
+template <typename TP> RT_HD double by_quadrant(TP tab, double a, double da, int n) {
     const double r = (n & 1) ? table_cos(tab, a, da) : table_sin(tab, a, da);
     return (n & 2) ? -r : r;
 }
@@ -129,7 +129,7 @@ RT_HD double by_quadrant(const double* tab, double a, double da, int n) {
 // true when |x| is in the range the functions below reproduce (everything the path produces)
 RT_HD bool in_range(double x) { return hi_word_(x) < 0x419921FBu; }
 
-RT_HD double sin(const double* tab, double x) {
+template <typename TP> RT_HD double sin(TP tab, double x) {
     const unsigned k = hi_word_(x);
     if (k < 0x3e500000u) return x;
     if (k < 0x3feb6000u) return table_sin(tab, x, 0.0);
@@ -139,7 +139,7 @@ RT_HD double sin(const double* tab, double x) {
     return by_quadrant(tab, a, da, n);
 }
 
-RT_HD double cos(const double* tab, double x) {
+template <typename TP> RT_HD double cos(TP tab, double x) {
     const unsigned k = hi_word_(x);
     if (k < 0x3e400000u) return 1.0;
     if (k < 0x3feb6000u) return table_cos(tab, x, 0.0);

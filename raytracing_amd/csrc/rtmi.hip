@@ -1078,6 +1078,9 @@ template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool COH, int PH
 __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, long blk, int nsteps) {
     typename GatherOf<T, METHOD, LDS, PH, NOFLAT>::type gather;
     gather_init<T, LDS>(gather, lds);
+    if constexpr (rt::IsExact<T, METHOD>::value) {
+        if constexpr (rt::ex::inline_sincos(rt::base_method(METHOD))) rt::ex::stage_sincos_tab();   // glibc's table into LDS (rt_exact.h)
+    }
     const long k = blk + threadIdx.x;
     rt::Ray<T> r;
     int i = 0;
@@ -1228,6 +1231,9 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : light_method(METHOD) ? RT
     __shared__ __attribute__((aligned(16))) T lds[kernel_lds_elems<T, METHOD, LDS>()];
     typename GatherOf<T, METHOD, LDS>::type gather;
     gather_init<T, LDS>(gather, lds);
+    if constexpr (rt::IsExact<T, METHOD>::value) {
+        if constexpr (rt::ex::inline_sincos(rt::base_method(METHOD))) rt::ex::stage_sincos_tab();
+    }
     const bool RECORD = a.stride != 0;
     const unsigned lane = threadIdx.x & 63;
     rt::Ray<T> r;

@@ -887,6 +887,7 @@ def test_headline_bench_configuration_every_row_and_whole_record_checksum(rb, gp
     b.run()
     st = b.stats()
     assert st["launch_mode_used"] == "sliced" and st["ray_steps"] == 1937541698 and st["live_rays"] == 0
+    assert st["auto_fallbacks"] == 0                          # no time-sliced launch gave up a wait (rtmi_stats, ABI v6)
     s = b.device_tensors()["s_ray"]
     assert tuple(s.shape) == (rows, 6, R) and s.dtype == torch.float64
 
@@ -916,7 +917,7 @@ def test_headline_bench_configuration_every_row_and_whole_record_checksum(rb, gp
     assert np.array_equal(s[:, :, sub].cpu().numpy(), got)
     for _ in range(3):                                        # two more exploration runs, then the faster: same record again
         b.reset(); b.run()
-    assert b.stats()["launch_mode_used"] in ("sliced", "plain") and checksum() == c_sliced
+    assert b.stats()["launch_mode_used"] in ("sliced", "plain") and checksum() == c_sliced and b.stats()["auto_fallbacks"] == 0
     b.close()
 
 
