@@ -1079,7 +1079,7 @@ __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, lon
     typename GatherOf<T, METHOD, LDS, PH, NOFLAT>::type gather;
     gather_init<T, LDS>(gather, lds);
     if constexpr (rt::IsExact<T, METHOD>::value) {
-        if constexpr (rt::ex::inline_sincos(rt::base_method(METHOD))) rt::ex::stage_sincos_tab();   // glibc's table into LDS (rt_exact.h)
+        if constexpr (rt::ex::inline_sincos(rt::base_method(METHOD)) || (METHOD & rt::kFastField) != 0) rt::ex::stage_sincos_tab();   // glibc's table into LDS (rt_exact.h)
     }
     const long k = blk + threadIdx.x;
     rt::Ray<T> r;
@@ -1232,7 +1232,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : light_method(METHOD) ? RT
     typename GatherOf<T, METHOD, LDS>::type gather;
     gather_init<T, LDS>(gather, lds);
     if constexpr (rt::IsExact<T, METHOD>::value) {
-        if constexpr (rt::ex::inline_sincos(rt::base_method(METHOD))) rt::ex::stage_sincos_tab();
+        if constexpr (rt::ex::inline_sincos(rt::base_method(METHOD)) || (METHOD & rt::kFastField) != 0) rt::ex::stage_sincos_tab();
     }
     const bool RECORD = a.stride != 0;
     const unsigned lane = threadIdx.x & 63;

@@ -523,7 +523,7 @@ def test_lds_tile_equals_global_gather(scen, m, shuffle, mode, rb, gpu_fields):
         out.append((b.d_ray(), b.final(), b.rows(), b.stats()["lds_bytes"]))
         b.close()
     if m == 11:
-        assert out[0][3] > 4096 and out[1][3] <= 512    # the tile variant really carries the LDS tile
+        assert out[0][3] > 16384 and out[1][3] <= 4096  # the tile variant really carries the LDS tile (the other: glibc's 3.5 KB sin/cos table)
     for u, v in zip(out[0][:3], out[1][:3]):
         assert np.array_equal(u, v)
 
