@@ -24,6 +24,28 @@ def test_launcher_command_forwards_every_argument():
     assert bench.free_port() > 0
 
 
+def test_run_ranks_forwards_rank0s_line_and_the_exit_status(monkeypatch, capsys, tmp_path):
+    """run_ranks with the child replaced by a stand-in that behaves like N ranks: chatter on stdout and stderr, ONE JSON line
+    from "rank 0", an exit status -- the parent's stdout must carry exactly that line and its return value the status."""
+    child = tmp_path / "child.py"
+    child.write_text('import sys\n'
+                     'print("rank 1: hello")\n'
+                     'print(\'{"metric": "m", "value": 1.5, "n_gpus": 2}\')\n'
+                     'print("trailing chatter", file=sys.stderr)\n'
+                     'sys.exit(int(sys.argv[1]))\n')
+    for status in (0, 3):
+        monkeypatch.setattr(bench, "launcher_command", lambda argv, gpus, port, python=None, s=status: [sys.executable, str(child), str(s)])
+        rc = bench.run_ranks(["--gpus", "2"], 2)
+        out = capsys.readouterr()
+        assert rc == status
+        assert out.out.strip().splitlines() == ['{"metric": "m", "value": 1.5, "n_gpus": 2}']
+        assert "rank 1: hello" in out.err                      # everything else the ranks wrote goes to stderr
+    # ranks that exit 0 without a line are a failure of the run, not a silent success
+    child.write_text('print("no line")\n')
+    monkeypatch.setattr(bench, "launcher_command", lambda argv, gpus, port, python=None: [sys.executable, str(child)])
+    assert bench.run_ranks([], 2) != 0
+
+
 def _env_without_rank_variables():
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     return env
