@@ -277,6 +277,8 @@ def main():
                     help="initialise torch.distributed even with one rank and run the N>1 collectives through it")
     ap.add_argument("--reference-order", action="store_true",
                     help="rtmi_params.reference_order = 1: op1/2/6/8 too in the reference's own operation order (op7 always is)")
+    ap.add_argument("--fast-field", action="store_true",
+                    help="rtmi_params.reference_order = 3: op7's reference-order step on the fused field lookup")
     ap.add_argument("--fused", action="store_true",
                     help="rtmi_params.reference_order = 2: fused forms wherever there is one -- op7 too (outside 1e-9 on interface)")
     ap.add_argument("--parity-stride", type=int, default=512, help="parity_check: every this-many-th ray (0 = skip)")
@@ -348,7 +350,7 @@ def main():
                         launch_mode=args.mode, refill_min=args.refill_min, slice_steps=args.slice_steps,
                         field_path={"auto": 0, "global": 1, "lds": 2, "shared": 2}[args.field_path], sort_rays=args.sort,
                         lazy_clear=True,    # every pass re-runs the same launch conditions: same rows rewritten
-                        keep_n_ray=args.n_ray, reference_order=2 if args.fused else int(args.reference_order))
+                        keep_n_ray=args.n_ray, reference_order=3 if args.fast_field else 2 if args.fused else int(args.reference_order))
 
     try:
         batch = make_batch(stride, rec_rows)
@@ -465,7 +467,7 @@ def main():
         # the profiles were taken with every other option at its default: a run that changes one of them (ray order, sort,
         # field path, slice length, block size, refill threshold, a shard of a larger fan) has no profile of its own
         defaults = (args.order == "fan" and not args.sort and args.field_path == "auto" and args.slice_steps in (0, 512)
-                    and args.block == 0 and args.refill_min == 0 and part_world == 1 and not args.reference_order and not args.fused)
+                    and args.block == 0 and args.refill_min == 0 and part_world == 1 and not args.reference_order and not args.fused and not args.fast_field)
         prof = {}
         try:
             prof = (json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key, {}) or {}) if defaults else {}
@@ -525,7 +527,7 @@ def main():
                                    f"rays, interleaved across ranks), op{args.method}, DELTA_S={step:.12g}, "
                                    f"box={tuple(float(v) for v in lim)}, record={args.record}",
                        "rays_total": R_total, "rays_rank0": R_local, "ray_steps_per_pass_rank0": int(steps_per_pass),
-                       "method": f"op{args.method}", "record": args.record, "n_ray_rows": bool(args.n_ray and stride), "launch_mode": args.mode, "launch_mode_used": mode_used, "auto_fallbacks": int(st["auto_fallbacks"]), "reference_order": 2 if args.fused else int(args.reference_order),
+                       "method": f"op{args.method}", "record": args.record, "n_ray_rows": bool(args.n_ray and stride), "launch_mode": args.mode, "launch_mode_used": mode_used, "auto_fallbacks": int(st["auto_fallbacks"]), "reference_order": 3 if args.fast_field else 2 if args.fused else int(args.reference_order),
                        "ray_order": args.order, "sort_rays": bool(args.sort), "field_path": args.field_path,
                        "steps_per_launch": args.chunk or "all", "parallelism": f"ray-shard x{world}"},
             "roofline": roof,

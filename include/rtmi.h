@@ -52,7 +52,7 @@ typedef enum {
 } rtmi_launch_mode;
 
 /* rtmi_params.reference_order */
-typedef enum { RTMI_ORDER_DEFAULT = 0, RTMI_ORDER_REFERENCE = 1, RTMI_ORDER_FUSED = 2 } rtmi_order;
+typedef enum { RTMI_ORDER_DEFAULT = 0, RTMI_ORDER_REFERENCE = 1, RTMI_ORDER_FUSED = 2, RTMI_ORDER_FAST_FIELD = 3 } rtmi_order;
 
 typedef struct rtmi_field rtmi_field;   /* z + grd of interpolacion() (:435-464), resident in HBM */
 typedef struct rtmi_batch rtmi_batch;   /* one trazar() call's ray batch (:766-948), resident in HBM */
@@ -128,15 +128,16 @@ typedef struct {
     int32_t slice_steps;     /* time-sliced schedule: DELTA_S steps per time slice of a bundle (0 -> 512); a bundle's first two
                                 slices are 4 and 2 times as long */
     int32_t reference_order; /* rtmi_order.  RTMI_ORDER_DEFAULT (0): op1/2/6/8 step in fused forms (~1e-13 from the reference per
-                                trajectory).  op7's new angle differentiates POSITIONS (:370-372), so their last bits matter: it takes
-                                the reference-order step -- the advancement's operation order, numpy's arctan2, glibc's sin / cos --
-                                on the fused field lookup (n and grad n reach a position only through a 1e-6 term): <= 4e-11 from the
-                                reference on every scenario, 1.5 times the fused cost.  RTMI_ORDER_REFERENCE (1, fp64 only):
-                                op1/2/6/7/8 in the reference's operation order throughout, field lookup included, like
-                                op3/4/5/9/10/11 always are: the oracle's bits (the reference's, within 1 ulp where numpy's scalar
-                                pow(x, 2) is not x*x), at a quarter to a third of the fused speed.  RTMI_ORDER_FUSED (2): fused forms
-                                wherever there is one, op7 too (up to 8e-9 from the reference on the interface scenario); fp32
-                                batches always run fused forms */
+                                trajectory).  op7's new angle differentiates POSITIONS (:370-372), so their last bits enter it: it
+                                steps in the reference's own operation order throughout, like op3/4/5/9/10/11 always do (the
+                                oracle's bits; 3.3 times the fused cost).  RTMI_ORDER_REFERENCE (1, fp64 only): op1/2/6/8 too: the
+                                oracle's bits (the reference's, within 1 ulp where numpy's scalar pow(x, 2) is not x*x), at a
+                                quarter to a third of the fused speed.  RTMI_ORDER_FUSED (2): fused forms wherever there is one,
+                                op7 too (up to 8e-9 from the reference on the interface scenario); fp32 batches always run fused
+                                forms.  RTMI_ORDER_FAST_FIELD (3): as DEFAULT, but op7 takes its reference-order step -- the
+                                advancement's operation order, numpy's arctan2, glibc's sin / cos -- on the fused field lookup:
+                                2.3 times faster, <= 8e-11 from the reference except on rays grazing a sharp interface at its
+                                critical angle (2.6e-9 on one sampled ray of the 1 M-ray interface fan) */
 } rtmi_params;
 
 /* Upload R launch conditions (host pointers; x0/y0 per ray -- pos_x[k], -2 or the fisheye start, :809-813),

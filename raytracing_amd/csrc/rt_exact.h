@@ -719,7 +719,7 @@ __device__ __forceinline__ bool ray_step(const FieldDev<double>& F, const Consts
     if constexpr (IsPoly<G>::value) rt::n_gradient(F, gather, active, fx, fy, fn, fgx, fgy);   // kFastField: the cell's polynomial
     else ex::n_gradient(F, gather, active, fx, fy, fn, fgx, fgy);
     const double fth = ex::op_angle<METHOD>(k, r, flag, fx, fy, fn, fgx, fgy, i);
-    ex::store_update<inline_sincos(METHOD) || IsPoly<G>::value>(k, r, fx, fy, fth, fn, fgx, fgy);   // (IsPoly: op7's default, kFastField)
+    ex::store_update<inline_sincos(METHOD) || IsPoly<G>::value>(k, r, fx, fy, fth, fn, fgx, fgy);   // (IsPoly: op7 with RTMI_ORDER_FAST_FIELD, kFastField)
     return (METHOD == 7 && i <= 2) || !outside(k, r);     // no boundary test in op7's bootstrap rows
 }
 

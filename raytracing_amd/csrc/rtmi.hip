@@ -97,13 +97,15 @@ static double libm_square(double x) {
 // five.  RTMI_ORDER_DEFAULT: op7 alone -- it differentiates POSITIONS (11 P3 - 18 P2 + 9 P1 - 2 P0 over 6 DELTA_S), so the
 // last bits of the positions enter every new angle at 2e-12 and a fused position update (an ulp or two from the reference's)
 // random-walks away from it: 8.4e-9 on recorded rows of the interface scenario, past the 1e-9 the path is held to; only the
-// reference's own roundings reproduce its noise.  RTMI_ORDER_FUSED keeps op7 in the fused form (3.4 times faster, fp32 always).
+// reference's own roundings reproduce its noise.  RTMI_ORDER_FUSED keeps op7 in the fused form (3.3 times faster, fp32 always).
 static bool ref_order(const rtmi_params& p) {
-    return p.dtype == RTMI_F64 && (p.reference_order == RTMI_ORDER_REFERENCE || (p.method == 7 && p.reference_order == RTMI_ORDER_DEFAULT));
+    return p.dtype == RTMI_F64 && (p.reference_order == RTMI_ORDER_REFERENCE ||
+                                   (p.method == 7 && (p.reference_order == RTMI_ORDER_DEFAULT || p.reference_order == RTMI_ORDER_FAST_FIELD)));
 }
-// ... and op7's default takes that step on the FAST field lookup (rt::kFastField, rt_device.h: the positions still round like the
-// reference's but for an ulp's shift once in 1e4 .. 1e6 steps): 1e-13 from the reference instead of its bits, 1.5 times faster.
-static bool fast_field_order(const rtmi_params& p) { return p.dtype == RTMI_F64 && p.method == 7 && p.reference_order == RTMI_ORDER_DEFAULT; }
+// RTMI_ORDER_FAST_FIELD: op7 takes that step on the FAST field lookup (rt::kFastField, rt_device.h): 2.3 times faster, and within
+// 1e-9 of the reference everywhere but on rays that graze a sharp interface at its critical angle (one of 16 384 sampled rays of
+// the 1 M-ray interface fan: 2.6e-9; profiles/r04_op7_offenders_interface_1m.txt) -- which is why it is not the default.
+static bool fast_field_order(const rtmi_params& p) { return p.dtype == RTMI_F64 && p.method == 7 && p.reference_order == RTMI_ORDER_FAST_FIELD; }
 
 // ------------------------------------------------------------------ handles
 struct rtmi_field {
@@ -1415,7 +1417,7 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
 // kernel variant tables: [kernel method][iso][lds].  Kernel methods: the step methods 1..11, then op1/2/6/7/8 in the reference's
 // operation order (METHOD = method | rt::kRefOrder, fp64 only: the fp32 tables alias the ordinary builds there).
 // Anisotropic-only methods (op10/op11) have no ISO build.
-// Index 16: op7's default -- the reference-order step on the fast field lookup (rt::kFastField).
+// Index 16: op7 with RTMI_ORDER_FAST_FIELD -- the reference-order step on the fast field lookup (rt::kFastField).
 constexpr int kKernelMethods = 17;
 constexpr int kmethod_of(int idx) {
     return idx < 11 ? idx + 1 : idx == 16 ? (7 | rt::kRefOrder | rt::kFastField) : (idx == 11 ? 1 : idx == 12 ? 2 : idx == 13 ? 6 : idx == 14 ? 7 : 8) | rt::kRefOrder;
@@ -1625,7 +1627,7 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     ARG_TRY(p->lazy_clear == 0 || p->lazy_clear == 1, "rtmi_batch_create: lazy_clear must be 0 or 1");
     ARG_TRY(p->no_n_ray == 0 || p->no_n_ray == 1, "rtmi_batch_create: no_n_ray must be 0 or 1");
     ARG_TRY(!(p->no_n_ray && p->ext_n_ray), "rtmi_batch_create: no_n_ray set together with ext_n_ray");
-    ARG_TRY(p->reference_order >= 0 && p->reference_order <= 2, "rtmi_batch_create: reference_order must be 0, 1 or 2 (RTMI_ORDER_*)");
+    ARG_TRY(p->reference_order >= 0 && p->reference_order <= 3, "rtmi_batch_create: reference_order must be 0 .. 3 (RTMI_ORDER_*)");
     ARG_TRY(!(p->reference_order == RTMI_ORDER_REFERENCE && p->dtype != RTMI_F64), "rtmi_batch_create: reference_order 1 needs an fp64 batch (the reference has no fp32)");
     DEVICE_TRY(f, "rtmi_batch_create");
     rtmi_batch* b = new (std::nothrow) rtmi_batch();

@@ -37,7 +37,7 @@ DELTA_S_DIVISOR_VERT_UPPER_LIMIT = 2                 # :96
 DELTA_S_DIVISOR_VERT_LOWER_LIMIT = 1 / 40            # :97
 
 F64, F32 = 0, 1
-ORDERS = {"default": 0, "reference": 1, "fused": 2}          # rtmi_order (rtmi_params.reference_order)
+ORDERS = {"default": 0, "reference": 1, "fused": 2, "fast_field": 3}          # rtmi_order (rtmi_params.reference_order)
 
 
 # --------------------------------------------------------------------------- scenarios (:106-119)
@@ -313,7 +313,8 @@ class Batch:
         p.no_n_ray = int(not keep_n_ray)
         p.slice_steps = int(slice_steps)
         # rtmi_order: False / 0 default (op7 alone of the fused five steps in the reference's operation order); True / 1 all of
-        # op1/2/6/7/8 (fp64: the oracle's bits, slower); "fused" / 2 fused forms throughout, op7 included
+        # op1/2/6/7/8 (fp64: the oracle's bits, slower); "fused" / 2 fused forms throughout, op7 included; "fast_field" / 3 op7's
+        # reference-order step on the fused field lookup
         p.reference_order = ORDERS[reference_order] if isinstance(reference_order, str) else int(reference_order)
         self.params = p
         self._h = C.c_void_p()

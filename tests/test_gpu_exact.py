@@ -197,13 +197,12 @@ def test_extreme_anisotropy_is_the_oracles_bits(m, gam, rb, fields):
 
 
 @pytest.mark.parametrize("scen", ["vert_heterogeneous", "fisheye", "interface"])
-def test_op7_default_keeps_the_references_positions(scen, rb, fields):
+def test_op7_steps_in_reference_order_by_default(scen, rb, fields):
     """op7's new angle differentiates positions (RT_bench.py:370-372), so the positions' last bits matter: a default batch
-    (rtmi_params.reference_order = 0) takes the reference-order step -- its advancement, numpy's arctan2, glibc's sin / cos -- on
-    the fast field lookup, whose n and grad n reach a position only through the second-order term: the positions round like the
-    reference's on almost every step, and every recorded row stays within 1e-10 of the oracle here (measured 8e-16 .. 2e-12;
-    4e-11 on rows of a 4 096-ray interface fan, profiles/r04_parity_sweep.txt), where the fused form (RTMI_ORDER_FUSED, opt-in)
-    walks up to 8e-9 away; reference_order = 1 gives the oracle's bits (test_reference_order_mode)."""
+    (rtmi_params.reference_order = 0) steps op7 in the reference's operation order throughout and gives the ORACLE's bits.  The
+    two opt-ins: RTMI_ORDER_FAST_FIELD (the same step on the fused field lookup: every recorded row within 1e-10 of the oracle
+    here, 8e-11 on 4 096-ray fans -- but 2.6e-9 on the critical ray of a 1 M-ray interface fan,
+    profiles/r04_op7_offenders_interface_1m.txt) and RTMI_ORDER_FUSED (up to 8e-9 on interface rows)."""
     from bench import parity_relerr
     from oracle import rt_oracle as O
     F, OF = fields(scen)
@@ -212,16 +211,20 @@ def test_op7_default_keeps_the_references_positions(scen, rb, fields):
     x0, y0, th = traj_inputs(t, scen)
     step, ms, lim = float(t["step"]), int(t["max_size"]), t["box"]
     o = O.trazar(OF, 7, 1, step, ms, lim, x0, y0, th, record_stride=1, nthreads=8)
+    b = rb.Batch(F, 7, step, ms, lim, 1, th, x0, y0, record_stride=1)
+    b.run()
+    assert _bits_equal(b.d_ray(), o["d_ray"]) and _bits_equal(b.final(), o["final"]) and _bits_equal(b.rows(), o["s_ray"])
+    b.close()
     errs = {}
-    for order in ("default", "fused"):
+    for order in ("fast_field", "fused"):
         b = rb.Batch(F, 7, step, ms, lim, 1, th, x0, y0, record_stride=1, reference_order=order)
         b.run()
         d, fin, s = b.d_ray(), b.final(), b.rows()
         b.close()
         assert np.array_equal(d[2], o["d_ray"][2])
         errs[order] = max(parity_relerr(s, o["s_ray"]), parity_relerr(fin, o["final"]), parity_relerr(d[:2], o["d_ray"][:2]))
-    print(f"{scen} op7 vs oracle: default {errs['default']:.1e}, fused {errs['fused']:.1e}")
-    assert errs["default"] < 1e-10 and errs["fused"] < 1e-7
+    print(f"{scen} op7 vs oracle: fast_field {errs['fast_field']:.1e}, fused {errs['fused']:.1e}")
+    assert errs["fast_field"] < 1e-10 and errs["fused"] < 1e-7
 
 
 def test_reference_order_needs_fp64(rb):

@@ -8,5 +8,9 @@ for scen in vert_heterogeneous fisheye interface; do
   done
 done
 for m in 10 11; do echo -n "anisotropy : "; python3 tools/bench_line.py --scenario anisotropy --method $m --rays 524288 --record none --steps 3; done
-# rtmi_params.reference_order: op1/2/6/7/8 in the reference's operation order
-for m in 1 2 6 7 8; do echo -n "vert_heterogeneous reference_order : "; python3 tools/bench_line.py --scenario vert_heterogeneous --method $m --rays 1048576 --record none --steps 3 --reference-order; done
+# rtmi_params.reference_order = 1: op1/2/6/8 in the reference's operation order too (op7's default is that already)
+for m in 1 2 6 8; do echo -n "vert_heterogeneous reference_order : "; python3 tools/bench_line.py --scenario vert_heterogeneous --method $m --rays 1048576 --record none --steps 3 --reference-order; done
+# op7's opt-ins: the fused form (--fused) and the reference-order step on the fused field lookup (--fast-field)
+for scen in vert_heterogeneous fisheye interface; do
+  for o in --fused --fast-field; do echo -n "$scen op7 $o : "; python3 tools/bench_line.py --scenario $scen --method 7 --rays 1048576 --record none --steps 3 $o; done
+done

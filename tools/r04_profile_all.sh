@@ -17,6 +17,7 @@ tools/profile_config.sh r04q_cfg5_aniso_none --scenario anisotropy --record none
 tools/profile_config.sh r04q_cfg5_shard8_none --scenario anisotropy --record none --total-rays 1048576 --emulate-world 8
 tools/profile_config.sh r04q_iface_op9_none --scenario interface --method 9 --rays 524288 --record none
 tools/profile_config.sh r04q_op7_vert_none --method 7 --record none
+tools/profile_config.sh r04q_op7_fastfield_vert_none --method 7 --record none --fast-field
 tools/profile_config.sh r04q_op3_vert_none --method 3 --record none
 tools/profile_config.sh r04q_op9_vert_none --method 9 --rays 524288 --record none
 tools/profile_config.sh r04q_strong8_full --total-rays 1048576 --emulate-world 8 --record full
