@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """The interface scenario's worst case for a form that is not the reference's bits: the rays of the 1 048 576-ray fan around
 the CRITICAL angle (where the fan splits into reflected and refracted rays; a ray there runs along the interface and amplifies
-any last-bit difference).  Finds the split on every 64th ray (device only), then compares the 4 096 CONTIGUOUS rays of the
-full fan around it with the oracle, every 16th row, per quantity group, for each method's orders.  Checker run (tests/
-material)."""
+any last-bit difference).  Per method: finds the split on every 64th ray (device only), then compares the 4 096 CONTIGUOUS
+rays of the full fan around it with the oracle, every 16th row, per quantity group, for each of the method's orders -- and
+measures the CONDITIONING of those rays: how far the oracle's own rows move when the launch angle moves by one ulp.  A ray
+whose rows move by more than 1e-9 for a 1-ulp change of its input cannot be reproduced to 1e-9 by anything but the same
+roundings.  Checker run (tests/ material)."""
 import os
 import sys
 
@@ -23,33 +25,46 @@ F = rb.Field.build("interface", lim, rb.DELTA)
 OF = O.Field("interface", lim, rb.DELTA)
 threads = min(O.max_threads(), os.cpu_count() or 1)
 
-b = rb.Batch(F, 6, rb.DELTA_S, ms, lim, 1, th[::64], -2.0, -2.0, record_stride=0)
-b.run()
-fin = b.final()
-b.close()
-jump = np.abs(np.diff(fin[1]))                      # final y: refracted rays leave through the top, reflected ones do not
-k = int(np.argmax(jump))
-i0 = max(0, k * 64 + 32 - W // 2)
-win = slice(i0, i0 + W)
-print(f"# the fan splits between rays {k * 64} and {k * 64 + 64} ({np.degrees(th[k * 64]):.5f} .. {np.degrees(th[k * 64 + 64]):.5f} deg); "
-      f"window: rays {i0} .. {i0 + W - 1}, every 16th row, {threads} host threads")
-print(f"{'op':>3s} {'order':10s} {'same steps':>10s} {'x y':>9s} {'p':>9s} {'T':>9s} {'theta':>9s} {'final':>9s} {'rays > 1e-9':>11s}")
+
+
+def per_ray(a, w):
+    """largest difference of each ray's rows, per quantity group, relative to the group's largest magnitude in w: [4][R]"""
+    out = []
+    for q in ((0, 1), (2, 3), (4,), (5,)):
+        out.append(np.abs(a[:, list(q)] - w[:, list(q)]).max(axis=(0, 1)) / np.abs(w[:, list(q)]).max())
+    return np.array(out)
+
+
+print(f"# interface scenario, {R} rays; windows of {W} contiguous rays around each method's split, every 16th row; {threads} host threads")
+print("# columns x y / p / T / theta: largest difference from the oracle over the window, relative to the quantity's largest magnitude")
+print("# '> 1e-9': rays with any quantity beyond 1e-9; 'of them ill': those whose oracle rows move MORE than 1e-9 when theta_0 moves by 1 ulp;")
+print("# 'worst / ulp': the largest ratio (difference from the oracle) / (the oracle's own movement per ulp of theta_0) over the rays beyond 1e-9")
+print(f"{'op':>3s} {'order':10s} {'split at':>9s} {'same steps':>10s} {'x y':>9s} {'p':>9s} {'T':>9s} {'theta':>9s} {'final':>9s} {'> 1e-9':>7s} {'of them ill':>11s} {'worst / ulp':>11s}")
 for m in (1, 2, 6, 8, 7):
-    o = O.trazar(OF, m, 1, rb.DELTA_S, ms, lim, -2.0, -2.0, th[win], record_stride=16, rec_rows=600, nthreads=threads)
+    b = rb.Batch(F, m, rb.DELTA_S, ms, lim, 1, th[::64], -2.0, -2.0, record_stride=0, reference_order="fused")
+    b.run()
+    fin = b.final()
+    b.close()
+    k = int(np.argmax(np.abs(np.diff(fin[1]))))     # final y: refracted rays leave through the top, reflected ones do not
+    i0 = min(max(0, k * 64 + 32 - W // 2), R - W)
+    win = slice(i0, i0 + W)
+    kw = dict(record_stride=16, rec_rows=600)
+    o = O.trazar(OF, m, 1, rb.DELTA_S, ms, lim, -2.0, -2.0, th[win], nthreads=threads, **kw)
+    o1 = O.trazar(OF, m, 1, rb.DELTA_S, ms, lim, -2.0, -2.0, np.nextafter(th[win], np.inf), nthreads=threads, **kw)
+    moved = per_ray(o1["s_ray"], o["s_ray"]).max(axis=0)                 # the oracle's own movement per ulp of theta_0, per ray
+    moved[o1["d_ray"][2] != o["d_ray"][2]] = np.inf                      # (a different number of steps: any difference goes)
     for order in (("default", "fast_field", "fused") if m == 7 else ("default", "reference")):
-        b = rb.Batch(F, m, rb.DELTA_S, ms, lim, 1, th[win], -2.0, -2.0, record_stride=16, rec_rows=600, reference_order=order)
+        b = rb.Batch(F, m, rb.DELTA_S, ms, lim, 1, th[win], -2.0, -2.0, reference_order=order, **kw)
         b.run()
         s, d, fin = b.rows(), b.d_ray(), b.final()
         b.close()
         same = d[2] == o["d_ray"][2]
-        cols = []
-        over = np.zeros(W, bool)
-        for q in ((0, 1), (2, 3), (4,), (5,)):
-            a, w = s[:, list(q)][:, :, same], o["s_ray"][:, list(q)][:, :, same]
-            scale = np.abs(w).max()
-            e = np.abs(a - w).max(axis=(0, 1)) / scale
-            cols.append(e.max())
-            over[np.flatnonzero(same)[e > 1e-9]] = True
+        e = per_ray(s[:, :, same], o["s_ray"][:, :, same])
+        dev = e.max(axis=0)
+        over = dev > 1e-9
+        ill = over & (moved[same] > 1e-9)
+        ratio = (dev[over] / np.maximum(moved[same][over], 1e-300)).max() if over.any() else 0.0
         ef = parity_relerr(fin[:, same], o["final"][:, same])
-        print(f"{m:3d} {order:10s} {int(same.sum()):10d} " + " ".join(f"{c:9.1e}" for c in cols) + f" {ef:9.1e} {int(over.sum()):11d}", flush=True)
+        print(f"{m:3d} {order:10s} {np.degrees(th[k * 64 + 32]):9.4f} {int(same.sum()):10d} " + " ".join(f"{c:9.1e}" for c in e.max(axis=1)) +
+              f" {ef:9.1e} {int(over.sum()):7d} {int(ill.sum()):11d} {ratio:11.1f}", flush=True)
 F.close()
