@@ -137,7 +137,10 @@ typedef struct {
                                 forms.  RTMI_ORDER_FAST_FIELD (3): as DEFAULT, but op7 takes its reference-order step -- the
                                 advancement's operation order, numpy's arctan2, glibc's sin / cos -- on the fused field lookup:
                                 2.3 times faster, <= 8e-11 from the reference except on rays grazing a sharp interface at its
-                                critical angle (2.6e-9 on one sampled ray of the 1 M-ray interface fan) */
+                                critical angle (2.6e-9 on one sampled ray of the 1 M-ray interface fan).  Such rays -- a handful
+                                of a million, running along a sharp interface -- are ill-conditioned in the reference itself
+                                (its rows move 1e-6 for a 1e-12 change of the launch angle): there only the reference-order
+                                forms agree with it to 1e-9 (fused op1/2/6/8: up to 1.9e-8 on 2-6 rays of the 1 M) */
 } rtmi_params;
 
 /* Upload R launch conditions (host pointers; x0/y0 per ray -- pos_x[k], -2 or the fisheye start, :809-813),

@@ -1111,6 +1111,49 @@ def test_set_per_ray_only_on_a_fresh_batch_and_reset_clears_rows(rb, gpu_fields)
     lz.close()
 
 
+# ------------------------------------------------------------------ the ill-conditioned rays of the interface scenario
+@pytest.mark.parametrize("method, first", [(6, 487296), (8, 487168), (1, 483328), (2, 483328)])
+def test_critical_rays_of_the_1m_interface_fan(method, first, rb, gpu_fields, oracle_fields):
+    """Where the 1 048 576-ray interface fan splits into reflected and refracted rays (near 45 degrees; each method at its own
+    angle) a ray runs along the interface and amplifies last-bit differences a million times: a handful of rays per method --
+    2 to 6 of the 1 M (tools/critical_ray_window.py, profiles/r04_critical_ray_window.txt) -- leave 1e-9 in the fused forms,
+    p and theta on rows inside the interface.  Those rays are ill-conditioned in the REFERENCE: its own rows move 300 times
+    further when the launch angle changes by 1e-12 of itself.  1 024 contiguous rays of the fan around the split, every 16th
+    row: (a) rtmi_params.reference_order = 1 gives the oracle's bits on every one of them; (b) a default batch is within 1e-9 on
+    all but at most 8 rays, and on those within a twentieth of the oracle's own movement under that perturbation -- that is, it
+    returns the reference's trajectory for a launch angle within 5e-14 of the given one."""
+    from oracle import rt_oracle as O
+    R, W = 1 << 20, 1024
+    th = np.linspace(2 * np.pi / 60, np.pi / 2, R)[first:first + W]
+    lim = LIMITS["interface"]
+    ms = int(np.ceil(80 / rb.DELTA_S) + 1)
+    kw = dict(record_stride=16, rec_rows=600)
+
+    def groups(a, w):
+        return np.array([np.abs(a[:, q] - w[:, q]).max(axis=(0, 1)) / np.abs(w[:, q]).max() for q in ([0, 1], [2, 3], [4], [5])]).max(axis=0)
+
+    OF = oracle_fields("interface")
+    o = O.trazar(OF, method, 1, rb.DELTA_S, ms, lim, -2.0, -2.0, th, nthreads=16, **kw)
+    o1 = O.trazar(OF, method, 1, rb.DELTA_S, ms, lim, -2.0, -2.0, th * (1 + 1e-12), nthreads=16, **kw)
+    moved = groups(o1["s_ray"], o["s_ray"])
+    assert np.ptp(o["final"][1]) > 1.0                                   # the window does hold the split: rays leave at different heights
+    b = rb.Batch(gpu_fields("interface"), method, rb.DELTA_S, ms, lim, 1, th, -2.0, -2.0, reference_order=True, **kw)
+    b.run()
+    assert np.array_equal(b.rows(), o["s_ray"]) and np.array_equal(b.final(), o["final"]) and np.array_equal(b.d_ray(), o["d_ray"])
+    b.close()
+    b = rb.Batch(gpu_fields("interface"), method, rb.DELTA_S, ms, lim, 1, th, -2.0, -2.0, **kw)
+    b.run()
+    s, d = b.rows(), b.d_ray()
+    b.close()
+    assert np.array_equal(d[2], o["d_ray"][2])
+    dev = groups(s, o["s_ray"])
+    over = dev > REL
+    print(f"op{method}: {int(over.sum())} of {W} rays beyond 1e-9 (largest {dev.max():.1e}); of the rest the largest is {dev[~over].max():.1e}; "
+          f"largest (difference) / (the oracle's movement for theta_0 (1 + 1e-12)) on them: {(dev[over] / moved[over]).max() if over.any() else 0:.4f}")
+    assert over.sum() <= 8 and dev.max() < 1e-7
+    assert np.all(dev[over] < 0.05 * moved[over])
+
+
 # ------------------------------------------------------------------ BASELINE configs at FULL size on one GPU
 def test_cfg5_anisotropy_full_1m_rays(rb, gpu_fields, oracle_fields):
     """cfg5 whole: anisotropy (gamma = 3), op11, 1 048 576 rays fp64 on ONE MI355X, every 16th row recorded (9.7 GB).  p_x (the
