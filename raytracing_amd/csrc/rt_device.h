@@ -225,6 +225,10 @@ template <typename T> struct FieldDev {
     T ax, hx, bx, inv_hx;
     T ay, hy, by, inv_hy;
     int exact;   // 1: FITPACK's arithmetic with true knots in every cell (see axis_eval)
+    // window: 1 when rt::ex::n_gradient may serve a wave whose live lanes share one cell through the scalar cache (lookup_uniform).
+    // Set per batch (batch_dev): it pays from three waves per SIMD on -- a lone wave waits longer for its scalar loads than for
+    // its vector loads (65 536 rays: -4 .. -10 %; 262 144: +17 %; 1 M: +12 .. +26 %, profiles/r04_ab_uniform_window.txt)
+    int window;
     // poly: [(qy-1)*(qx-1)][kPolyStride] the same three splines as one polynomial per grid cell (rt_polytab.h) -- what the
     // fast-form step methods evaluate (PolyGather below); zn / g serve the reference-order methods and rtmi_field_eval
     const T* poly;
@@ -234,8 +238,9 @@ template <typename T> struct FieldDev {
     // (flatn, 0, 0) and never touches its 36 coefficients; 8 (fp64) cells of a grid row share a cache line of the map, where
     // every cell of the table proper is five lines of its own.  0 when no cell of the grid is flat: one scalar test per lookup.
     int flat;
-    // rdx / rdy: [q][8] fp64, per cell index of an axis the correctly rounded reciprocals of the seven knot differences
-    // FITPACK's fpbspl divides by there (rt_exact.h, axis_exact); nullptr in fp32 fields (the reference-order path is fp64)
+    // rdx / rdy: [q][24] fp64, per cell index of an axis the correctly rounded reciprocals of the seven knot differences
+    // FITPACK's fpbspl divides by there, then the cell's knots and the differences themselves (rt_exact.h: axis_exact reads the
+    // reciprocals per lane, AxisTab the whole entry for a wave in one cell); nullptr in fp32 fields (the reference-order path is fp64)
     const double *rdx, *rdy;
 };
 
@@ -505,6 +510,7 @@ __device__ __forceinline__ void lookup_global_rows(const FieldDev<T>& F, const C
 #endif
 // Gather policy 1: every lookup reads its 36 coefficients from global memory (L1/L2-resident in practice).
 template <typename T> struct GlobalGather {
+    static constexpr bool kUniformWindow = true;     // rt::ex::n_gradient: a wave in one cell reads the window through the scalar cache
     __device__ __forceinline__ void fetch(const FieldDev<T>& F, const Cell<T>& c, bool active, T z[4], Pair<T> g[4][4]) {
         // an idle lane reads the grid's first window instead of its stale cell: all idle lanes then share one
         // cache line, without a branch around the loads
@@ -554,6 +560,7 @@ __device__ __forceinline__ int wave_max_i(int v) {
 // depend on the policy.  No block barrier: the tile is private to one wave and LDS executes a wave's DS
 // instructions in order; fetch() must be reached in wave-uniform control flow (it votes and shuffles).
 template <typename T, int PHASES = RTMI_TILE_PHASES> struct LdsGather {
+    static constexpr bool kUniformWindow = false;
     static constexpr int TILE = 16;                 // coefficient rows/cols held
     static constexpr int GPITCH = TILE + 1;         // pairs per g row (one pad pair against bank aliasing)
     static constexpr int ZPITCH = TILE + 2;         // elements per zn row

@@ -173,20 +173,23 @@ __device__ __forceinline__ double impulse(double a, double b, double step) { ret
 // and k = 3 with IEEE divisions and separate multiply/add, exactly as oracle/rt_oracle.c fpbspl().
 //
 // The seven divisions of one axis all divide by a difference of knots, and a cell has only one set of them: the field build
-// tabulates their CORRECTLY ROUNDED reciprocals per cell index (rd[j][0..6], fp_recip_build on the host: the same knots by
+// tabulates their CORRECTLY ROUNDED reciprocals per cell index (rd[j][0..6], fp_axis_tab_build on the host: the same knots by
 // the same operations, then an IEEE division).  1.0 / d is then the table value itself, and a / d is Markstein's division
 //     q0 = a r,   e = a - d q0  (exact: one fma),   q = q0 + e r  (one fma)      with r = RN(1 / d)
 // which returns the correctly rounded quotient (Markstein 1990; Cornea, Harrison, Tang: Scientific Computing on Itanium,
 // thm 8.3 -- no overflow or underflow here: 0 <= a <= 1, d ~ the grid pitch): 3 instructions for the 11 of the IEEE sequence
 // (v_div_scale x2, v_rcp, four fma, v_div_fmas, v_div_fixup), 110 fewer per lookup.  Bits: every test that holds a
 // reference-order method to the oracle's bits runs through it (the oracle divides).
+// The table (rtmi.hip, fp_axis_tab_build) holds kAxisTab doubles per cell index: the seven reciprocals and a zero (what this
+// function reads), then the cell's knots and the seven differences themselves for a wave that shares ONE cell (AxisTab below).
+constexpr int kAxisTab = 24;
 __device__ __forceinline__ void axis_exact(double v, int q, double a, double h, double b, double ih, const double* rd, int& j, int& l,
                                            double wl[2], double w[4]) {
     double t0, t1;
     j = locate(v, q, a, h, b, ih, t0, t1);      // v is clamped in place (quirk Q4)
     // the cell's seven reciprocals: two 32-byte rows (L1-resident: q x 64 bytes per axis)
     typedef double Quad4 __attribute__((ext_vector_type(4)));
-    const Quad4 ra = *reinterpret_cast<const Quad4*>(rd + (size_t)j * 8), rb = *reinterpret_cast<const Quad4*>(rd + (size_t)j * 8 + 4);
+    const Quad4 ra = *reinterpret_cast<const Quad4*>(rd + (size_t)j * kAxisTab), rb = *reinterpret_cast<const Quad4*>(rd + (size_t)j * kAxisTab + 4);
     {   // k = 1 on [t0, t1]
         const double f = ra.x;                  // 1.0 / (t1 - t0)
         wl[0] = 0.0 + f * (t1 - v);
@@ -248,9 +251,101 @@ __device__ __forceinline__ void field_combine(const Cell<double>& c, const doubl
     gy = sy;
 }
 
+// ---------------------------------------------------------------- the same lookup for a wave whose live lanes share ONE cell
+// The rays of a wave leave one origin with neighbouring angles: on a fan 64 of them sit in one grid cell on 98 % of their steps.
+// Everything of the lookup that depends only on the cell is then the same number in every lane -- the 36 coefficients of the
+// window, the knots, the seven knot differences of each axis and their reciprocals -- and is read ONCE per wave through the
+// scalar cache into scalar registers, where the vector instructions take it as their scalar operand: no vector load (18 + 4
+// per lookup in the per-lane form), no address arithmetic, no knot arithmetic, and none of the 72 vector registers the window
+// is staged in.  The operations on the per-lane numbers (x, y, the basis values, the sums) are axis_exact's and
+// field_combine's, one for one: the same bits.  A wave in several cells takes the per-lane form.
+#ifndef RTMI_EXACT_UNIFORM
+#define RTMI_EXACT_UNIFORM 1
+#endif
+struct AxisTab { double r[8]; double t0, t1, tm2, tm1, k0, k1, k2, k3; double d[8]; };   // one cell index of one axis
+static_assert(sizeof(AxisTab) == kAxisTab * sizeof(double), "fp_axis_tab_build writes this layout");
+typedef const AxisTab __attribute__((address_space(4)))* AxisTabS;
+__device__ __forceinline__ void axis_uniform(double v, AxisTabS t, double wl[2], double w[4]) {
+    {   // k = 1 on [t0, t1]
+        const double f = t->r[0];
+        wl[0] = 0.0 + f * (t->t1 - v);
+        wl[1] = f * (v - t->t0);
+    }
+    const double tm2 = t->tm2, tm1 = t->tm1, k0 = t->k0, k1 = t->k1, k2 = t->k2, k3 = t->k3;
+    double f = t->r[1];
+    double h0 = 0.0 + f * (k1 - v), h1 = f * (v - k0), h2, h3;
+    double hh0 = h0, hh1 = h1, hh2;
+    f = mdiv(hh0, t->d[2], t->r[2]);
+    h0 = 0.0 + f * (k1 - v);
+    h1 = f * (v - tm1);
+    f = mdiv(hh1, t->d[3], t->r[3]);
+    h1 = h1 + f * (k2 - v);
+    h2 = f * (v - k0);
+    hh0 = h0; hh1 = h1; hh2 = h2;
+    f = mdiv(hh0, t->d[4], t->r[4]);
+    h0 = 0.0 + f * (k1 - v);
+    h1 = f * (v - tm2);
+    f = mdiv(hh1, t->d[5], t->r[5]);
+    h1 = h1 + f * (k2 - v);
+    h2 = f * (v - tm1);
+    f = mdiv(hh2, t->d[6], t->r[6]);
+    h2 = h2 + f * (k3 - v);
+    h3 = f * (v - k0);
+    w[0] = h0; w[1] = h1; w[2] = h2; w[3] = h3;
+}
+// (jx, jy): the wave's cell, in scalar registers; x, y: per lane, clamped by locate() already
+__device__ __forceinline__ void lookup_uniform(const FieldDev<double>& F, int jx, int jy, double x, double y, double& n, double& gx, double& gy) {
+    AxisTabS tx = (AxisTabS)(F.rdx) + jx, ty = (AxisTabS)(F.rdy) + jy;
+    asm volatile("" : "+s"(tx), "+s"(ty));
+    int lx = jx + 2, ly = jy + 2;
+    lx = lx < 3 ? 3 : (lx > F.qx - 1 ? F.qx - 1 : lx);
+    ly = ly < 3 ? 3 : (ly > F.qy - 1 ? F.qy - 1 : ly);
+    typedef const double __attribute__((address_space(4)))* SD;
+    typedef const Pair<double> __attribute__((address_space(4)))* SP;
+    SD zp = (SD)(F.zn) + ((long)jy * F.qx + jx);
+    SP gp = (SP)(F.g) + ((long)(ly - 3) * F.qx + (lx - 3));
+    asm volatile("" : "+s"(zp), "+s"(gp));
+    double lwx[2], lwy[2], wx[4], wy[4];
+    axis_uniform(x, tx, lwx, wx);
+    axis_uniform(y, ty, lwy, wy);
+    double sp = 0.0;
+    sp += zp[0] * lwy[0] * lwx[0];
+    sp += zp[1] * lwy[0] * lwx[1];
+    sp += zp[F.qx] * lwy[1] * lwx[0];
+    sp += zp[F.qx + 1] * lwy[1] * lwx[1];
+    n = sp;
+    double sx = 0.0, sy = 0.0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        SP row = gp + (long)r * F.qx;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const Pair<double> g = row[q];
+            sx += g.x * wy[r] * wx[q];
+            sy += g.y * wy[r] * wx[q];
+        }
+    }
+    gx = sx;
+    gy = sy;
+}
+
 template <typename G>
 __device__ __forceinline__ void n_gradient(const FieldDev<double>& F, G& gather, bool active, double x, double y,
                                            double& n, double& gx, double& gy) {
+    if constexpr (RTMI_EXACT_UNIFORM && G::kUniformWindow) {
+        const unsigned long long live = rt_ballot(active && F.window != 0);     // no lane is asked when the batch does not use the window
+        if (live != 0ull) {
+            double xv = x, yv = y, t0, t1;
+            const int jx = locate(xv, F.qx, F.ax, F.hx, F.bx, F.inv_hx, t0, t1);
+            const int jy = locate(yv, F.qy, F.ay, F.hy, F.by, F.inv_hy, t0, t1);
+            const int lead = __builtin_ctzll(live);
+            const int jx0 = __builtin_amdgcn_readlane(jx, lead), jy0 = __builtin_amdgcn_readlane(jy, lead);
+            if ((rt_ballot(jx != jx0 || jy != jy0) & live) == 0ull) {
+                lookup_uniform(F, jx0, jy0, xv, yv, n, gx, gy);
+                return;
+            }
+        }
+    }
     Cell<double> c;
     ex::field_locate(F, x, y, c);
     double z[4];

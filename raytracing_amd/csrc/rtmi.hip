@@ -121,7 +121,7 @@ struct rtmi_field {
     void* poly_base = nullptr;   // the allocation: the flat-cell map ([flat_pad] of dtype, rt::FieldDev::flat), then the table
     long flat_pad = 0;           // elements from the map's start to the table's
     long flat_cells = 0;         // cells the map marks flat (0: the kernels never look at it)
-    double* rdiv = nullptr;      // [qx][8] then [qy][8]: reciprocals of the knot differences fpbspl divides by (rt_exact.h)
+    double* rdiv = nullptr;      // [qx][24] then [qy][24]: reciprocals of the knot differences fpbspl divides by, knots, differences (rt_exact.h, AxisTab)
     hipStream_t stream = nullptr;
 };
 
@@ -158,7 +158,8 @@ template <typename T> static rt::FieldDev<T> field_dev(const rtmi_field* f, int 
     F.ncx = f->qx - 1;
     F.flat = f->flat_cells > 0 ? (int)f->flat_pad : 0;
     F.rdx = f->rdiv;
-    F.rdy = f->rdiv ? f->rdiv + (size_t)f->qx * 8 : nullptr;
+    F.rdy = f->rdiv ? f->rdiv + (size_t)f->qx * rt::ex::kAxisTab : nullptr;
+    F.window = 0;
     return F;
 }
 
@@ -408,27 +409,26 @@ FpAxis fp_axis_build(const std::vector<double>& x) {
     }
     return A;
 }
-// Per cell index j of an axis: the correctly rounded reciprocals of the seven knot differences rt::ex::axis_exact divides by
-// (same knots by the same operations as the device forms them: x is numpy.linspace as linspace() below restates it; then an
-// IEEE division).  [m][8]: 1/(x[j+1]-x[j]), 1/(k1-k0), 1/(k1-tm1), 1/(k2-k0), 1/(k1-tm2), 1/(k2-tm1), 1/(k3-k0), 0.
-std::vector<double> fp_recip_build(const std::vector<double>& x) {
+// Per cell index j of an axis, rt::ex::kAxisTab = 24 doubles (rt::ex::AxisTab): the correctly rounded reciprocals of the seven knot
+// differences rt::ex::axis_exact divides by (same knots by the same operations as the device forms them: x is numpy.linspace as
+// linspace() below restates it; then an IEEE division) -- 1/(x[j+1]-x[j]), 1/(k1-k0), 1/(k1-tm1), 1/(k2-k0), 1/(k1-tm2),
+// 1/(k2-tm1), 1/(k3-k0), 0 -- then x[j], x[j+1], the six knots tm2 .. k3 and the seven differences (and a 0) in the same order.
+std::vector<double> fp_axis_tab_build(const std::vector<double>& x) {
+    constexpr int S = rt::ex::kAxisTab;
     const int m = (int)x.size();
-    std::vector<double> out((size_t)m * 8, 0.0);
+    std::vector<double> out((size_t)m * S, 0.0);
     auto knot = [&](int l) { return l <= 3 ? x[0] : (l >= m ? x[m - 1] : x[l - 2]); };   // rt::knot3
     for (int j = 0; j < m - 1; j++) {
         int l = j + 2;
         l = l < 3 ? 3 : (l > m - 1 ? m - 1 : l);
         const double tm2 = knot(l - 2), tm1 = knot(l - 1), k0 = knot(l), k1 = knot(l + 1), k2 = knot(l + 2), k3 = knot(l + 3);
-        double* o = &out[(size_t)j * 8];
-        o[0] = 1.0 / (x[j + 1] - x[j]);
-        o[1] = 1.0 / (k1 - k0);
-        o[2] = 1.0 / (k1 - tm1);
-        o[3] = 1.0 / (k2 - k0);
-        o[4] = 1.0 / (k1 - tm2);
-        o[5] = 1.0 / (k2 - tm1);
-        o[6] = 1.0 / (k3 - k0);
+        double* o = &out[(size_t)j * S];
+        const double d[7] = {x[j + 1] - x[j], k1 - k0, k1 - tm1, k2 - k0, k1 - tm2, k2 - tm1, k3 - k0};
+        for (int i = 0; i < 7; i++) { o[i] = 1.0 / d[i]; o[16 + i] = d[i]; }
+        o[8] = x[j]; o[9] = x[j + 1];
+        o[10] = tm2; o[11] = tm1; o[12] = k0; o[13] = k1; o[14] = k2; o[15] = k3;
     }
-    for (int i = 0; i < 8; i++) out[(size_t)(m - 1) * 8 + i] = out[(size_t)(m - 2) * 8 + i];
+    for (int i = 0; i < S; i++) out[(size_t)(m - 1) * S + i] = out[(size_t)(m - 2) * S + i];
     return out;
 }
 std::vector<double> linspace(double a, double b, int n) {
@@ -489,7 +489,7 @@ static int field_finish_impl(rtmi_field* f, double delta) {
                                (float*)f->zn, (float*)f->g, nz);
         HIP_TRY(hipGetLastError());
         {   // reciprocals of the knot differences for the reference-order lookup (rt_exact.h)
-            const std::vector<double> RX = fp_recip_build(linspace(f->ax, f->bx, qx)), RY = fp_recip_build(linspace(f->ay, f->by, qy));
+            const std::vector<double> RX = fp_axis_tab_build(linspace(f->ax, f->bx, qx)), RY = fp_axis_tab_build(linspace(f->ay, f->by, qy));
             HIP_TRY(hipMalloc(&f->rdiv, (RX.size() + RY.size()) * sizeof(double)));
             HIP_TRY(hipMemcpyAsync(f->rdiv, RX.data(), RX.size() * sizeof(double), hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(f->rdiv + RX.size(), RY.data(), RY.size() * sizeof(double), hipMemcpyHostToDevice, st));
@@ -1388,9 +1388,16 @@ static int batch_staging(rtmi_batch* b, size_t bytes, void** out) {
     return RTMI_OK;
 }
 
+// The reference-order lookup's wave-uniform window (rt::ex::lookup_uniform) from three waves per SIMD on: 1024 SIMDs x 64 lanes x 3
+// (FieldDev::window).  RTMI_WINDOW_MIN_RAYS overrides (0: always, a huge number: never) for A/B runs.
+static long window_min_rays() {
+    static const long v = [] { const char* e = getenv("RTMI_WINDOW_MIN_RAYS"); return e ? atol(e) : 196608L; }();
+    return v;
+}
 template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     BatchDev<T> a;
     a.F = field_dev<T>(b->field, b->p.exact_basis);
+    a.F.window = b->R >= window_min_rays() ? 1 : 0;
     const rtmi_params& p = b->p;
     a.K.step = (T)p.step;
     a.K.step2h = (T)(libm_square(p.step) / 2.0);    // numpy scalar step**2 is libm pow (:330); /2 is exact
