@@ -226,8 +226,9 @@ template <typename T> struct FieldDev {
     T ay, hy, by, inv_hy;
     int exact;   // 1: FITPACK's arithmetic with true knots in every cell (see axis_eval)
     // window: 1 when rt::ex::n_gradient may serve a wave whose live lanes share one cell through the scalar cache (lookup_uniform).
-    // Set per batch (batch_dev): it pays from three waves per SIMD on -- a lone wave waits longer for its scalar loads than for
-    // its vector loads (65 536 rays: -4 .. -10 %; 262 144: +17 %; 1 M: +12 .. +26 %, profiles/r04_ab_uniform_window.txt)
+    // Set per batch (batch_dev): it pays from two waves per SIMD on -- a lone wave waits longer for its scalar loads than for its
+    // vector loads (4 096 rays: -11 %; 65 536: -1 .. -10 %; 131 072: +1 .. +4 %; 262 144: +12 %; 1 M: +5 .. +21 %,
+    // profiles/r04_ab_uniform_window.txt)
     int window;
     // poly: [(qy-1)*(qx-1)][kPolyStride] the same three splines as one polynomial per grid cell (rt_polytab.h) -- what the
     // fast-form step methods evaluate (PolyGather below); zn / g serve the reference-order methods and rtmi_field_eval

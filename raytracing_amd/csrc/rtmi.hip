@@ -1388,10 +1388,10 @@ static int batch_staging(rtmi_batch* b, size_t bytes, void** out) {
     return RTMI_OK;
 }
 
-// The reference-order lookup's wave-uniform window (rt::ex::lookup_uniform) from three waves per SIMD on: 1024 SIMDs x 64 lanes x 3
+// The reference-order lookup's wave-uniform window (rt::ex::lookup_uniform) from two waves per SIMD on: 1024 SIMDs x 64 lanes x 2
 // (FieldDev::window).  RTMI_WINDOW_MIN_RAYS overrides (0: always, a huge number: never) for A/B runs.
 static long window_min_rays() {
-    static const long v = [] { const char* e = getenv("RTMI_WINDOW_MIN_RAYS"); return e ? atol(e) : 196608L; }();
+    static const long v = [] { const char* e = getenv("RTMI_WINDOW_MIN_RAYS"); return e ? atol(e) : 131072L; }();
     return v;
 }
 template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
