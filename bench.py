@@ -252,10 +252,11 @@ def main():
                     help="ray order inside the batch: the sorted fan, or a seeded random permutation of it")
     ap.add_argument("--refill-min", type=int, default=0)
     ap.add_argument("--sort", action="store_true", help="sort rays inside the batch by launch cell and angle (sort_rays)")
-    ap.add_argument("--field-path", default="auto", choices=["auto", "lds", "global", "shared"],
+    ap.add_argument("--field-path", default="auto", choices=["auto", "lds", "global", "shared", "window"],
                     help="auto (default): the library's choice (rtmi_params.field_path 0); shared (= lds, its old name): the "
                          "wave-shared lookup -- a wave-uniform cell's polynomial through the scalar cache for the fast-form "
-                         "methods, the LDS tile for the reference-order ones; global: every lane reads for itself")
+                         "methods, the LDS tile for the reference-order ones; window: as shared, the reference-order methods "
+                         "through the scalar cache too (auto's choice from 131 072 rays on); global: every lane reads for itself")
     ap.add_argument("--rec-rows", type=int, default=0, help="rows to allocate (0 = from max_size; full: 3072 for vert)")
     ap.add_argument("--block", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=0,
@@ -348,7 +349,7 @@ def main():
         return rb.Batch(fld, args.method, step, max_size, lim, sc["gamma"], th, sc["start"][0], sc["start"][1],
                         record_stride=stride_, rec_rows=rec_rows_, block_size=args.block,
                         launch_mode=args.mode, refill_min=args.refill_min, slice_steps=args.slice_steps,
-                        field_path={"auto": 0, "global": 1, "lds": 2, "shared": 2}[args.field_path], sort_rays=args.sort,
+                        field_path={"auto": 0, "global": 1, "lds": 2, "shared": 2, "window": 3}[args.field_path], sort_rays=args.sort,
                         lazy_clear=True,    # every pass re-runs the same launch conditions: same rows rewritten
                         keep_n_ray=args.n_ray, reference_order=3 if args.fast_field else 2 if args.fused else int(args.reference_order))
 

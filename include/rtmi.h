@@ -110,8 +110,11 @@ typedef struct {
     int32_t field_path;      /* how a wave gets at the field; identical results.  0 auto; 1 every lane reads for itself
                                 (L1/L2); 2 wave-shared: the fast-form methods read a wave-uniform cell's polynomial through
                                 the scalar cache into scalar registers (lanes in other cells fall back to 1), the
-                                reference-order methods stage a wave-private LDS tile of B-spline coefficients.  Auto: 2 for
-                                the fast-form methods and fp32, 1 for fp64 op3/4/5/9/10/11 and reference_order */
+                                reference-order methods stage a wave-private LDS tile of B-spline coefficients; 3 as 2, but
+                                the reference-order methods read a wave-uniform cell's B-spline window, knots and knot
+                                reciprocals through the scalar cache (a wave in several cells falls back to 1).  Auto: 2 for
+                                the fast-form methods and fp32; for fp64 op3/4/5/7/9/10/11 and reference_order 3 from
+                                131 072 rays on (two waves per SIMD), 1 below */
     int32_t sort_rays;       /* 1: reorder rays inside the batch by launch cell block and angle so that lanes of a wave stay
                                 coherent; every read call still answers in the caller's ray order (see rtmi_device_view.perm) */
     /* optional caller-owned DEVICE buffers (e.g. torch tensors); NULL -> the library allocates */

@@ -1389,7 +1389,8 @@ static int batch_staging(rtmi_batch* b, size_t bytes, void** out) {
 }
 
 // The reference-order lookup's wave-uniform window (rt::ex::lookup_uniform) from two waves per SIMD on: 1024 SIMDs x 64 lanes x 2
-// (FieldDev::window).  RTMI_WINDOW_MIN_RAYS overrides (0: always, a huge number: never) for A/B runs.
+// (FieldDev::window) when rtmi_params.field_path is 0 (auto); 3 asks for it whatever the size, 1 and 2 never use it.
+// RTMI_WINDOW_MIN_RAYS overrides the size (0: always, a huge number: never) for A/B runs.
 static long window_min_rays() {
     static const long v = [] { const char* e = getenv("RTMI_WINDOW_MIN_RAYS"); return e ? atol(e) : 131072L; }();
     return v;
@@ -1397,7 +1398,7 @@ static long window_min_rays() {
 template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     BatchDev<T> a;
     a.F = field_dev<T>(b->field, b->p.exact_basis);
-    a.F.window = b->R >= window_min_rays() ? 1 : 0;
+    a.F.window = (b->p.field_path == 3 || (b->p.field_path == 0 && b->R >= window_min_rays())) ? 1 : 0;
     const rtmi_params& p = b->p;
     a.K.step = (T)p.step;
     a.K.step2h = (T)(libm_square(p.step) / 2.0);    // numpy scalar step**2 is libm pow (:330); /2 is exact
@@ -1516,6 +1517,7 @@ static int batch_kernel_index(const rtmi_batch* b) { return kernel_index(b->p.me
 static bool use_lds_tile(const rtmi_batch* b) {
     if (b->p.field_path == 1) return false;
     if (b->p.field_path == 2) return true;
+    if (b->p.field_path == 3) return !batch_exact(b) || fast_field_order(b->p);     // reference-order methods: the scalar-cache window (FieldDev::window)
     // Measured: the tile build wins for the fast-form methods in every record mode -- op2/op6 at four waves
     // per SIMD 12.5 vs 15.0 ms without recording and 19 vs 24 ms with the full record, op1/7/8 and fp32 by 0-2 %, a
     // shuffled fan 44 vs 50 ms; the reference-order fp64 methods (op3/4/5/9/10/11: 2-74 cost evaluations per step, more
@@ -1629,7 +1631,7 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     ARG_TRY(p->slice_steps >= 0, "rtmi_batch_create: slice_steps must be >= 0");
     ARG_TRY(p->refill_min >= 0 && p->refill_min <= 64, "rtmi_batch_create: refill_min must be in [0, 64]");
     ARG_TRY(p->exact_basis == 0 || p->exact_basis == 1, "rtmi_batch_create: exact_basis must be 0 or 1");
-    ARG_TRY(p->field_path >= 0 && p->field_path <= 2, "rtmi_batch_create: field_path must be 0 (auto), 1 (global) or 2 (LDS tile)");
+    ARG_TRY(p->field_path >= 0 && p->field_path <= 3, "rtmi_batch_create: field_path must be 0 (auto), 1 (global), 2 (wave-shared: LDS tile) or 3 (wave-shared: scalar cache)");
     ARG_TRY(p->sort_rays == 0 || p->sort_rays == 1, "rtmi_batch_create: sort_rays must be 0 or 1");
     ARG_TRY(p->lazy_clear == 0 || p->lazy_clear == 1, "rtmi_batch_create: lazy_clear must be 0 or 1");
     ARG_TRY(p->no_n_ray == 0 || p->no_n_ray == 1, "rtmi_batch_create: no_n_ray must be 0 or 1");

@@ -528,6 +528,44 @@ def test_lds_tile_equals_global_gather(scen, m, shuffle, mode, rb, gpu_fields):
         assert np.array_equal(u, v)
 
 
+@pytest.mark.parametrize("scen,m,shuffle,mode", [("vert_heterogeneous", 7, False, "plain"), ("vert_heterogeneous", 3, False, "plain"),
+                                                 ("vert_heterogeneous", 6, False, "plain"), ("vert_heterogeneous", 9, False, "sliced"),
+                                                 ("vert_heterogeneous", 4, True, "plain"), ("interface", 7, False, "plain"),
+                                                 ("interface", 5, False, "plain"), ("fisheye", 3, False, "plain"),
+                                                 ("vert_heterogeneous", 7, False, "refill"), ("anisotropy", 11, False, "plain"),
+                                                 ("anisotropy", 10, False, "sliced")])
+def test_uniform_window_equals_per_lane_lookup(scen, m, shuffle, mode, rb, gpu_fields, oracle_fields):
+    """field_path 3 -- the reference-order lookup of a wave whose live lanes share one grid cell reads the 4 x 4 (and 2 x 2) coefficient
+    window, the cell's knots, the seven knot differences of each axis and their reciprocals ONCE through the scalar cache
+    (rt::ex::lookup_uniform; auto's choice from 131 072 rays on) -- must give the same bits as field_path 1 (every lane gathers its
+    own window), and both the oracle's: coherent fans (vert: one cell per wave on most steps; interface and fisheye: waves that
+    straddle cells take the per-lane path on those steps), a shuffled batch (never uniform), the refill and sliced schedules, rays
+    that run into the not-a-knot end cells and out of the grid (FITPACK's clamp), op6 with reference_order."""
+    from oracle import rt_oracle as O
+    R = 2000 if m not in (5, 9, 10, 11) else 256
+    lim = LIMITS[scen]
+    if scen == "fisheye":
+        th, x0, y0, step, ms = np.linspace(np.pi / 4, 3 * np.pi / 4, R), 1.0, 0.0, 2 * np.pi / 303, 3040
+    else:
+        th, x0, y0, step, ms = np.linspace(0.06, np.pi / 2, R), -2.0, -2.0, rb.DELTA_S, 30228
+    if shuffle:
+        th = np.random.default_rng(9).permutation(th)
+    if scen == "vert_heterogeneous" and not shuffle and m in (7, 3):
+        lim = (-5.2, 8.2, -5.7, 4.2)          # through the not-a-knot end cells and past the grid's rim (the grid ends 3 units outside the default box)
+    gam = 3 if scen == "anisotropy" else 1
+    out = []
+    for path in (3, 1):
+        b = rb.Batch(gpu_fields(scen), m, step, ms, lim, gam, th, x0, y0, record_stride=8, field_path=path, launch_mode=mode,
+                     reference_order=(m == 6))
+        b.run()
+        out.append((b.d_ray(), b.final(), b.rows()))
+        b.close()
+    for u, v in zip(out[0], out[1]):
+        assert np.array_equal(u, v)
+    o = O.trazar(oracle_fields(scen), m, gam, step, ms, lim, x0, y0, th, record_stride=8, nthreads=16)
+    assert np.array_equal(out[0][0], o["d_ray"]) and np.array_equal(out[0][1], o["final"]) and np.array_equal(out[0][2], o["s_ray"])
+
+
 def test_record_strides_and_edges(rb, gpu_fields):
     F = gpu_fields("vert_heterogeneous")
     lim = LIMITS["vert_heterogeneous"]
