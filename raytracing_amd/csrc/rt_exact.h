@@ -262,6 +262,13 @@ __device__ __forceinline__ void field_combine(const Cell<double>& c, const doubl
 #ifndef RTMI_EXACT_UNIFORM
 #define RTMI_EXACT_UNIFORM 1
 #endif
+// The per-lane fallback reads its 4 x 4 window in this many groups of rows (1: all 36 coefficients in flight, 72 staging registers).
+// fpbisp's sums run row by row anyway -- same order, same bits -- and with the window path in front of it the fallback no longer
+// has to be the fast one, only not to set the kernel's register count: in two groups op3's kernel has 117 instead of 143 vector
+// registers (four waves per SIMD) and is 4.7 % faster, op4 121 / 147, +5.5 %; op5 and op9 lose their scratch; cfg5 +1.6 %, in four
+// groups +2.1 %.  Per method, because the register allocation of the kernels at the 168-register cap answers in its own way:
+// interface x op9 loses 6-12 % with either (profiles/r04_ab_exact_fallback_phases.txt) and keeps the single group.
+constexpr int fallback_phases(int method) { return method == 9 ? 1 : method == 11 ? 4 : 2; }
 struct AxisTab { double r[8]; double t0, t1, tm2, tm1, k0, k1, k2, k3; double d[8]; };   // one cell index of one axis
 static_assert(sizeof(AxisTab) == kAxisTab * sizeof(double), "fp_axis_tab_build writes this layout");
 typedef const AxisTab __attribute__((address_space(4)))* AxisTabS;
@@ -329,7 +336,7 @@ __device__ __forceinline__ void lookup_uniform(const FieldDev<double>& F, int jx
     gy = sy;
 }
 
-template <typename G>
+template <int PH = 1, typename G>
 __device__ __forceinline__ void n_gradient(const FieldDev<double>& F, G& gather, bool active, double x, double y,
                                            double& n, double& gx, double& gy) {
     if constexpr (RTMI_EXACT_UNIFORM && G::kUniformWindow) {
@@ -348,6 +355,42 @@ __device__ __forceinline__ void n_gradient(const FieldDev<double>& F, G& gather,
     }
     Cell<double> c;
     ex::field_locate(F, x, y, c);
+    if constexpr (RTMI_EXACT_UNIFORM && G::kUniformWindow && PH > 1) {
+        // the per-lane gather with the window consumed in groups of rows: fpbisp's sums run row by row anyway (same order, same
+        // bits), and the kernel's register count is no longer set by 72 staging registers of a path a coherent wave rarely takes
+        Cell<double> cc = c;   // an idle lane reads the grid's first window instead of its stale cell (one shared cache line)
+        cc.jx = active ? c.jx : 0; cc.jy = active ? c.jy : 0; cc.lx = active ? c.lx : 3; cc.ly = active ? c.ly : 3;
+        const double* zp = F.zn + (size_t)cc.jy * F.qx + cc.jx;
+        const double z0 = zp[0], z1 = zp[1], z2 = zp[F.qx], z3 = zp[F.qx + 1];
+        const Pair<double>* gp = reinterpret_cast<const Pair<double>*>(F.g) + ((size_t)(cc.ly - 3) * F.qx + (cc.lx - 3));
+        constexpr int ROWS = 4 / PH;
+        double sx = 0.0, sy = 0.0;
+#pragma unroll
+        for (int ph = 0; ph < PH; ph++) {
+            Pair<double> a[ROWS][4];
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) a[r][q] = gp[(size_t)(ph * ROWS + r) * F.qx + q];
+            }
+#pragma unroll
+            for (int r = 0; r < ROWS; r++) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    sx += a[r][q].x * c.wy[ph * ROWS + r] * c.wx[q];
+                    sy += a[r][q].y * c.wy[ph * ROWS + r] * c.wx[q];
+                }
+            }
+            asm volatile("" : "+v"(sx), "+v"(sy) : : "memory");   // the next rows' loads stay behind these sums
+        }
+        double sp = 0.0;
+        sp += z0 * c.lwy[0] * c.lwx[0];
+        sp += z1 * c.lwy[0] * c.lwx[1];
+        sp += z2 * c.lwy[1] * c.lwx[0];
+        sp += z3 * c.lwy[1] * c.lwx[1];
+        n = sp; gx = sx; gy = sy;
+        return;
+    }
     double z[4];
     Pair<double> g[4][4];
     gather.fetch(F, c, active, z, g);
@@ -812,7 +855,7 @@ __device__ __forceinline__ bool ray_step(const FieldDev<double>& F, const Consts
     double fx, fy, fn, fgx, fgy;
     const bool flag = ex::op_advance<METHOD>(k, r, fx, fy);
     if constexpr (IsPoly<G>::value) rt::n_gradient(F, gather, active, fx, fy, fn, fgx, fgy);   // kFastField: the cell's polynomial
-    else ex::n_gradient(F, gather, active, fx, fy, fn, fgx, fgy);
+    else ex::n_gradient<fallback_phases(METHOD)>(F, gather, active, fx, fy, fn, fgx, fgy);
     const double fth = ex::op_angle<METHOD>(k, r, flag, fx, fy, fn, fgx, fgy, i);
     ex::store_update<inline_sincos(METHOD) || IsPoly<G>::value>(k, r, fx, fy, fth, fn, fgx, fgy);   // (IsPoly: op7 with RTMI_ORDER_FAST_FIELD, kFastField)
     return (METHOD == 7 && i <= 2) || !outside(k, r);     // no boundary test in op7's bootstrap rows
