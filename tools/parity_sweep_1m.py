@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Every step method on every scenario at the NORTH-STAR size -- 1 048 576 rays per fan (524 288 for the golden-section methods),
+every 16th row recorded -- against the oracle on every 256th ray (512th for the golden-section methods): step counts, final
+states and recorded rows, per quantity group (bench.parity_relerr).  tools/parity_sweep.py does the same matrix on 4 096-ray fans
+and random rays; this one is what the default schedules, the scalar-cache window and the full-size grids actually run.
+Checker run (tests/ material): the oracle is the measure, never the path."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import parity_relerr                     # noqa: E402
+from raytracing_amd import rt_bench as rb          # noqa: E402
+from oracle import rt_oracle as O                   # noqa: E402
+
+LIM = {"vert_heterogeneous": (-2, 5, -2.5, 1), "fisheye": (-1.5, 1.5, -1.5, 1.5), "interface": (-2, 20, -2, 4),
+       "anisotropy": (-2, 5, -2.5, 1)}
+EXACT = (3, 4, 5, 7, 9, 10, 11)
+GOLDEN = (5, 9, 10, 11)
+
+
+def main():
+    threads = min(O.max_threads(), os.cpu_count() or 1)
+    print(f"# device (default schedule, default field path) vs oracle ({threads} host threads) at full size; tolerance of the north star: 1e-9 relative, step counts exactly")
+    print("# op column: R = rtmi_params.reference_order 1 (op1/2/6/8 in the reference's operation order too; op7 always is)")
+    print(f"{'scenario':19s} {'op':>4s} {'rays':>8s} {'checked':>7s} {'rows':>5s} {'ray-steps':>11s} {'ms/pass':>8s} {'same steps':>10s} {'final':>9s} {'rows/16':>9s} {'bits':>5s}")
+    worst = worst_exact = 0.0
+    all_bits = True
+    t0 = time.time()
+    for scen in ("vert_heterogeneous", "fisheye", "interface", "anisotropy"):
+        key = "vert_heterogeneous" if scen == "anisotropy" else scen
+        F = rb.Field.build(key, LIM[key], rb.DELTA)
+        OF = O.Field(key, LIM[key], rb.DELTA)
+        gam = 3 if scen == "anisotropy" else 1
+        lim = LIM[scen]
+        for m in ((10, 11) if scen == "anisotropy" else range(1, 10)):
+            R = 524288 if m in GOLDEN else 1048576
+            every = 512 if m in GOLDEN else 256
+            if scen == "fisheye":
+                step, ms, x0, y0, th, rows = 2 * np.pi / 303, 3040, 1.0, 0.0, np.linspace(np.pi / 4, 3 * np.pi / 4, R), 0
+            elif scen == "interface":
+                step, ms, x0, y0, th, rows = rb.DELTA_S, 30228, -2.0, -2.0, np.linspace(2 * np.pi / 60, np.pi / 2, R), 600
+            else:
+                step, ms, x0, y0, th, rows = rb.DELTA_S, 30228, -2.0, -2.0, np.linspace(0, np.pi / 2, R), 192
+            sub = slice(0, R, every)
+            o = O.trazar(OF, m, gam, step, ms, lim, x0, y0, th[sub], record_stride=16, rec_rows=rows, nthreads=threads)
+            for ref_order in ((0, 1) if m in (1, 2, 6, 8) else (0,)):
+                b = rb.Batch(F, m, step, ms, lim, gam, th, x0, y0, record_stride=16, rec_rows=rows, reference_order=ref_order, keep_n_ray=False)
+                b.run()
+                b.reset()
+                t1 = time.perf_counter()
+                b.run()
+                dt = (time.perf_counter() - t1) * 1e3
+                d, fin = b.d_ray()[:, sub], b.final()[:, sub]
+                got = b.device_tensors()["s_ray"][:, :, sub].cpu().numpy()
+                steps = int(b.stats()["ray_steps"])
+                b.close()
+                same = d[2] == o["d_ray"][2]
+                ef = parity_relerr(fin[:, same], o["final"][:, same])
+                er = parity_relerr(got[:, :, same], o["s_ray"][:, :, same])
+                bits = bool(np.array_equal(fin, o["final"]) and np.array_equal(got, o["s_ray"]) and np.array_equal(d, o["d_ray"]))
+                want_bits = m in EXACT or ref_order == 1
+                print(f"{scen:19s} {m:3d}{' R'[ref_order]} {R:8d} {len(th[sub]):7d} {got.shape[0]:5d} {steps:11d} {dt:8.2f} {int(same.sum()):10d} {ef:9.1e} {er:9.1e} "
+                      f"{'yes' if bits else ('NO' if want_bits else '-'):>5s}", flush=True)
+                if want_bits:
+                    worst_exact = max(worst_exact, ef, er)
+                    all_bits &= bits
+                else:
+                    worst = max(worst, ef, er)
+        F.close()
+    print(f"# reference-order rows (op3/4/5/7/9/10/11 always, op1/2/6/8 with R): the oracle's bits in every case: {all_bits} "
+          f"(largest difference {worst_exact:.1e}); default of op1/2/6/8: largest difference {worst:.1e}; {time.time() - t0:.0f} s")
+
+
+if __name__ == "__main__":
+    main()
