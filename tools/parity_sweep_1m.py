@@ -45,7 +45,7 @@ def main():
             else:
                 step, ms, x0, y0, th, rows = rb.DELTA_S, 30228, -2.0, -2.0, np.linspace(0, np.pi / 2, R), 192
             sub = slice(0, R, every)
-            o = O.trazar(OF, m, gam, step, ms, lim, x0, y0, th[sub], record_stride=16, rec_rows=rows, nthreads=threads)
+            o = O.trazar(OF, m, gam, step, ms, lim, x0, y0, th[sub], record_stride=16, rec_rows=rows or None, nthreads=threads)
             for ref_order in ((0, 1) if m in (1, 2, 6, 8) else (0,)):
                 b = rb.Batch(F, m, step, ms, lim, gam, th, x0, y0, record_stride=16, rec_rows=rows, reference_order=ref_order, keep_n_ray=False)
                 b.run()
