@@ -300,10 +300,22 @@ __device__ __forceinline__ void axis_uniform(double v, AxisTabS t, double wl[2],
     h3 = f * (v - k0);
     w[0] = h0; w[1] = h1; w[2] = h2; w[3] = h3;
 }
-// (jx, jy): the wave's cell, in scalar registers; x, y: per lane, clamped by locate() already
-__device__ __forceinline__ void lookup_uniform(const FieldDev<double>& F, int jx, int jy, double x, double y, double& n, double& gx, double& gy) {
+// (jx, jy): the cell the wave's first live lane estimates for itself, in scalar registers; x, y: per lane, clamped to the grid
+// (FITPACK's argument clamp, quirk Q4).  The estimate is (int)((x - a) / h); fpbisp's interval search ends in THE cell with
+// t0 <= x < t1 on the true knots -- which are the table entry's t0, t1, so whether the estimate is that cell, for every live lane,
+// is two comparisons per axis against scalars that are loaded anyway (rt::locate, the search itself, is ~25 vector instructions
+// per axis).  False when a live lane is elsewhere (a wave in several cells; an estimate off by one at a knot; the grid's last
+// point, which belongs to the cell on its left; NaN): the caller takes the per-lane path, which searches.
+// CHECK false: (jx, jy) is what every live lane's interval search returned (n_gradient's EST false): nothing to check.
+template <bool CHECK>
+__device__ __forceinline__ bool lookup_uniform(const FieldDev<double>& F, int jx, int jy, unsigned long long live, double x, double y,
+                                               double& n, double& gx, double& gy) {
     AxisTabS tx = (AxisTabS)(F.rdx) + jx, ty = (AxisTabS)(F.rdy) + jy;
     asm volatile("" : "+s"(tx), "+s"(ty));
+    if constexpr (CHECK) {
+        const bool in = tx->t0 <= x && x < tx->t1 && ty->t0 <= y && y < ty->t1;
+        if ((rt_ballot(!in) & live) != 0ull) return false;
+    }
     int lx = jx + 2, ly = jy + 2;
     lx = lx < 3 ? 3 : (lx > F.qx - 1 ? F.qx - 1 : lx);
     ly = ly < 3 ? 3 : (ly > F.qy - 1 ? F.qy - 1 : ly);
@@ -334,22 +346,36 @@ __device__ __forceinline__ void lookup_uniform(const FieldDev<double>& F, int jx
     }
     gx = sx;
     gy = sy;
+    return true;
 }
 
-template <int PH = 1, typename G>
+// EST: the window path's cell from the first live lane's estimate, checked against the table's knots (lookup_uniform), instead of
+// from every lane's interval search and a vote on the result: op7 +3.3 %, op3 +4.4 %, op4 +3.9 %, op6 in reference order +3.8 %,
+// interface op3 +5.7 %; cfg5's kernel, at its register cap, answers with -0.8 % and keeps the search (window_estimates;
+// profiles/r04_ab_uniform_window.txt, last section).
+constexpr bool window_estimates(int method) { return method != 10 && method != 11; }
+template <int PH = 1, bool EST = true, typename G>
 __device__ __forceinline__ void n_gradient(const FieldDev<double>& F, G& gather, bool active, double x, double y,
                                            double& n, double& gx, double& gy) {
     if constexpr (RTMI_EXACT_UNIFORM && G::kUniformWindow) {
         const unsigned long long live = rt_ballot(active && F.window != 0);     // no lane is asked when the batch does not use the window
         if (live != 0ull) {
-            double xv = x, yv = y, t0, t1;
-            const int jx = locate(xv, F.qx, F.ax, F.hx, F.bx, F.inv_hx, t0, t1);
-            const int jy = locate(yv, F.qy, F.ay, F.hy, F.by, F.inv_hy, t0, t1);
             const int lead = __builtin_ctzll(live);
-            const int jx0 = __builtin_amdgcn_readlane(jx, lead), jy0 = __builtin_amdgcn_readlane(jy, lead);
-            if ((rt_ballot(jx != jx0 || jy != jy0) & live) == 0ull) {
-                lookup_uniform(F, jx0, jy0, xv, yv, n, gx, gy);
-                return;
+            if constexpr (EST) {
+                double xv = x < F.ax ? F.ax : x, yv = y < F.ay ? F.ay : y;
+                xv = xv > F.bx ? F.bx : xv;
+                yv = yv > F.by ? F.by : yv;
+                const int jx = (int)((xv - F.ax) * F.inv_hx), jy = (int)((yv - F.ay) * F.inv_hy);
+                int jx0 = __builtin_amdgcn_readlane(jx, lead), jy0 = __builtin_amdgcn_readlane(jy, lead);
+                jx0 = jx0 < 0 ? 0 : (jx0 > F.qx - 2 ? F.qx - 2 : jx0);
+                jy0 = jy0 < 0 ? 0 : (jy0 > F.qy - 2 ? F.qy - 2 : jy0);
+                if (lookup_uniform<true>(F, jx0, jy0, live, xv, yv, n, gx, gy)) return;
+            } else {
+                double xv = x, yv = y, t0, t1;
+                const int jx = locate(xv, F.qx, F.ax, F.hx, F.bx, F.inv_hx, t0, t1);      // clamps in place
+                const int jy = locate(yv, F.qy, F.ay, F.hy, F.by, F.inv_hy, t0, t1);
+                const int jx0 = __builtin_amdgcn_readlane(jx, lead), jy0 = __builtin_amdgcn_readlane(jy, lead);
+                if ((rt_ballot(jx != jx0 || jy != jy0) & live) == 0ull && lookup_uniform<false>(F, jx0, jy0, live, xv, yv, n, gx, gy)) return;
             }
         }
     }
@@ -855,7 +881,7 @@ __device__ __forceinline__ bool ray_step(const FieldDev<double>& F, const Consts
     double fx, fy, fn, fgx, fgy;
     const bool flag = ex::op_advance<METHOD>(k, r, fx, fy);
     if constexpr (IsPoly<G>::value) rt::n_gradient(F, gather, active, fx, fy, fn, fgx, fgy);   // kFastField: the cell's polynomial
-    else ex::n_gradient<fallback_phases(METHOD)>(F, gather, active, fx, fy, fn, fgx, fgy);
+    else ex::n_gradient<fallback_phases(METHOD), window_estimates(METHOD)>(F, gather, active, fx, fy, fn, fgx, fgy);
     const double fth = ex::op_angle<METHOD>(k, r, flag, fx, fy, fn, fgx, fgy, i);
     ex::store_update<inline_sincos(METHOD) || IsPoly<G>::value>(k, r, fx, fy, fth, fn, fgx, fgy);   // (IsPoly: op7 with RTMI_ORDER_FAST_FIELD, kFastField)
     return (METHOD == 7 && i <= 2) || !outside(k, r);     // no boundary test in op7's bootstrap rows
