@@ -114,7 +114,8 @@ typedef struct {
                                 the reference-order methods read a wave-uniform cell's B-spline window, knots and knot
                                 reciprocals through the scalar cache (a wave in several cells falls back to 1).  Auto: 2 for
                                 the fast-form methods and fp32; for fp64 op3/4/5/7/9/10/11 and reference_order 3 from
-                                131 072 rays on (two waves per SIMD), 1 below */
+                                131 072 rays on (two waves per SIMD), 1 below -- and 1 for the golden-section methods when a
+                                step is longer than half a grid cell (measured: the fisheye fan at DELTA_S = 2 pi / 303) */
     int32_t sort_rays;       /* 1: reorder rays inside the batch by launch cell block and angle so that lanes of a wave stay
                                 coherent; every read call still answers in the caller's ray order (see rtmi_device_view.perm) */
     /* optional caller-owned DEVICE buffers (e.g. torch tensors); NULL -> the library allocates */

@@ -1395,10 +1395,22 @@ static long window_min_rays() {
     static const long v = [] { const char* e = getenv("RTMI_WINDOW_MIN_RAYS"); return e ? atol(e) : 131072L; }();
     return v;
 }
+// ... except for the golden-section methods on a fan that enters a new cell on (nearly) every step: the fisheye fan at its calibrated
+// DELTA_S = 2 pi / 303 (two cells per step) runs op9 in 165 ms with the window and 48 without, op5 in 78 / 54 -- the other
+// reference-order methods gain there as everywhere (op3 53 -> 46 ms, op7 37 -> 29, op6 in reference order 40 -> 32), and op5 / op9
+// gain where a wave stays in its cell for several steps (vert_heterogeneous and interface: a quarter of a cell per step).  Measured,
+// not understood: the kernels' vector-instruction counts are the same, the waves wait (profiles/r04q_fisheye_op9_none_pmc_summary.txt,
+// taken with the window on; asking for all of the window's cache lines at once did not change it, profiles/r04_ab_variants_not_kept.txt).
+static bool window_loses(const rtmi_batch* b) {
+    const int m = b->p.method;
+    if (m != 5 && m != 9 && m != 10 && m != 11) return false;
+    const rtmi_field* f = b->field;
+    return std::fabs(b->p.step) > 0.5 * std::fmin(f->hx, f->hy);
+}
 template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     BatchDev<T> a;
     a.F = field_dev<T>(b->field, b->p.exact_basis);
-    a.F.window = (b->p.field_path == 3 || (b->p.field_path == 0 && b->R >= window_min_rays())) ? 1 : 0;
+    a.F.window = (b->p.field_path == 3 || (b->p.field_path == 0 && b->R >= window_min_rays() && !window_loses(b))) ? 1 : 0;
     const rtmi_params& p = b->p;
     a.K.step = (T)p.step;
     a.K.step2h = (T)(libm_square(p.step) / 2.0);    // numpy scalar step**2 is libm pow (:330); /2 is exact
