@@ -354,7 +354,12 @@ __device__ __forceinline__ bool lookup_uniform(const FieldDev<double>& F, int jx
 // interface op3 +5.7 %; cfg5's kernel, at its register cap, answers with -0.8 % and keeps the search (window_estimates;
 // profiles/r04_ab_uniform_window.txt, last section).
 constexpr bool window_estimates(int method) { return method != 10 && method != 11; }
-template <int PH = 1, bool EST = true, typename G>
+// VOTE (with EST): the attempt is abandoned on the lanes' OWN estimates -- a ballot -- before the table entry is asked for: a wave
+// that straddles cells (8 % of a vert fan's steps at most, a third of an interface fan's near the interface) goes to the per-lane path
+// without a scalar load.  vert op7 +1.5 %, op3 +1.5 %, interface op5 +4 %, op7 +2 %; vert op9 -1.5 % (window_votes;
+// profiles/r04_ab_variants_not_kept.txt, call 50, where it was tried as a cure for the fisheye case and was not one).
+constexpr bool window_votes(int method) { return method != 9; }
+template <int PH = 1, bool EST = true, bool VOTE = false, typename G>
 __device__ __forceinline__ void n_gradient(const FieldDev<double>& F, G& gather, bool active, double x, double y,
                                            double& n, double& gx, double& gy) {
     if constexpr (RTMI_EXACT_UNIFORM && G::kUniformWindow) {
@@ -367,9 +372,11 @@ __device__ __forceinline__ void n_gradient(const FieldDev<double>& F, G& gather,
                 yv = yv > F.by ? F.by : yv;
                 const int jx = (int)((xv - F.ax) * F.inv_hx), jy = (int)((yv - F.ay) * F.inv_hy);
                 int jx0 = __builtin_amdgcn_readlane(jx, lead), jy0 = __builtin_amdgcn_readlane(jy, lead);
+                bool others = false;
+                if constexpr (VOTE) others = (rt_ballot(jx != jx0 || jy != jy0) & live) != 0ull;
                 jx0 = jx0 < 0 ? 0 : (jx0 > F.qx - 2 ? F.qx - 2 : jx0);
                 jy0 = jy0 < 0 ? 0 : (jy0 > F.qy - 2 ? F.qy - 2 : jy0);
-                if (lookup_uniform<true>(F, jx0, jy0, live, xv, yv, n, gx, gy)) return;
+                if (!others && lookup_uniform<true>(F, jx0, jy0, live, xv, yv, n, gx, gy)) return;
             } else {
                 double xv = x, yv = y, t0, t1;
                 const int jx = locate(xv, F.qx, F.ax, F.hx, F.bx, F.inv_hx, t0, t1);      // clamps in place
@@ -881,7 +888,7 @@ __device__ __forceinline__ bool ray_step(const FieldDev<double>& F, const Consts
     double fx, fy, fn, fgx, fgy;
     const bool flag = ex::op_advance<METHOD>(k, r, fx, fy);
     if constexpr (IsPoly<G>::value) rt::n_gradient(F, gather, active, fx, fy, fn, fgx, fgy);   // kFastField: the cell's polynomial
-    else ex::n_gradient<fallback_phases(METHOD), window_estimates(METHOD)>(F, gather, active, fx, fy, fn, fgx, fgy);
+    else ex::n_gradient<fallback_phases(METHOD), window_estimates(METHOD), window_votes(METHOD)>(F, gather, active, fx, fy, fn, fgx, fgy);
     const double fth = ex::op_angle<METHOD>(k, r, flag, fx, fy, fn, fgx, fgy, i);
     ex::store_update<inline_sincos(METHOD) || IsPoly<G>::value>(k, r, fx, fy, fth, fn, fgx, fgy);   // (IsPoly: op7 with RTMI_ORDER_FAST_FIELD, kFastField)
     return (METHOD == 7 && i <= 2) || !outside(k, r);     // no boundary test in op7's bootstrap rows
