@@ -2148,8 +2148,11 @@ RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
     // that starts from the launch conditions is timed; once both schedules have a time the faster one is kept.
     const bool fresh = b->launches == 0 && !b->dirty_state;
     // explore: sliced, plain, sliced, plain (a batch's very first run is cold -- clocks, caches, page tables -- so one sample
-    // each would favour whichever ran second); then the smaller of each schedule's best times, slicing kept unless the
-    // plain launch is more than 1 % ahead (it is the schedule that does not depend on how the fan's lengths fall into rounds)
+    // each would favour whichever ran second); then each schedule's SECOND time, slicing kept unless the plain launch is more
+    // than 1 % ahead (it is the schedule that does not depend on how the fan's lengths fall into rounds).  Not the smaller of
+    // the two: a recording kernel runs into the package's power limit within a few passes (2.4 -> 1.7 GHz), so
+    // an early sample flatters the schedule it belongs to -- on one box the plain launch was kept for the headline on the strength
+    // of its second-pass time and then ran 16.3 ms where the sliced one runs 15.3.
     int pick;
     if (b->auto_n[0] + b->auto_n[1] < 4 && b->auto_ms[0] < 1e29) pick = b->auto_n[0] <= b->auto_n[1] ? 0 : 1;
     else pick = b->auto_ms[1] < 0.99 * b->auto_ms[0] ? 1 : 0;
@@ -2164,7 +2167,7 @@ RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
     if (rc == RTMI_OK && fresh && ev) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev->first, ev->second) == hipSuccess) {   // the stream is idle (read_counters)
-            b->auto_ms[pick] = b->auto_n[pick] == 0 ? (double)ms : std::min(b->auto_ms[pick], (double)ms);
+            b->auto_ms[pick] = (double)ms;
             b->auto_n[pick]++;
         }
     }
