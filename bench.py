@@ -6,10 +6,13 @@ synthetic rays per GPU.  N=1 workload: vert_heterogeneous, 1 048 576 rays, op6 (
 fp64, full trajectory record -- the configuration the metric is quoted on (SURVEY.md 8d "north-star run").
 
 Multi-GPU (one process per GPU, no data-path collective -- rays are independent):
-  weak   (default): every rank owns --rays rays of an N-times finer fan, interleaved (ray k*N + rank), so per-GPU
-                    work is fixed and balanced;
-  strong (--total-rays R): the SAME R-ray fan at every N (the north star's 1 048 576 rays at 1/2/4/8 GPUs),
-                    rank r owns rays r, r+N, r+2N, ...
+  strong (default; --total-rays R, R = 1 048 576 unless given): the SAME R-ray fan at every N -- the north star's
+                    "vert_heterogeneous, 1M rays" at 1/2/4/8 GPUs (SURVEY.md 8d) -- rank r owns rays r, r+N, r+2N, ...;
+                    `value`, `ms_per_step` and `scaling: "strong"` of the JSON line are this run's.  For N > 1 the same ranks
+                    then time the weak configuration too (1 048 576 rays per GPU) and report it as the secondary record
+                    `weak` of the same line (--no-weak skips it);
+  weak   (--rays R): every rank owns R rays of an N-times finer fan, interleaved (ray k*N + rank), so per-GPU work is
+                    fixed and balanced; `scaling: "weak"`.
 
   python bench.py --gpus 1 --steps 5 --warmup 1
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -102,6 +105,16 @@ def parity_relerr(a, b):
     return worst
 
 
+def parity_relerr_elementwise(a, b):
+    """The measure of rounds 1-3: max |a - b| / max(|b|, 1), element by element -- an ABSOLUTE 1e-9 for everything below 1 in
+    magnitude (tighter than parity_relerr for a coordinate near 0, looser for p_x ~ 0.05).  Reported beside parity_relerr so
+    that the 1e-9 claim reads the same across rounds; the tests assert both."""
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    if a.size == 0:
+        return 0.0
+    return float(np.max(np.abs(a - b) / np.maximum(np.abs(b), 1.0)))
+
+
 def fan(scen, R_total, rank, world):
     lo, hi = SCEN[scen]["theta"]
     step = (hi - lo) / (R_total - 1)
@@ -156,18 +169,24 @@ def parity_check(args, rb, batch, th, stride, step, max_size, lim):
     d = batch.d_ray()[:, sub]
     fin = batch.final()[:, sub]
 
-    rel = parity_relerr           # per-quantity scales
+    rel, rel_el = parity_relerr, parity_relerr_elementwise           # per-quantity scales; and rounds 1-3's element-wise measure
     steps_equal = bool(np.array_equal(d[2], o["d_ray"][2]))
     same = d[2] == o["d_ray"][2]
     err = max(rel(fin[:, same], o["final"][:, same]), rel(d[:2, same], o["d_ray"][:2, same]))
+    err_el = max(rel_el(fin[:, same], o["final"][:, same]), rel_el(d[:2, same], o["d_ray"][:2, same]))
     out = {"rays": int(len(ths)), "every": args.parity_stride, "steps_equal": steps_equal,
-           "rays_with_equal_steps": int(same.sum()), "max_rel_err": err, "oracle": "oracle/rt_oracle.c (kind: port)"}
+           "rays_with_equal_steps": int(same.sum()), "max_rel_err": err, "max_rel_err_elementwise": err_el,
+           "measures": "max_rel_err: per quantity, relative to that quantity's largest magnitude in the sample; "
+                       "max_rel_err_elementwise: |a-b|/max(|b|,1); both must be below the tolerance",
+           "oracle": "oracle/rt_oracle.c (kind: port)"}
     if want_rows:
         import torch
         s_dev = batch.device_tensors()["s_ray"][:, :, sub]                   # strided view of the device record
         s = s_dev.to(torch.float64).cpu().numpy()
         out["rows_compared"] = int(s.shape[0])
         out["rows_max_rel_err"] = rel(s[:, :, same], o["s_ray"][:, :, same])
+        out["rows_max_rel_err_elementwise"] = rel_el(s[:, :, same], o["s_ray"][:, :, same])
+        err_el = max(err_el, out["rows_max_rel_err_elementwise"])
         # rows past a ray's last written row must read 0 like the reference's np.zeros (RT_bench.py:802)
         last = (d[2] // stride).astype(np.int64)
         tail_ok = all(not s[int(last[k]) + 1:, :, k].any() for k in range(0, len(ths), max(1, len(ths) // 64)))
@@ -175,7 +194,7 @@ def parity_check(args, rb, batch, th, stride, step, max_size, lim):
         err = max(err, out["rows_max_rel_err"])
     tol = 1e-9 if args.dtype == "f64" else None
     out["tolerance"] = tol
-    out["ok"] = bool(tol is None or (steps_equal and err < tol and out.get("rows_beyond_last_are_zero", True)))
+    out["ok"] = bool(tol is None or (steps_equal and err < tol and err_el < tol and out.get("rows_beyond_last_are_zero", True)))
     return out
 
 
@@ -232,9 +251,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--rays", type=int, default=1048576, help="rays per GPU (weak scaling)")
-    ap.add_argument("--total-rays", type=int, default=0,
-                    help="strong scaling: this many rays in total, split over the ranks (0 = weak scaling with --rays per GPU)")
+    ap.add_argument("--rays", type=int, default=None,
+                    help="weak scaling: this many rays per GPU (an N-times finer fan on N GPUs); makes the line's value the weak one")
+    ap.add_argument("--total-rays", type=int, default=None,
+                    help="strong scaling (the default, with 1 048 576): this many rays in total, split over the ranks")
+    ap.add_argument("--no-weak", action="store_true",
+                    help="N > 1, default (strong) run: skip the secondary weak record (1 048 576 rays per GPU on the same ranks)")
     ap.add_argument("--scenario", default="vert_heterogeneous", choices=sorted(SCEN))
     ap.add_argument("--method", type=int, default=None)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
@@ -337,8 +359,12 @@ def main():
     rec_rows = args.rec_rows
     if stride and not rec_rows and args.scenario in ("vert_heterogeneous", "anisotropy"):
         rec_rows = (3072 + stride - 1) // stride     # the fan's longest ray takes 2 938 steps
-    strong = args.total_rays > 0
-    R_total = args.total_rays if strong else args.rays * part_world
+    if args.rays is not None and args.total_rays:
+        sys.exit("bench.py: --rays (weak: per GPU) and --total-rays (strong: in total) exclude each other")
+    # The north-star run is the SAME 1 048 576-ray fan at every N (BASELINE.json's metric: "whole node ... 1M rays"),
+    # so the default line is the strong split; --rays asks for the weak one.
+    strong = args.rays is None
+    R_total = (args.total_rays or 1048576) if strong else args.rays * part_world
     th = fan(args.scenario, R_total, part_rank, part_world)    # rank r owns rays r, r+world, ... of the R_total-ray fan
     R_local = len(th)
     if args.order == "shuffled":
@@ -370,34 +396,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_pass():
-        batch.reset()
+    def one_pass(b):
+        b.reset()
         if args.chunk <= 0:
-            batch.run()
+            b.run()
             return
         # host-stepped: launches of `chunk` steps until no ray is live (checked every `group` launches: the check is a
         # reduction kernel + a host sync, which a real stepping caller would not pay per launch either)
         group = max(1, 256 // args.chunk)
         while True:
-            batch.step(args.chunk, group)          # `group` launches as one hipGraph (rtmi_step_repeat)
-            if batch.stats()["live_rays"] == 0:
+            b.step(args.chunk, group)          # `group` launches as one hipGraph (rtmi_step_repeat)
+            if b.stats()["live_rays"] == 0:
                 break
 
-    # untimed passes: --warmup of them, at least four with --mode auto -- RTMI_LAUNCH_AUTO times two runs under each of its
-    # two schedules (rtmi_params.launch_mode) before it settles on the faster, and that belongs to the warm-up, not to the
-    # timed region
-    untimed = max(args.warmup, 4 if args.mode == "auto" else 1)
-    for _ in range(untimed):
-        one_pass()
-    k0 = batch.stats()                       # kernel time and launches so far (rtmi_stats.*_total survive the resets)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_pass()
-    barrier()
-    dt = time.perf_counter() - t0
-    st = batch.stats()                       # counters of the LAST pass (reset clears them), totals of all
-    assert st["live_rays"] == 0, "a pass ended with live rays"
+    # untimed passes: --warmup of them, at least AUTO_EXPLORE_RUNS with --mode auto -- RTMI_LAUNCH_AUTO times its two schedules
+    # alternately on re-runs of a batch before it settles on one (rtmi_params.launch_mode), and that belongs to the warm-up,
+    # not to the timed region
+    untimed = max(args.warmup, rb.AUTO_EXPLORE_RUNS if args.mode == "auto" else 1)
+
+    def timed_passes(b):
+        """W untimed passes, then EXACTLY --steps passes between barrier + synchronize on both sides.  -> (seconds, stats
+        before, stats after)."""
+        for _ in range(untimed):
+            one_pass(b)
+        k0_ = b.stats()                      # kernel time and launches so far (rtmi_stats.*_total survive the resets)
+        barrier()
+        t0_ = time.perf_counter()
+        for _ in range(args.steps):
+            one_pass(b)
+        barrier()
+        dt_ = time.perf_counter() - t0_
+        st_ = b.stats()                      # counters of the LAST pass (reset clears them), totals of all
+        assert st_["live_rays"] == 0, "a pass ended with live rays"
+        return dt_, k0_, st_
+
+    dt, k0, st = timed_passes(batch)
     steps_per_pass = st["ray_steps"]
     # advance-kernel time per pass: the mean over the K timed passes themselves (HIP events on the batch's stream, folded
     # by the two stats calls around the timed region: no host sync per pass)
@@ -528,11 +561,12 @@ def main():
                                    f"rays, interleaved across ranks), op{args.method}, DELTA_S={step:.12g}, "
                                    f"box={tuple(float(v) for v in lim)}, record={args.record}",
                        "rays_total": R_total, "rays_rank0": R_local, "ray_steps_per_pass_rank0": int(steps_per_pass),
-                       "method": f"op{args.method}", "record": args.record, "n_ray_rows": bool(args.n_ray and stride), "launch_mode": args.mode, "launch_mode_used": mode_used, "auto_fallbacks": int(st["auto_fallbacks"]), "reference_order": 3 if args.fast_field else 2 if args.fused else int(args.reference_order),
+                       "method": f"op{args.method}", "record": args.record, "n_ray_rows": bool(args.n_ray and stride), "launch_mode": args.mode, "launch_mode_used": mode_used, "auto_fallbacks": int(st["auto_fallbacks"]), "retraced": int(st["retraced"]), "retrace_overflow": int(st["retrace_overflow"]), "reference_order": 3 if args.fast_field else 2 if args.fused else int(args.reference_order),
                        "ray_order": args.order, "sort_rays": bool(args.sort), "field_path": args.field_path,
                        "steps_per_launch": args.chunk or "all", "parallelism": f"ray-shard x{world}"},
             "roofline": roof,
         }
+        out["config"]["auto_exploration"] = st["auto_exploration"]     # RTMI_LAUNCH_AUTO: both schedules' kernel ms, and the one kept
         if args.emulate_world:
             out["config"]["emulated"] = {"world": part_world, "rank": part_rank,
                                          "note": "one rank's shard of the N-way split, run alone on one GPU"}
@@ -543,10 +577,39 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args, rb, args.cpu_seconds, R_local)
         if args.parity_stride > 0 and args.chunk <= 0:
             out["parity_check"] = parity_check(args, rb, batch, th, stride, step, max_size, lim)
-        print(json.dumps(out), flush=True)
-        if args.parity_stride > 0 and args.chunk <= 0 and not out["parity_check"]["ok"]:
-            parity_failed = True
+            parity_failed = not out["parity_check"]["ok"]
     batch.close()
+
+    # The secondary record of the default N > 1 line: the WEAK configuration on the same ranks -- 1 048 576 rays per GPU of an
+    # N-times finer fan, everything else as above -- timed by the same barrier-bracketed loop.  (Weak scaling has nothing to
+    # lose here: no collective in the timed region, every GPU does the single-GPU job; it is reported so that the driver's
+    # per-GPU figure can be read beside the strong split's.)
+    if strong and world > 1 and not args.no_weak and args.rays is None and not args.emulate_world:
+        weak = {"scaling": "weak", "rays_per_gpu": 1048576, "rays_total": 1048576 * world}
+        try:
+            th_w = fan(args.scenario, 1048576 * world, rank, world)
+            if args.order == "shuffled":
+                th_w = np.random.default_rng(1234 + rank).permutation(th_w)
+            th = th_w                                   # make_batch reads `th`
+            bw = make_batch(stride, rec_rows)
+            dt_w, k0_w, st_w = timed_passes(bw)
+            dt_w = rd.max_over_ranks(dt_w, cdev)
+            steps_w = rd.sum_over_ranks(st_w["ray_steps"], cdev) * args.steps
+            weak.update(value=steps_w / dt_w, unit="ray-steps/s", ms_per_step=1e3 * dt_w / args.steps, steps=args.steps,
+                        kernel_ms_per_pass_rank0=(st_w["kernel_ms_total"] - k0_w["kernel_ms_total"]) / args.steps,
+                        launch_mode_used=st_w["launch_mode_used"], auto_exploration=st_w["auto_exploration"])
+            bw.close()
+        except Exception as e:       # the primary (strong) result stands; say what happened to the secondary one
+            weak["error"] = str(e)
+            if use_dist:             # keep the ranks' collectives paired: the failing rank still joins both reductions
+                try:
+                    rd.max_over_ranks(0.0, cdev); rd.sum_over_ranks(0, cdev)
+                except Exception:
+                    pass
+        if rank == 0:
+            out["weak"] = weak
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     fld.close()
     if use_dist:
         dist.barrier()

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RTMI_ABI_VERSION 6
+#define RTMI_ABI_VERSION 7
 
 typedef enum {
     RTMI_OK = 0,
@@ -99,8 +99,10 @@ typedef struct {
     int32_t launch_mode;     /* how rtmi_run schedules the loop on the device (rtmi_launch_mode); results are bit-identical in
                                 all of them.  0 = RTMI_LAUNCH_AUTO, the value a zero-initialised struct gets: time-sliced bundles
                                 when the batch has more 256-ray bundles than the device holds resident blocks, else the plain
-                                launch; a batch that is re-run (rtmi_batch_reset + rtmi_run) times each schedule twice and then
-                                keeps the faster (rtmi_stats.launch_mode_used tells which ran) */
+                                launch; a batch that is re-run (rtmi_batch_reset + rtmi_run) is timed RTMI_AUTO_SAMPLES times under
+                                each schedule, interleaved (sliced, plain, plain, sliced, sliced, plain), and then keeps ONE for
+                                good: the plain launch if its median is more than 3 % ahead, else slicing (rtmi_stats.auto_ms /
+                                auto_kept hold the record, launch_mode_used what the last run used) */
     int32_t block_size;      /* 0 -> default */
     int32_t refill_min;      /* RTMI_LAUNCH_REFILL: compact when this many lanes of a wave are idle (0 -> 32) */
     int32_t exact_basis;     /* kept for ABI compatibility (0 or 1; it used to select fpbspl on the true knots), no effect now: the fast-form methods evaluate the
@@ -144,7 +146,20 @@ typedef struct {
                                 critical angle (2.6e-9 on one sampled ray of the 1 M-ray interface fan).  Such rays -- a handful
                                 of a million, running along a sharp interface -- are ill-conditioned in the reference itself
                                 (its rows move 1e-6 for a 1e-12 change of the launch angle): there only the reference-order
-                                forms agree with it to 1e-9 (fused op1/2/6/8: up to 1.9e-8 on 2-6 rays of the 1 M) */
+                                forms agree with it to 1e-9 -- which is why a DEFAULT fp64 op1/2/6/8 batch finds those rays on the way
+                                and re-traces them in reference order by itself (no_retrace below): every ray of a default batch is
+                                within 1e-9 of the reference */
+    int32_t no_retrace;      /* 0 (default): a fused fp64 op1/2/6/8 batch on a field with a sharp transition (cells whose Hessian of n
+                                is large against the size of the grid: the interface scenario; none in fisheye / vert_heterogeneous)
+                                adds up, per ray, the steepness of the cells in which the ray runs nearly ALONG the iso-lines; a ray
+                                whose sum says its trajectory amplifies rounding differences more than ~5e3 times is stopped, queued
+                                and re-traced from its launch conditions in the reference's operation order (a hidden batch of the
+                                same parameters, launched beside the main kernel); its rows and final state replace the fused
+                                ones -- the oracle's bits.  A few hundred rays of a million on the interface fan, within 2 % of
+                                the time; rays are independent (RT_bench.py:807), so no other ray's bits change.  rtmi_run does
+                                this before it returns; after rtmi_step it happens at the next call that reads results (rays handed
+                                over are no longer live, and are then at their END, ahead of the others).  1: never (A/B runs).
+                                rtmi_stats.retraced counts them */
 } rtmi_params;
 
 /* Upload R launch conditions (host pointers; x0/y0 per ray -- pos_x[k], -2 or the fisheye start, :809-813),
@@ -241,6 +256,7 @@ typedef struct {
 /* Raw device pointers for zero-copy consumers (torch / RCCL gather of the read-back). */
 int rtmi_batch_view(rtmi_batch *b, rtmi_device_view *v);
 
+#define RTMI_AUTO_SAMPLES 3   /* timed runs per schedule before RTMI_LAUNCH_AUTO settles (rtmi_params.launch_mode) */
 typedef struct {
     uint64_t ray_steps;      /* sum over rays of the last written row (= sum of d_ray[2]): steps taken since create/reset */
     uint64_t live_rays;      /* rays that would still step */
@@ -255,7 +271,15 @@ typedef struct {
     uint32_t auto_fallbacks;            /* RTMI_LAUNCH_AUTO only: time-sliced launches of this batch that gave up a bounded wait and
                                            were finished by the plain kernel (results unaffected).  Expected 0: a non-zero count is a
                                            scheduler defect signal, and the batch stays on the plain schedule afterwards */
-    uint32_t reserved_;
+    uint32_t auto_kept;                 /* RTMI_LAUNCH_AUTO: 0 while the batch is still exploring (or never had the choice: fewer bundles
+                                           than resident blocks, per-ray steps), else the schedule it keeps: RTMI_LAUNCH_SLICED / _PLAIN */
+    double auto_ms[2][RTMI_AUTO_SAMPLES];   /* the exploration record: kernel time of each timed run under [0] the time-sliced and
+                                           [1] the plain schedule, in the order they were taken; auto_n[k] of them are valid */
+    uint32_t auto_n[2];
+    uint32_t retraced;                  /* critical rays re-traced in reference order since create/reset (rtmi_params.no_retrace) */
+    uint32_t retrace_overflow;          /* ... and rays that qualified but found the hand-over queue full (1/128 of the batch, at least
+                                           256): they stay in the fused form.  Expected 0 */
+    uint64_t retraced_total;            /* re-traced over the batch's whole life */
 } rtmi_stats;
 /* Synchronises the stream, then fills *s. */
 int rtmi_batch_stats(rtmi_batch *b, rtmi_stats *s);
@@ -316,6 +340,11 @@ int rtmi_debug_sincos(int64_t n, const double *x, double *s, double *c);
  * n_gradient :141-156) in every cell; tests compare it bit for bit with the host restatement of the same table. */
 int rtmi_debug_field_lookup(const rtmi_field *f, int64_t npts, const double *x, const double *y, double *n,
                             double *gx, double *gy);
+/* Diagnostic (host only, no device needed): RTMI_LAUNCH_AUTO's rule on a recorded sequence.  Given the kernel times taken so far
+ * under the time-sliced (sliced_ms[ns]) and the plain (plain_ms[np]) schedule, ns, np <= RTMI_AUTO_SAMPLES: *next = the schedule
+ * the next exploration run takes (RTMI_LAUNCH_SLICED / RTMI_LAUNCH_PLAIN; -1 once exploration is over), *decision = the schedule
+ * that would be kept on these samples (medians; the plain launch only if more than 3 % ahead).  Either pointer may be NULL. */
+int rtmi_debug_auto_rule(const double *sliced_ms, int ns, const double *plain_ms, int np, int *next, int *decision);
 
 #ifdef __cplusplus
 }

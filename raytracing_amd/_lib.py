@@ -7,7 +7,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # RTMI_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants in one session)
 LIB_PATH = os.environ.get("RTMI_LIB_PATH") or os.path.join(_HERE, "librtmi.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
+AUTO_SAMPLES = 3        # RTMI_AUTO_SAMPLES (include/rtmi.h)
 # rtmi_launch_mode (include/rtmi.h)
 LAUNCH_AUTO, LAUNCH_REFILL, LAUNCH_SLICED, LAUNCH_PLAIN = 0, 1, 2, 3
 LAUNCH_MODES = {"auto": LAUNCH_AUTO, "refill": LAUNCH_REFILL, "sliced": LAUNCH_SLICED, "plain": LAUNCH_PLAIN, "lane": LAUNCH_PLAIN}
@@ -30,7 +31,7 @@ class Params(C.Structure):
                 ("refill_min", C.c_int32), ("exact_basis", C.c_int32),
                 ("field_path", C.c_int32), ("sort_rays", C.c_int32),
                 ("ext_s_ray", C.c_void_p), ("ext_n_ray", C.c_void_p), ("lazy_clear", C.c_int32), ("no_n_ray", C.c_int32), ("slice_steps", C.c_int32),
-                ("reference_order", C.c_int32)]
+                ("reference_order", C.c_int32), ("no_retrace", C.c_int32)]
 
 
 class DeviceView(C.Structure):
@@ -45,7 +46,9 @@ class Stats(C.Structure):
     _fields_ = [("ray_steps", C.c_uint64), ("live_rays", C.c_uint64), ("kernel_ms", C.c_double),
                 ("launches", C.c_uint32), ("vgprs", C.c_uint32), ("sgprs", C.c_uint32), ("lds_bytes", C.c_uint32),
                 ("launch_mode_used", C.c_uint32), ("kernel_ms_total", C.c_double), ("launches_total", C.c_uint64),
-                ("auto_fallbacks", C.c_uint32), ("reserved_", C.c_uint32)]
+                ("auto_fallbacks", C.c_uint32), ("auto_kept", C.c_uint32),
+                ("auto_ms", (C.c_double * AUTO_SAMPLES) * 2), ("auto_n", C.c_uint32 * 2),
+                ("retraced", C.c_uint32), ("retrace_overflow", C.c_uint32), ("retraced_total", C.c_uint64)]
 
 
 class ShardStats(C.Structure):
@@ -100,6 +103,7 @@ SYMBOLS = {
     "rtmi_shard_destroy": (None, [C.c_void_p]),
     "rtmi_debug_sincos": (C.c_int, [C.c_int64, _dp, _dp, _dp]),
     "rtmi_debug_field_lookup": (C.c_int, [C.c_void_p, C.c_int64] + [_dp] * 5),
+    "rtmi_debug_auto_rule": (C.c_int, [_dp, C.c_int, _dp, C.c_int, _ip, _ip]),
 }
 
 _lib = None
@@ -118,7 +122,15 @@ def _share_torchs_hip_runtime():
     RTMI_NO_PRELOAD=1 skips this (the probe uses it)."""
     import importlib.util
     import sys
-    if os.environ.get("RTMI_NO_PRELOAD") or "torch" in sys.modules:      # torch imported: its runtime is mapped already
+    if os.environ.get("RTMI_NO_PRELOAD"):
+        return
+    if "torch" in sys.modules:
+        # torch imported first: its runtime is mapped once torch has initialised its HIP side; do that before librtmi.so asks
+        # for "libamdhip64.so.7", so that the request is answered by SONAME from torch's copy and not from /opt/rocm
+        try:
+            sys.modules["torch"].cuda.init()
+        except Exception:
+            pass                                   # no device / a CPU-only torch: librtmi's own calls will say so
         return
     try:
         spec = importlib.util.find_spec("torch")                           # locates the package, does not import it
@@ -129,6 +141,35 @@ def _share_torchs_hip_runtime():
     hip = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
     if os.path.exists(hip):
         C.CDLL(hip, mode=C.RTLD_GLOBAL)
+
+
+def mapped_hip_runtimes():
+    """Paths of every libamdhip64 mapped into this process (/proc/self/maps)."""
+    found = []
+    try:
+        with open("/proc/self/maps") as fh:
+            for line in fh:
+                path = line.rsplit(None, 1)[-1] if "/" in line else ""
+                if "libamdhip64" in os.path.basename(path) and path not in found:
+                    found.append(path)
+    except OSError:
+        pass
+    return found
+
+
+def _check_one_hip_runtime():
+    """Two HIP runtimes in one process (a torch wheel built for another ROCm major version, so that the SONAMEs differ, or
+    RTMI_NO_PRELOAD set) fail much later and far from the cause -- "No HIP GPUs are available" from whichever runtime opens the
+    device second.  Say so here, by name, at load time."""
+    import warnings
+    paths = mapped_hip_runtimes()
+    if len({os.path.realpath(p) for p in paths}) > 1:
+        msg = ("raytracing_amd: more than one HIP runtime is mapped into this process (" + ", ".join(paths) + "): librtmi.so and "
+               "torch would each open the device through their own; the second to do so gets 'No HIP GPUs are available'. "
+               "Import raytracing_amd before torch without RTMI_NO_PRELOAD, or use a torch wheel of librtmi's ROCm major version.")
+        if os.environ.get("RTMI_STRICT_RUNTIME"):
+            raise ImportError(msg)
+        warnings.warn(msg, RuntimeWarning, stacklevel=3)
 
 
 def lib():
@@ -142,6 +183,7 @@ def lib():
                 "raytracing_amd has no CPU fallback.")
         _share_torchs_hip_runtime()
         L = C.CDLL(LIB_PATH)
+        _check_one_hip_runtime()
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)  # AttributeError if the library does not export a declared symbol
             fn.restype = res

@@ -716,6 +716,20 @@ template <typename T, int PHASES = RTMI_TILE_PHASES> struct LdsGather {
 template <typename G> struct IsPoly { static constexpr bool value = false; };
 template <typename T, int MODE, bool FLAT> struct PolyGather;
 template <typename T, int MODE, bool FLAT> struct IsPoly<PolyGather<T, MODE, FLAT>> { static constexpr bool value = true; };
+template <typename G> struct ReportsSteep { static constexpr bool value = false; };
+template <typename T, int MODE, bool FLAT> struct ReportsSteep<PolyGather<T, MODE, FLAT>> { static constexpr bool value = RTMI_FLAT_MAP && FLAT && sizeof(T) == 8; };
+// ... and the steepness of the cell (flat-cell map, FlatBits): 0 for every lookup that is not a PolyGather with the map compiled in
+template <typename T, typename G>
+__device__ __forceinline__ void n_gradient(const FieldDev<T>& F, G& gather, bool active, T x, T y, T& n, T& gx, T& gy, float& lam) {
+    if constexpr (IsPoly<G>::value) {
+        gather.lookup_xy(F, active, x, y, n, gx, gy, lam);
+    } else {
+        lam = 0.f;
+        Cell<T> c;
+        field_locate(F, x, y, c);
+        gather.lookup(F, c, active, n, gx, gy);
+    }
+}
 template <typename T, typename G>
 __device__ __forceinline__ void n_gradient(const FieldDev<T>& F, G& gather, bool active, T x, T y, T& n, T& gx, T& gy) {
     if constexpr (IsPoly<G>::value) {
@@ -833,27 +847,48 @@ template <typename T, int SC> __device__ __forceinline__ T poly_bilinear(Quad<T>
 // The arithmetic is poly_bicubic / poly_bilinear on the same numbers either way: the result does not depend on the policy,
 // on the wave mates or on which round served the lane.
 constexpr int kPolyLane = 0, kPolyScalar = 1, kPolyCached = 2;
-// The flat-cell map (FieldDev::flat).  An entry is the cell's constant index, or all-ones bits (a NaN) for an ordinary cell.
+// The flat-cell map (FieldDev::flat).  An entry is the cell's constant index, or -- for an ordinary cell -- a NaN: in fp32 fields
+// all-ones bits; in fp64 fields the high word all ones and the low word the cell's STEEPNESS as float bits (0 for most cells).
+// Steepness (k_polytab; rtmi.hip "critical rays"): lambda = sqrt(|Hessian of n| / n) over the cell, the rate (per unit length) at
+// which a ray running along the iso-lines of a transition that sharp drifts away from its neighbours, kept when it is at least
+// FieldDev-wide lambda_0 (so: only in cells of a SHARP transition -- the interface scenario's sigmoid; no cell of the fisheye or
+// vert_heterogeneous grids).  The fused step kernels add it up over the steps a ray hovers in such cells (Ray::hov) to find the
+// few rays per million whose trajectory amplifies rounding differences past the 1e-9 the path is held to; those are re-traced in
+// the reference's operation order (rtmi.hip, retrace).
 template <typename T> struct FlatBits;
 template <> struct FlatBits<double> { typedef unsigned long long type; };
 template <> struct FlatBits<float> { typedef unsigned type; };
-template <typename T> __device__ __forceinline__ bool flat_entry(typename FlatBits<T>::type b) { return b != ~(typename FlatBits<T>::type)0; }
-// per lane (vector load): the lanes of an incoherent wave, the one-lane-per-point lookups
-template <typename T> __device__ __forceinline__ bool flat_lane(const FieldDev<T>& F, int cell, T& c) {
+template <typename T> __device__ __forceinline__ bool flat_entry(typename FlatBits<T>::type b) {
+    if constexpr (sizeof(T) == 8) return (unsigned)(b >> 32) != 0xffffffffu;
+    else return b != ~(typename FlatBits<T>::type)0;
+}
+template <typename T> __device__ __forceinline__ float steep_of(typename FlatBits<T>::type b) {
+    if constexpr (sizeof(T) == 8) return __builtin_bit_cast(float, (unsigned)b);     // only read when !flat_entry(b)
+    else return 0.f;
+}
+__host__ __device__ inline unsigned long long steep_entry_bits(float lam) {
+    return 0xffffffff00000000ull | (unsigned long long)__builtin_bit_cast(unsigned, lam);
+}
+// per lane (vector load): the lanes of an incoherent wave, the one-lane-per-point lookups.  lam: the cell's steepness (0: none)
+template <typename T> __device__ __forceinline__ bool flat_lane(const FieldDev<T>& F, int cell, T& c, float& lam) {
     typedef typename FlatBits<T>::type B;
     const B b = reinterpret_cast<const B*>(F.poly)[(long)cell - (long)F.flat];
     c = __builtin_bit_cast(T, b);
-    return flat_entry<T>(b);
+    const bool fl = flat_entry<T>(b);
+    lam = fl ? 0.f : steep_of<T>(b);
+    return fl;
 }
 // for a wave-uniform cell, through the scalar cache
-template <typename T> __device__ __forceinline__ bool flat_uniform(const FieldDev<T>& F, int cu, T& c) {
+template <typename T> __device__ __forceinline__ bool flat_uniform(const FieldDev<T>& F, int cu, T& c, float& lam) {
     typedef typename FlatBits<T>::type B;
     typedef const B __attribute__((address_space(4)))* SP;
     SP q = (SP)(F.poly) + ((long)cu - (long)F.flat);
     asm volatile("" : "+s"(q));
     const B b = *q;
     c = __builtin_bit_cast(T, b);
-    return flat_entry<T>(b);
+    const bool fl = flat_entry<T>(b);
+    lam = fl ? 0.f : steep_of<T>(b);
+    return fl;
 }
 // FLAT false: built for fields WITHOUT flat cells (the host knows: rtmi_field::flat_cells) -- the map's tests are not even
 // compiled in.  Left in as run-time tests on a scalar they cost the fisheye fan 4.5 % and the vert fan 1.4 % (register allocation
@@ -894,10 +929,10 @@ template <typename T, int MODE, bool FLAT = true> struct PolyGather {
 #endif
     }
     // one lane, its own cell: the flat-cell rule first (a flat cell's coefficients are never read), else the polynomial
-    static __device__ __forceinline__ void eval_lane(const FieldDev<T>& F, int cell, T u, T v, T& n, T& gx, T& gy) {
+    static __device__ __forceinline__ void eval_lane(const FieldDev<T>& F, int cell, T u, T v, T& n, T& gx, T& gy, float& lam) {
         if (RTMI_FLAT_MAP && FLAT && F.flat) {
             T cf;
-            if (flat_lane(F, cell, cf)) { n = cf; gx = T(0); gy = T(0); return; }
+            if (flat_lane(F, cell, cf, lam)) { n = cf; gx = T(0); gy = T(0); return; }
         }
         eval_lane_poly(F, cell, u, v, n, gx, gy);
     }
@@ -936,18 +971,23 @@ template <typename T, int MODE, bool FLAT = true> struct PolyGather {
     // 304 VGPRs and twice the control flow: cfg2 2.59 vs 2.21 ms, a one-cell-wide fan 2.00 vs 1.86; reloading through the
     // scalar cache with 72 copies into the vector registers (no vmcnt wait behind the trajectory stores): 2.54 vs 2.25 ms.
     int tagA;
+    float lamA;           // CACHED: the kept cell's steepness
     Quad<T> rowsA[NA];
-    __device__ __forceinline__ void init() { tagA = -1; }
+    // Does this lookup report steepness?  Only where the map's tests are compiled in, and only fp64 (the fp32 map has no room
+    // for it and fp32 batches have no reference to be re-traced against).
+    static constexpr bool kSteep = RTMI_FLAT_MAP && FLAT && sizeof(T) == 8;
+    __device__ __forceinline__ void init() { tagA = -1; lamA = 0.f; }
     template <int N> static __device__ __forceinline__ void eval_rows(const Quad<T> (&rows)[N], T u, T v, T& n, T& gx, T& gy) {
         auto row = [&](int k) -> Quad<T> { return rows[N == 9 ? k : 0]; };
         gx = poly_bicubic<T, 2>(row, 0, u, v);
         gy = poly_bicubic<T, 2>(row, 4, u, v);
         n = poly_bilinear<T, 2>(rows[N == 9 ? 8 : 0], u, v);
     }
-    template <int N> static __device__ __forceinline__ void load_rows(Quad<T> (&rows)[N], const FieldDev<T>& F, int cu) {
+    template <int N> static __device__ __forceinline__ void load_rows(Quad<T> (&rows)[N], const FieldDev<T>& F, int cu, float& lam) {
+        lam = 0.f;
         if (RTMI_FLAT_MAP && FLAT && F.flat) {       // a flat cell is kept as the polynomial (b0, 0, ...): eval_rows then gives (b0, 0, 0) exactly
             T cf;
-            if (flat_uniform(F, cu, cf)) {
+            if (flat_uniform(F, cu, cf, lam)) {
 #pragma unroll
                 for (int k = 0; k < N; k++) rows[k] = Quad<T>{T(0), T(0), T(0), T(0)};
                 rows[N == 9 ? 8 : 0].x = cf;
@@ -964,20 +1004,23 @@ template <typename T, int MODE, bool FLAT = true> struct PolyGather {
         // vmcnt(0), which also counts the trajectory stores of the step before
         __builtin_amdgcn_s_waitcnt(0x0F70);
     }
-    __device__ __forceinline__ void lookup_xy(const FieldDev<T>& F, bool active, T x, T y, T& n, T& gx, T& gy) {
+    // lam: the steepness of the cell the lane's point lies in (0 in almost every cell, see FlatBits above), for Ray::hov
+    __device__ __forceinline__ void lookup_xy(const FieldDev<T>& F, bool active, T x, T y, T& n, T& gx, T& gy, float& lam) {
         PolyCell<T> c;
         const unsigned long long live = rt_ballot(active);
         poly_locate(F, x, y, live, c);
+        lam = 0.f;
         if constexpr (CACHED || SCALAR) {
             // no live lane (the step loops leave before this can happen): nothing addresses the table with an idle lane's cell
             if (live == 0ull) { n = T(1); gx = T(0); gy = T(0); return; }
         }
         if constexpr (CACHED) {
             const int cu = __builtin_amdgcn_readlane(c.cell, __builtin_ctzll(live));
-            if (cu != tagA) { load_rows(rowsA, F, cu); tagA = cu; }
+            if (cu != tagA) { load_rows(rowsA, F, cu, lamA); tagA = cu; }
             // every lane evaluates the first live lane's cell in straight-line code; lanes of another cell are redone
             eval_rows(rowsA, c.u, c.v, n, gx, gy);
-            if (active && c.cell != cu) eval_lane(F, c.cell, c.u, c.v, n, gx, gy);
+            lam = lamA;
+            if (active && c.cell != cu) eval_lane(F, c.cell, c.u, c.v, n, gx, gy, lam);
         } else if constexpr (SCALAR) {
             // the first live lane's cell; when every live lane is in it (98 % of a fan's wave-steps) all lanes evaluate its
             // polynomial in straight-line code -- an idle lane too, at its own (u, v) in [0, 1)^2: finite, and nobody reads it
@@ -989,7 +1032,7 @@ template <typename T, int MODE, bool FLAT = true> struct PolyGather {
             if ((rt_ballot(c.cell != cu) & live) == 0ull) {
                 if (RTMI_FLAT_MAP && FLAT && F.flat) {
                     T cf;
-                    if (flat_uniform(F, cu, cf)) { n = cf; gx = T(0); gy = T(0); return; }     // scalar branch: the map entry is wave-uniform
+                    if (flat_uniform(F, cu, cf, lam)) { n = cf; gx = T(0); gy = T(0); return; }     // scalar branch: the map entry is wave-uniform
                 }
                 eval_scalar(p, c.u, c.v, n, gx, gy);
                 return;
@@ -1006,17 +1049,23 @@ template <typename T, int MODE, bool FLAT = true> struct PolyGather {
                     asm volatile("" : "+s"(p));
                     if (c.cell == cu) {
                         T cf;
-                        if (RTMI_FLAT_MAP && FLAT && F.flat && flat_uniform(F, cu, cf)) { n = cf; gx = T(0); gy = T(0); }
+                        float lu = 0.f;
+                        if (RTMI_FLAT_MAP && FLAT && F.flat && flat_uniform(F, cu, cf, lu)) { n = cf; gx = T(0); gy = T(0); }
                         else eval_scalar(p, c.u, c.v, n, gx, gy);
+                        lam = lu;
                         todo = false;
                     }
                 }
             }
-            if (todo) eval_lane(F, c.cell, c.u, c.v, n, gx, gy);
+            if (todo) eval_lane(F, c.cell, c.u, c.v, n, gx, gy, lam);
         } else {
             n = T(1); gx = T(0); gy = T(0);          // what an idle lane steps on with (finite; nobody reads its state)
-            if (active) eval_lane(F, c.cell, c.u, c.v, n, gx, gy);
+            if (active) eval_lane(F, c.cell, c.u, c.v, n, gx, gy, lam);
         }
+    }
+    __device__ __forceinline__ void lookup_xy(const FieldDev<T>& F, bool active, T x, T y, T& n, T& gx, T& gy) {
+        float lam;
+        lookup_xy(F, active, x, y, n, gx, gy, lam);
     }
 };
 
@@ -1034,6 +1083,10 @@ template <typename T> struct Ray {
     Acc dsim, dreal, tt;     // simulated / expected arclength, traveltime (accumulators)
     T mx, my;                // momenta of the current row (output only)
     T hx0, hy0, hx1, hy1;    // op7: the two positions before (x,y), oldest first (VECTOR_LIST, Q11)
+    float hov;               // fused fp64 op1/2/6/8 on a field with steep cells: sum of the steepness of the cells in which the ray
+                             // ran nearly along the iso-lines (hover_update); times DELTA_S it estimates how far the ray's
+                             // trajectory amplifies a rounding difference (ln amp ~ 3.5 + 2.5 hov DELTA_S, calibrated on the
+                             // interface scenario's critical rays) -- past kHoverLimit the ray is re-traced in reference order
 };
 template <typename T> constexpr bool kMixed = !__is_same(T, double);   // fp32 arithmetic on fp64 accumulators
 
@@ -1355,6 +1408,21 @@ inline bool rotates_unit(int method, bool f64) {
 // For op7 rows 1 and 2 are the bootstrap steps (:833-864): first- and second-order backward differences and
 // no boundary test.  Every lane of a wave calls this together (the gather policy may vote); `active` marks
 // the lanes whose ray is really stepping -- an idle lane just evolves a stale, finite state nobody reads.
+// Critical rays.  A ray that runs ALONG a sharp transition of the medium amplifies any rounding difference: at the
+// interface scenario's critical angle a million times (the reference's own rows move 1e-6 for a 1e-12 change of the launch
+// angle), and there a fused step -- ~1e-16 per step from the reference's roundings -- ends up past 1e-9.  Which rays those are
+// cannot be told from the launch conditions, but it shows on the way: they spend hundreds of steps in the few steep cells of the
+// grid (FlatBits: lambda >= lambda_0) heading within 0.1 rad of the iso-lines, where a ray that crosses the transition spends a
+// dozen.  hov adds the cells' steepness over exactly those steps.  (grad n . u)^2 < 0.01 |grad n|^2 with the gradient at the
+// new point and the tangent the step started with: five fp64 instructions, executed only when some lane of the wave is in a
+// steep cell.  Per lane from the ray's own values: independent of wave mates, schedule and partition.
+constexpr float kHoverLimit = 2.0f;      // hov * DELTA_S beyond which a ray is re-traced (amplification ~ 5e3, error ~ 2e-11)
+template <typename T> __device__ __forceinline__ void hover_update(Ray<T>& r, bool active, float lam, T fgx, T fgy) {
+    if (rt_ballot(lam != 0.f) == 0ull) return;
+    const T d = fma_(fgy, r.uy, fgx * r.ux), g2 = fma_(fgy, fgy, fgx * fgx);
+    if (active && lam != 0.f && d * d < T(0.01) * g2) r.hov += lam;
+}
+
 template <typename T, int METHOD, bool ISO, typename G>
 __device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& k, G& gather, bool active, Ray<T>& r, int i) {
     if constexpr (IsExact<T, METHOD>::value) {
@@ -1364,7 +1432,13 @@ __device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& 
     T fn, fgx, fgy;
     T eps;
     const bool flag = op_advance<T, METHOD>(k, r, fx, fy, eps);
-    n_gradient(F, gather, active, (T)fx, (T)fy, fn, fgx, fgy);
+    if constexpr (ReportsSteep<G>::value && RotatesUnit<T, METHOD>::value) {     // fp64 op1/2/6/8 with the flat-cell map compiled in
+        float lam;
+        n_gradient(F, gather, active, (T)fx, (T)fy, fn, fgx, fgy, lam);
+        hover_update(r, active, lam, fgx, fgy);
+    } else {
+        n_gradient(F, gather, active, (T)fx, (T)fy, fn, fgx, fgy);
+    }
     const T frn = rcp_full(fn);
     bool boot = false;
     if (METHOD == 7 && i <= 2) {

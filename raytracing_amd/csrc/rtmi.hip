@@ -2,6 +2,7 @@
 // gfx950 only.  Reference lines are RT_bench.py file:line of neyuru/RayTracing.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -12,6 +13,7 @@
 #include <numeric>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rtmi.h"
@@ -88,6 +90,9 @@ static void gold_sup_derivatives(double gamma, double out[8]) {
 
 // numpy's scalar x**2 calls libm pow(x, 2.0), which is not always the rounded product x*x (it differs by one ulp for
 // ~0.1 % of arguments on glibc 2.35); the exponent is volatile so that no compiler folds the call into a multiply.
+// Steep cells (k_polytab): lambda * (the grid's shorter side) >= kSteepRate.  40: the interface scenario's sigmoid (lambda up
+// to 36 on a 12 x 28 grid) has a band of them 0.07 wide; the fisheye (lambda <= 2, 9 x 9) and vert_heterogeneous (0.2) have none.
+constexpr double kSteepRate = 40.0;
 static double libm_square(double x) {
     volatile double two = 2.0;
     return std::pow(x, two);
@@ -120,7 +125,8 @@ struct rtmi_field {
     void* poly = nullptr;        // [(qy-1)*(qx-1)][rt::kPolyStride] of dtype: one polynomial per cell (rt_polytab.h)
     void* poly_base = nullptr;   // the allocation: the flat-cell map ([flat_pad] of dtype, rt::FieldDev::flat), then the table
     long flat_pad = 0;           // elements from the map's start to the table's
-    long flat_cells = 0;         // cells the map marks flat (0: the kernels never look at it)
+    long flat_cells = 0;         // cells the map marks flat
+    long steep_cells = 0;        // fp64 fields: cells whose map entry carries a steepness (k_polytab); with neither kind the kernels never look at the map
     double* rdiv = nullptr;      // [qx][24] then [qy][24]: reciprocals of the knot differences fpbspl divides by, knots, differences (rt_exact.h, AxisTab)
     hipStream_t stream = nullptr;
 };
@@ -156,7 +162,7 @@ template <typename T> static rt::FieldDev<T> field_dev(const rtmi_field* f, int 
     F.inv_hy = (T)(1.0 / f->hy);
     F.poly = (const T*)f->poly;
     F.ncx = f->qx - 1;
-    F.flat = f->flat_cells > 0 ? (int)f->flat_pad : 0;
+    F.flat = (f->flat_cells > 0 || f->steep_cells > 0) ? (int)f->flat_pad : 0;
     F.rdx = f->rdiv;
     F.rdy = f->rdiv ? f->rdiv + (size_t)f->qx * rt::ex::kAxisTab : nullptr;
     F.window = 0;
@@ -304,12 +310,18 @@ template <typename T> __global__ void k_pack(const double* Z, const double* cdy,
 
 // The per-cell polynomial table (rt_polytab.h): one thread per cell, fp64 conversion, stored in the field's dtype; and the
 // flat-cell map in front of it (rt::poly_cell_flat; thr from the grid's largest gradient-spline coefficient, k_absmax).
+// A cell's STEEPNESS lambda = sqrt(max |Hessian of n| / min n) over its four corners, from the cell's own polynomials: the
+// gradient splines' first derivatives (d/du, d/dv of both, scaled to x and y) are the Hessian the reference's field has there;
+// its infinity norm bounds |w' H w| for every unit w.  A ray that runs along the iso-lines of a transition drifts away from
+// its neighbours like exp(lambda s) on the side where n curves upwards: lambda = 36 per unit length in the interface scenario's
+// sigmoid, 2 at most in the fisheye, 0.2 in vert_heterogeneous.  Kept (as float bits in the map entry's low word, fp64 fields
+// only) when lambda >= lam0 = kSteepRate / (the grid's shorter side): a transition sharp against the size of the scene.
 template <typename T>
 __global__ void k_polytab(const double* Z, const double* cdx, const double* cdy, int qx, int qy, const double* Cx, const double* Lx,
                           const double* Cy, const double* Ly, T* out, T* flatn, const unsigned long long* gmax_bits,
-                          unsigned long long* nflat) {
+                          unsigned long long* nflat, double inv_hx, double inv_hy, double lam0) {
     const int jx = blockIdx.x * blockDim.x + threadIdx.x, jy = blockIdx.y;
-    bool flat = false;
+    bool flat = false, steep = false;
     if (jx < qx - 1 && jy < qy - 1) {
         double c[36];
         rt::poly_cell_convert(Z, cdx, cdy, qx, qy, jx, jy, Cx, Lx, Cy, Ly, c);
@@ -319,10 +331,40 @@ __global__ void k_polytab(const double* Z, const double* cdx, const double* cdy,
         for (int i = 36; i < rt::kPolyStride; i++) o[i] = T(0);
         flat = rt::poly_cell_flat(c, __builtin_bit_cast(double, *gmax_bits) * rt::kPolyFlatRel);
         typedef typename rt::FlatBits<T>::type B;
-        reinterpret_cast<B*>(flatn)[cell] = flat ? __builtin_bit_cast(B, (T)c[32]) : ~(B)0;
+        B entry = flat ? __builtin_bit_cast(B, (T)c[32]) : ~(B)0;
+        if constexpr (sizeof(T) == 8) {
+            if (!flat) {
+                double hmax = 0.0, nmin = INFINITY;
+                for (int corner = 0; corner < 4; corner++) {
+                    const double u = corner & 1, v = corner >> 1;
+                    double H[2][2];     // [spline s: 0 = dn/dx, 1 = dn/dy][0: d/dx, 1: d/dy]
+                    for (int sp = 0; sp < 2; sp++) {
+                        const double* A = c + 16 * sp;      // A[4k + p]: u^p v^k
+                        double du = 0.0, dv = 0.0, vk = 1.0;
+                        for (int k = 0; k < 4; k++) {
+                            du += vk * (A[4 * k + 1] + u * (2.0 * A[4 * k + 2] + u * 3.0 * A[4 * k + 3]));
+                            vk *= v;
+                        }
+                        double up = 1.0;
+                        for (int pq = 0; pq < 4; pq++) {
+                            dv += up * (A[4 + pq] + v * (2.0 * A[8 + pq] + v * 3.0 * A[12 + pq]));
+                            up *= u;
+                        }
+                        H[sp][0] = du * inv_hx; H[sp][1] = dv * inv_hy;
+                    }
+                    hmax = fmax(hmax, fmax(fabs(H[0][0]) + fabs(H[0][1]), fabs(H[1][0]) + fabs(H[1][1])));
+                    nmin = fmin(nmin, c[32] + u * c[33] + v * c[34] + u * v * c[35]);
+                }
+                const double lam = nmin > 0.0 ? sqrt(hmax / nmin) : 0.0;
+                steep = lam >= lam0 && lam < 3.0e38;
+                entry = rt::steep_entry_bits(steep ? (float)lam : 0.f);
+            }
+        }
+        reinterpret_cast<B*>(flatn)[cell] = entry;
     }
-    const unsigned long long votes = rt_ballot(flat);                 // one atomic per wave
+    const unsigned long long votes = rt_ballot(flat), svotes = rt_ballot(steep);                 // one atomic per wave
     if ((threadIdx.x & 63) == 0 && votes) atomicAdd(nflat, (unsigned long long)__popcll(votes));
+    if ((threadIdx.x & 63) == 0 && svotes) atomicAdd(nflat + 1, (unsigned long long)__popcll(svotes));
 }
 // max |v| over two arrays as the bit pattern of a non-negative double (ordered like the integers)
 __global__ void k_absmax(const double* a, const double* b, size_t n, unsigned long long* out) {
@@ -514,19 +556,22 @@ static int field_finish_impl(rtmi_field* f, double delta) {
             f->flat_pad = (long)((ncell + 31) / 32 * 32);
             HIP_TRY(hipMalloc(&f->poly_base, ((size_t)f->flat_pad + ncell * rt::kPolyStride) * esz));
             f->poly = (char*)f->poly_base + (size_t)f->flat_pad * esz;
-            unsigned long long* dcnt = nullptr;      // [0] bits of max |gradient-spline coefficient|, [1] flat cells
-            HIP_TRY(hipMalloc(&dcnt, 2 * sizeof(unsigned long long)));
-            unsigned long long hcnt[2] = {0, 0};
+            unsigned long long* dcnt = nullptr;      // [0] bits of max |gradient-spline coefficient|, [1] flat cells, [2] steep cells
+            HIP_TRY(hipMalloc(&dcnt, 3 * sizeof(unsigned long long)));
+            unsigned long long hcnt[3] = {0, 0, 0};
+            // steep: lambda >= kSteepRate / the grid's shorter side (RTMI_STEEP_RATE overrides, for calibration runs)
+            const double steep_rate = getenv("RTMI_STEEP_RATE") ? atof(getenv("RTMI_STEEP_RATE")) : kSteepRate;
+            const double lam0 = steep_rate / std::fmin(f->bx - f->ax, f->by - f->ay);
             hipError_t e = hipMemsetAsync(dcnt, 0, sizeof(hcnt), st);
             if (e == hipSuccess) {
                 hipLaunchKernelGGL(k_absmax, dim3(256), dim3(256), 0, st, f->dCdx, f->dCdy, nz, dcnt);
                 const dim3 pg((qx - 1 + 63) / 64, qy - 1), pb(64);
                 if (f->dtype == RTMI_F64)
                     hipLaunchKernelGGL(k_polytab<double>, pg, pb, 0, st, f->dZ, f->dCdx, f->dCdy, qx, qy, dCx, dLx, dCy, dLy, (double*)f->poly,
-                                       (double*)f->poly_base, dcnt, dcnt + 1);
+                                       (double*)f->poly_base, dcnt, dcnt + 1, ihx, ihy, lam0);
                 else
                     hipLaunchKernelGGL(k_polytab<float>, pg, pb, 0, st, f->dZ, f->dCdx, f->dCdy, qx, qy, dCx, dLx, dCy, dLy, (float*)f->poly,
-                                       (float*)f->poly_base, dcnt, dcnt + 1);
+                                       (float*)f->poly_base, dcnt, dcnt + 1, ihx, ihy, lam0);
                 e = hipGetLastError();
             }
             if (e == hipSuccess) e = hipMemcpyAsync(hcnt, dcnt, sizeof(hcnt), hipMemcpyDeviceToHost, st);
@@ -534,7 +579,8 @@ static int field_finish_impl(rtmi_field* f, double delta) {
             (void)hipFree(dcnt);
             HIP_TRY(e);
             f->flat_cells = getenv("RTMI_NO_FLAT") ? 0 : (long)hcnt[1];     // RTMI_NO_FLAT=1: A/B without the map
-            if (getenv("RTMI_DEBUG")) fprintf(stderr, "rtmi: field %d x %d: %ld of %zu cells flat\n", qx, qy, (long)hcnt[1], ncell);
+            f->steep_cells = getenv("RTMI_NO_FLAT") ? 0 : (long)hcnt[2];
+            if (getenv("RTMI_DEBUG")) fprintf(stderr, "rtmi: field %d x %d: %ld of %zu cells flat, %ld steep (lambda >= %.3g)\n", qx, qy, (long)hcnt[1], ncell, (long)hcnt[2], lam0);
         }
         HIP_TRY(hipStreamSynchronize(st));  // host vectors / LU buffers go out of scope
         return RTMI_OK;
@@ -724,7 +770,31 @@ template <typename T> struct BatchDev {
     const int* perm;               // sort_rays: slot k holds caller's ray perm[k] (nullptr: identity)
     const T *vstep, *vstep2h;      // per-ray DELTA_S and DELTA_S**2/2 (rtmi_batch_set_per_ray; nullptr: uniform)
     const int* vmax;               // per-ray max_size (same)
+    // Critical rays (rt::hover_update, "retrace" below): hov[R] is the per-ray hover sum (state; nullptr: this batch flags nothing),
+    // hov_limit = rt::kHoverLimit (the sum times DELTA_S beyond which a ray is handed over), rq the hand-over queue in device
+    // memory -- [0] rays pushed so far (also those beyond rq_cap: they stay), [1..] entries (row where the ray stopped << 32 | ray
+    // slot) -- and rq_host the same count in pinned host memory, where the host polls it while the kernel runs.
+    float* hov;
+    float hov_limit;
+    unsigned rq_cap;
+    unsigned long long* rq;
+    unsigned* rq_host;
+    int prio;                      // > 0: the kernel's waves raise their issue priority (the re-trace batch, beside the main kernel)
 };
+
+// A fused ray whose hover sum passed the limit: queue it for the re-trace in reference order and stop it.  False when the
+// queue is full (the ray then carries on in the fused form and is counted: rtmi_stats.retrace_overflow).
+// The entry goes to the coherence point (device scope) and is acknowledged before the count is published to the host, which
+// launches the consumer only after it has read that count: the consumer kernel starts with the entry visible.
+template <typename T> __device__ __forceinline__ bool push_critical(const BatchDev<T>& a, long k, int row) {
+    const unsigned long long slot = atomicAdd(a.rq, 1ull);
+    if (slot >= (unsigned long long)a.rq_cap) return false;
+    __hip_atomic_store(a.rq + 1 + slot, ((unsigned long long)(unsigned)row << 32) | (unsigned long long)(unsigned)k, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
+    __hip_atomic_store(a.rq_host, (unsigned)(slot + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return true;
+}
 
 template <typename T> __device__ __forceinline__ void write_row(const BatchDev<T>& a, long row, long k, const rt::Ray<T>& r) {
     T* p = a.s_ray + (size_t)row * 6 * a.R + k;
@@ -755,10 +825,8 @@ template <> __device__ __forceinline__ void n_gradient_rt<double>(const BatchDev
     else { InitGather<double> gg; rt::n_gradient(a.F, gg, true, x, y, n, gx, gy); }
 }
 
-// initial conditions (:809-826): one lane per ray
-template <typename T> __global__ void k_init(BatchDev<T> a) {
-    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= a.R) return;
+// initial conditions (:809-826) of the ray in slot k
+template <typename T> __device__ __forceinline__ void init_ray(const BatchDev<T>& a, long k) {
     rt::Ray<T> r;
     r.x = a.x0[k]; r.y = a.y0[k]; r.th = a.th0[k];
     n_gradient_rt(a, (T)r.x, (T)r.y, r.n, r.gx, r.gy);
@@ -768,9 +836,16 @@ template <typename T> __global__ void k_init(BatchDev<T> a) {
     a.acc(3)[k] = 0; a.acc(4)[k] = 0; a.acc(5)[k] = 0;
     if (a.has_hist) { a.aux(3)[k] = 0; a.aux(4)[k] = 0; a.aux(5)[k] = 0; a.aux(6)[k] = 0; }
     if (a.rot) { a.unit(0)[k] = r.ux; a.unit(1)[k] = r.uy; }
+    if (a.hov) a.hov[k] = 0.f;
     a.istep[k] = 0;
     a.alive[k] = max_size_of(a, k) > 1;
     if (a.stride && a.rec_rows > 0) write_row(a, 0, k, r);
+}
+// one lane per ray
+template <typename T> __global__ void k_init(BatchDev<T> a) {
+    const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= a.R) return;
+    init_ray(a, k);
 }
 
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -808,7 +883,8 @@ template <bool COH, typename V> __device__ __forceinline__ void st_state(V* p, V
     if constexpr (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else *p = v;
 }
-template <typename T, int METHOD, bool ISO, bool COH = false>
+// HOV: this build keeps the hover sum (critical rays; only the fp64 op1/2/6/8 builds with the flat-cell map compiled in)
+template <typename T, int METHOD, bool ISO, bool COH = false, bool HOV = false>
 __device__ __forceinline__ void load_ray(const BatchDev<T>& a, long k, rt::Ray<T>& r, int& i) {
     r.x = ld_state<COH>(a.acc(0) + k); r.y = ld_state<COH>(a.acc(1) + k); r.th = ld_state<COH>(a.acc(2) + k);
     r.n = ld_state<COH>(a.aux(0) + k); r.gx = ld_state<COH>(a.aux(1) + k); r.gy = ld_state<COH>(a.aux(2) + k);
@@ -822,9 +898,11 @@ __device__ __forceinline__ void load_ray(const BatchDev<T>& a, long k, rt::Ray<T
         r.ux = ld_state<COH>(a.unit(0) + k); r.uy = ld_state<COH>(a.unit(1) + k);
         rt::derive<T, ISO, true>(a.K, r);
     } else rt::derive<T, ISO>(a.K, r);
+    if constexpr (HOV) r.hov = a.hov ? ld_state<COH>(a.hov + k) : 0.f;
+    else r.hov = 0.f;
     i = ld_state<COH>(a.istep + k);
 }
-template <typename T, int METHOD, bool COH = false>
+template <typename T, int METHOD, bool COH = false, bool HOV = false>
 __device__ __forceinline__ void store_ray(const BatchDev<T>& a, long k, const rt::Ray<T>& r, int i, bool alive) {
     st_state<COH>(a.acc(0) + k, r.x); st_state<COH>(a.acc(1) + k, r.y); st_state<COH>(a.acc(2) + k, r.th);
     st_state<COH>(a.aux(0) + k, r.n); st_state<COH>(a.aux(1) + k, r.gx); st_state<COH>(a.aux(2) + k, r.gy);
@@ -833,7 +911,10 @@ __device__ __forceinline__ void store_ray(const BatchDev<T>& a, long k, const rt
         st_state<COH>(a.aux(3) + k, r.hx0); st_state<COH>(a.aux(4) + k, r.hy0);
         st_state<COH>(a.aux(5) + k, r.hx1); st_state<COH>(a.aux(6) + k, r.hy1);
     }
-    if constexpr (rt::RotatesUnit<T, METHOD>::value) { st_state<COH>(a.unit(0) + k, r.ux); st_state<COH>(a.unit(1) + k, r.uy); }
+    if constexpr (rt::RotatesUnit<T, METHOD>::value) {
+        st_state<COH>(a.unit(0) + k, r.ux); st_state<COH>(a.unit(1) + k, r.uy);
+        if constexpr (HOV) { if (a.hov) st_state<COH>(a.hov + k, r.hov); }
+    }
     st_state<COH>(a.istep + k, i);
     st_state<COH>(a.alive + k, (unsigned char)alive);
 }
@@ -844,6 +925,7 @@ template <typename T> __device__ __forceinline__ void idle_ray(const BatchDev<T>
     r.ux = 1; r.uy = 0; r.coef = 1; r.nray = 1; r.rn = 1;
     r.dsim = r.dreal = r.tt = r.mx = r.my = 0;
     r.hx0 = r.hx1 = r.x; r.hy0 = r.hy1 = r.y;
+    r.hov = 0.f;
 }
 
 // Gather policy of a step kernel.  Reference-order methods (rt_exact.h: FITPACK's sums on the B-spline window): the LDS tile
@@ -990,6 +1072,9 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
         until = stride - (i % stride);   // steps until the next recorded row
         row = i / stride;
     }
+    // critical rays: the hover sum's limit in units of steepness (rt::kHoverLimit / DELTA_S); +inf when this batch hands nothing over
+    constexpr bool HOV = rt::ReportsSteep<G>::value && rt::RotatesUnit<T, METHOD>::value;
+    float hov_limit = a.hov_limit / (float)K.step;
     // one DELTA_S step of every lane; false once no lane of the wave is live
     auto one_step = [&]() -> bool {
         if (rt_ballot(alive) == 0ull) return false;
@@ -1013,7 +1098,17 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
                 }
             }
             alive = inside && (i + 1 < max_size);
-            if (!alive) store_ray<T, METHOD, COH>(rare_batch(a), k, r, i, false);
+            if constexpr (HOV) {
+                if (r.hov > hov_limit) {          // a critical ray (rare: a few hundred of a million on the interface fan, none elsewhere)
+                    const BatchDev<T> ab = rare_batch(a);
+                    store_ray<T, METHOD, COH, true>(ab, k, r, i, false);
+                    __builtin_amdgcn_s_waitcnt(0x0F70);
+                    if (push_critical(ab, k, i)) alive = false;          // the re-trace takes it from its launch conditions
+                    else { r.hov = -INFINITY; if (alive) st_state<COH>(ab.alive + k, (unsigned char)1); }   // queue full: carries on, fused
+                    return true;
+                }
+            }
+            if (!alive) store_ray<T, METHOD, COH, HOV>(rare_batch(a), k, r, i, false);
         }
         return true;
     };
@@ -1064,6 +1159,7 @@ template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool NOFLAT = fa
 __global__ __launch_bounds__(256, sizeof(T) == 4 ? RTMI_F32_WAVES : LDS ? (light_method(METHOD) ? RTMI_TILE_WAVES : heavy_method(METHOD) ? 2 : 3) : ((METHOD == 5 || METHOD >= 9) ? RTMI_GOLD_WAVES : RTMI_GLOBAL_WAVES))
 void k_advance(BatchDev<T> a, int nsteps) {
     __shared__ __attribute__((aligned(16))) T lds[kernel_lds_elems<T, METHOD, LDS>()];
+    if (a.prio > 0) __builtin_amdgcn_s_setprio(3);     // the re-trace of a few hundred critical rays beside the main kernel's waves
     advance_bundle<T, METHOD, ISO, LDS, VAR, false, RTMI_TILE_PHASES, NOFLAT>(a, lds, (long)xcd_grouped_block(blockIdx.x, gridDim.x) * blockDim.x, nsteps);
 }
 // The kernel built for FEW waves: a batch of <= 2 waves per SIMD (cfg2's 65 536 rays: one) has nothing to hide a step's
@@ -1091,7 +1187,8 @@ __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, lon
     rt::Consts<T> K = a.K;
     int max_size = a.max_size;
     if (VAR && a.vstep && k < a.R) { K.step = a.vstep[k]; K.step2h = a.vstep2h[k]; K.step2 = K.step2h * T(2); max_size = a.vmax[k]; }
-    if (alive) load_ray<T, METHOD, ISO, COH>(a, k, r, i);
+    constexpr bool HOV = rt::ReportsSteep<decltype(gather)>::value && rt::RotatesUnit<T, METHOD>::value;
+    if (alive) load_ray<T, METHOD, ISO, COH, HOV>(a, k, r, i);
     else idle_ray(a, r);
     // Rows are recorded through the wave-uniform descriptor path (UROW) by every build except the VAR one: the host
     // launches a non-VAR build only while every live ray of the batch is at the same row (always, unless
@@ -1102,7 +1199,7 @@ __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, lon
     // step's row stores to be acknowledged.
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), expcnt and lgkmcnt untouched
     advance_loop<T, METHOD, ISO, decltype(gather), !VAR, COH>(a, K, gather, r, k, i, alive, max_size, nsteps, blk);
-    if (alive) store_ray<T, METHOD, COH>(a, k, r, i, true);
+    if (alive) store_ray<T, METHOD, COH, HOV>(a, k, r, i, true);
     return alive;
 }
 
@@ -1237,6 +1334,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : light_method(METHOD) ? RT
         if constexpr (rt::ex::inline_sincos(rt::base_method(METHOD)) || (METHOD & rt::kFastField) != 0) rt::ex::stage_sincos_tab();
     }
     const bool RECORD = a.stride != 0;
+    constexpr bool RHOV = rt::ReportsSteep<typename GatherOf<T, METHOD, LDS>::type>::value && rt::RotatesUnit<T, METHOD>::value;
     const unsigned lane = threadIdx.x & 63;
     rt::Ray<T> r;
     idle_ray(a, r);
@@ -1258,7 +1356,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : light_method(METHOD) ? RT
                 const long kk = (long)(base + slot);
                 if (kk < a.R && a.alive[kk]) {
                     k = kk;
-                    load_ray<T, METHOD, ISO>(a, k, r, i);
+                    load_ray<T, METHOD, ISO, false, RHOV>(a, k, r, i);
                     until = RECORD ? a.stride - (i % a.stride) : 0;
                     row = RECORD ? i / a.stride : 0;
                     alive = true;
@@ -1286,7 +1384,16 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : light_method(METHOD) ? RT
                     }
                 }
                 alive = inside && (i + 1 < a.max_size);
-                if (!alive) store_ray<T, METHOD>(a, k, r, i, false);
+                if constexpr (RHOV) {
+                    if (r.hov > a.hov_limit / (float)a.K.step) {          // a critical ray: see advance_loop
+                        store_ray<T, METHOD, false, true>(a, k, r, i, false);
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
+                        if (push_critical(a, k, i)) alive = false;
+                        else { r.hov = -INFINITY; if (alive) a.alive[k] = 1; }
+                        continue;
+                    }
+                }
+                if (!alive) store_ray<T, METHOD, false, RHOV>(a, k, r, i, false);
             }
         }
     }
@@ -1357,8 +1464,9 @@ struct rtmi_batch {
     bool dirty_state = false;    // rtmi_batch_set_state ran since create / reset
     // RTMI_LAUNCH_AUTO: kernel time of the last complete run from the launch conditions under each schedule
     // ([0] sliced, [1] plain; < 0: not measured yet), and what the last rtmi_run used
-    double auto_ms[2] = {-1.0, -1.0};
+    double auto_ms[2][RTMI_AUTO_SAMPLES] = {{0, 0, 0}, {0, 0, 0}};
     int auto_n[2] = {0, 0};      // timed runs per schedule so far
+    int auto_kept = -1;          // -1 while exploring; then 0 (sliced) or 1 (plain) for the rest of the batch's life
     double gold_sup[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // gold_sup_derivatives(gamma_step) for op10/op11
     int lat_simds = 0, lat_waves_per_simd = 0;       // SIMDs of the device (CUs x 4); > 0 once known (pick_advance's latency rule)
     int mode_used = RTMI_LAUNCH_PLAIN;
@@ -1371,8 +1479,50 @@ struct rtmi_batch {
     hipGraphExec_t graph_exec = nullptr;
     const void* graph_kfn = nullptr;
     int graph_nsteps = 0, graph_count = 0, graph_block = 0;
+    struct Retrace* rt = nullptr;   // critical rays handed over to a reference-order re-trace (nullptr: this batch hands nothing over)
+    bool is_retrace_sub = false;    // this batch IS such a re-trace batch (owned by another batch's Retrace)
 };
 static void drop_graph(rtmi_batch* b);
+
+// ------------------------------------------------------------------ critical rays: the automatic re-trace in reference order
+// The fused forms of op1/2/6/8 are ~1e-13 from the reference over a whole trajectory -- except on the handful of rays per
+// million that run ALONG a sharp transition of the medium (the interface scenario's critical angle): those amplify a last-bit
+// difference a million times, in the reference itself as much as here, and only the reference's own roundings
+// reproduce its rows to 1e-9.  The fused kernels find them on the way (rt::hover_update: the steepness of the cells in which a
+// ray runs nearly along the iso-lines, added up), stop them and push (row, slot) into a device queue (push_critical); the host,
+// which is waiting for the launch anyway, watches the queue's count in pinned memory and hands the queued rays to a second,
+// hidden batch of the same parameters in RTMI_ORDER_REFERENCE -- chunks of them as they arrive, on a high-priority stream
+// BESIDE the main kernel: a few hundred rays are a few waves, bound by the latency of their own ~4 000 dependent steps, which
+// the main kernel's remaining run time hides.  Rays are independent (RT_bench.py:807), so this changes no other ray's bits;
+// when both have finished k_retrace_scatter copies the re-traced rays' rows and final state over the fused ones.
+// Result: every ray of a default batch is within 1e-9 of the reference, the critical ones bit for bit (the oracle's bits).
+struct Retrace {
+    rtmi_batch* sub = nullptr;            // the hidden reference-order batch: cap + 256 slots (the tail is padding for offset views)
+    unsigned cap = 0;                     // queue entries = slots that can be re-traced per pass
+    unsigned long long* rq = nullptr;     // device: [0] rays pushed, [1 .. cap] entries
+    unsigned* host_count = nullptr;       // pinned host: [0] the count as the kernels publish it, [1..2] scratch for reading rq[0]
+    float* hov = nullptr;                 // device [R]: the main batch's hover sums (ray state)
+    hipStream_t aux = nullptr;            // high priority, non-blocking
+    hipEvent_t ev_main = nullptr, ev_aux = nullptr;
+    unsigned launched = 0;                // slots handed to the sub-batch since the last reset
+    unsigned scattered = 0;               // ... and copied back
+    bool pending = false;                 // advance kernels ran since the queue was last drained
+    unsigned overflow = 0;                // rays that found the queue full this pass (they stay fused)
+    uint64_t total = 0;                   // rays re-traced over the batch's life
+};
+static int retrace_create(rtmi_batch* b, const double* x0, const double* y0, const double* theta0);
+static void retrace_destroy(rtmi_batch* b);
+static int retrace_reset(rtmi_batch* b);
+static int retrace_drain(rtmi_batch* b, bool overlap);
+static bool retrace_wanted(const rtmi_batch* b);
+// every path that reads results first drains the queue (no-op unless kernels ran since)
+#define RETRACE_FLUSH(b)                                             \
+    do {                                                             \
+        if ((b)->rt && (b)->rt->pending) {                           \
+            const int rcf_ = retrace_drain((b), false);              \
+            if (rcf_) return rcf_;                                   \
+        }                                                            \
+    } while (0)
 
 // device scratch owned by the batch (one allocation reused by every read path instead of a hipMalloc/hipFree per call)
 static int batch_staging(rtmi_batch* b, size_t bytes, void** out) {
@@ -1407,6 +1557,11 @@ static bool window_loses(const rtmi_batch* b) {
     const rtmi_field* f = b->field;
     return std::fabs(b->p.step) > 0.5 * std::fmin(f->hx, f->hy);
 }
+// rt::kHoverLimit (RTMI_HOVER_LIMIT overrides it, for calibration runs)
+static float hover_limit() {
+    static const float v = [] { const char* e = getenv("RTMI_HOVER_LIMIT"); return e ? (float)atof(e) : rt::kHoverLimit; }();
+    return v;
+}
 template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     BatchDev<T> a;
     a.F = field_dev<T>(b->field, b->p.exact_basis);
@@ -1431,6 +1586,12 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     a.x0 = b->launch; a.y0 = b->launch + R; a.th0 = b->launch + 2 * R;
     a.perm = b->perm;
     a.vstep = (const T*)b->vstep; a.vstep2h = (const T*)b->vstep2h; a.vmax = b->vmax;
+    a.hov = b->rt ? b->rt->hov : nullptr;
+    a.hov_limit = b->rt ? hover_limit() : INFINITY;
+    a.rq_cap = b->rt ? b->rt->cap : 0u;
+    a.rq = b->rt ? b->rt->rq : nullptr;
+    a.rq_host = b->rt ? b->rt->host_count : nullptr;
+    a.prio = b->is_retrace_sub ? 1 : 0;
     return a;
 }
 
@@ -1556,7 +1717,7 @@ static const void* pick_advance(const rtmi_batch* b) {
     // the VAR build: per-ray DELTA_S / max_size when set, and per-lane row bookkeeping always
     if (b->vstep || !uniform_rows_ok(b))
         return b->p.dtype == RTMI_F64 ? advance_var_fn<double>(batch_kernel_index(b), iso) : advance_var_fn<float>(batch_kernel_index(b), iso);
-    const bool noflat = b->field->flat_cells == 0;      // no flat cell in this field: the builds without the map's tests
+    const bool noflat = b->field->flat_cells == 0 && b->field->steep_cells == 0;      // nothing in this field's map: the builds without its tests
     return b->p.dtype == RTMI_F64 ? advance_fn<double>(batch_kernel_index(b), iso, lds, noflat) : advance_fn<float>(batch_kernel_index(b), iso, lds, noflat);
 }
 // queue entries beyond the implicit first NB: every bundle is pushed back once per slice it survives
@@ -1584,7 +1745,7 @@ static unsigned long long sliced_timeout_ticks(const rtmi_batch* b, int slice) {
 static bool sliced_feasible(const rtmi_batch* b) { return sliced_capacity(b, sliced_steps(b)) <= (1ull << 25); }
 static const void* pick_sliced(const rtmi_batch* b) {
     const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
-    const bool noflat = b->field->flat_cells == 0;
+    const bool noflat = b->field->flat_cells == 0 && b->field->steep_cells == 0;
     return b->p.dtype == RTMI_F64 ? sliced_fn<double>(batch_kernel_index(b), iso, lds, noflat) : sliced_fn<float>(batch_kernel_index(b), iso, lds, noflat);
 }
 static const void* pick_refill(const rtmi_batch* b) {
@@ -1598,6 +1759,7 @@ static int batch_init_state(rtmi_batch* b, bool clear_traj) {
     hipStream_t st = b->stream;
     const size_t R = (size_t)b->R;
     HIP_TRY(hipMemsetAsync(b->counters, 0, 4 * sizeof(unsigned long long), st));
+    if (b->rt) { const int rcr = retrace_reset(b); if (rcr) return rcr; }
     if (clear_traj && b->s_ray) HIP_TRY(hipMemsetAsync(b->s_ray, 0, (size_t)b->p.rec_rows * 6 * R * b->esz, st));
     if (clear_traj && b->n_ray) HIP_TRY(hipMemsetAsync(b->n_ray, 0, (size_t)b->p.rec_rows * R * b->esz, st));
     b->dirty = false;
@@ -1621,6 +1783,7 @@ RTMI_EXPORT void rtmi_batch_destroy(rtmi_batch* b) {
     if (b->h_counters) (void)hipHostFree(b->h_counters);
     if (b->own_s) (void)hipFree(b->s_ray);
     if (b->own_n) (void)hipFree(b->n_ray);
+    retrace_destroy(b);
     drop_graph(b);
     for (auto& e : b->events) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
     delete b;
@@ -1650,6 +1813,7 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
     ARG_TRY(!(p->no_n_ray && p->ext_n_ray), "rtmi_batch_create: no_n_ray set together with ext_n_ray");
     ARG_TRY(p->reference_order >= 0 && p->reference_order <= 3, "rtmi_batch_create: reference_order must be 0 .. 3 (RTMI_ORDER_*)");
     ARG_TRY(!(p->reference_order == RTMI_ORDER_REFERENCE && p->dtype != RTMI_F64), "rtmi_batch_create: reference_order 1 needs an fp64 batch (the reference has no fp32)");
+    ARG_TRY(p->no_retrace == 0 || p->no_retrace == 1, "rtmi_batch_create: no_retrace must be 0 or 1");
     DEVICE_TRY(f, "rtmi_batch_create");
     rtmi_batch* b = new (std::nothrow) rtmi_batch();
     if (!b) return fail(RTMI_ERR_ALLOC, "rtmi_batch_create: host allocation failed");
@@ -1736,6 +1900,10 @@ RTMI_EXPORT int rtmi_batch_create(const rtmi_field* f, const rtmi_params* p, int
             const bool may_slice = b->p.launch_mode == RTMI_LAUNCH_SLICED || (sliced_feasible(b) && (R + 255) / 256 > b->sliced_blocks);
             if (may_slice)
                 HIP_TRY(hipMalloc(&b->sliced_ctl, (4 + sliced_capacity(b, sliced_steps(b))) * sizeof(unsigned long long)));
+        }
+        if (retrace_wanted(b)) {
+            const int rcr = retrace_create(b, x0, y0, theta0);
+            if (rcr) return rcr;
         }
         return batch_init_state(b, true);
     };
@@ -1842,6 +2010,7 @@ template <typename T> __global__ void k_set_state(BatchDev<T> a, const double* s
             a.unit(0)[k] = cs; a.unit(1)[k] = sn;
         }
     }
+    if (a.hov) a.hov[k] = (a.rot && hist && live) ? (float)hist[(size_t)2 * a.R + o] : 0.f;     // the hover sum of a checkpoint (aux4 row 2)
     if (istep) a.istep[k] = istep[o];
     // a checkpoint knows which rays had left the box (a position outside it does not say so: op7's bootstrap rows skip the test)
     a.alive[k] = (live ? live[o] != 0 : true) && a.istep[k] + 1 < max_size_of(a, k);
@@ -1857,7 +2026,7 @@ template <typename T> __global__ void k_get_state(BatchDev<T> a, double* out, in
     for (int q = 0; q < 3; q++) out[(6 + q) * R + o] = a.acc(3 + q)[k];
     double h[4] = {0, 0, 0, 0};
     if (a.has_hist) for (int q = 0; q < 4; q++) h[q] = (double)a.aux(3 + q)[k];
-    else if (a.rot) { h[0] = (double)a.unit(0)[k]; h[1] = (double)a.unit(1)[k]; }
+    else if (a.rot) { h[0] = (double)a.unit(0)[k]; h[1] = (double)a.unit(1)[k]; h[2] = a.hov ? (double)a.hov[k] : 0.0; }
     for (int q = 0; q < 4; q++) out[(9 + q) * R + o] = h[q];
     oi[o] = a.istep[k];
     ol[o] = a.alive[k];
@@ -1902,6 +2071,7 @@ RTMI_EXPORT int rtmi_batch_restore_state(rtmi_batch* b, const double* state9, co
 RTMI_EXPORT int rtmi_batch_get_state(rtmi_batch* b, double* state9, double* hist4, int32_t* istep, uint8_t* alive) {
     ARG_TRY(b, "rtmi_batch_get_state: null");
     DEVICE_TRY(b->field, "rtmi_batch_get_state");
+    RETRACE_FLUSH(b);
     const size_t R = (size_t)b->R;
     void* stg = nullptr;
     int rc = batch_staging(b, 13 * R * sizeof(double) + R * sizeof(int) + R, &stg);
@@ -2023,13 +2193,15 @@ RTMI_EXPORT int rtmi_step_repeat(rtmi_batch* b, int32_t nsteps, int32_t count) {
     if (rc0) return rc0;
     HIP_TRY(hipEventRecord(evp->first, b->stream));
     HIP_TRY(hipGraphLaunch(b->graph_exec, b->stream));
+    if (b->rt) b->rt->pending = true;
     HIP_TRY(hipEventRecord(evp->second, b->stream));
     b->launches += (uint32_t)count; b->total_launches += (uint64_t)count;
     b->mode_used = RTMI_LAUNCH_PLAIN;
     return RTMI_OK;
 }
 
-RTMI_EXPORT int rtmi_step(rtmi_batch* b, int32_t nsteps) {
+// drain: the launch runs every ray to its end (rtmi_run) -- critical rays are re-traced beside it, inside its timing events
+static int step_impl(rtmi_batch* b, int32_t nsteps, bool drain) {
     ARG_TRY(b, "rtmi_step: null");
     ARG_TRY(nsteps > 0, "rtmi_step: nsteps must be > 0");
     DEVICE_TRY(b->field, "rtmi_step");
@@ -2043,11 +2215,16 @@ RTMI_EXPORT int rtmi_step(rtmi_batch* b, int32_t nsteps) {
     if (b->p.dtype == RTMI_F64) launch_advance<double>(b, nsteps);
     else launch_advance<float>(b, nsteps);
     HIP_TRY(hipGetLastError());
+    if (b->rt) {
+        b->rt->pending = true;
+        if (drain) { const int rcd = retrace_drain(b, true); if (rcd) return rcd; }
+    }
     HIP_TRY(hipEventRecord(ev.second, b->stream));
     b->launches++; b->total_launches++;
     b->mode_used = RTMI_LAUNCH_PLAIN;
     return RTMI_OK;
 }
+RTMI_EXPORT int rtmi_step(rtmi_batch* b, int32_t nsteps) { return step_impl(b, nsteps, false); }
 
 static int read_counters(rtmi_batch* b) {
     HIP_TRY(hipMemsetAsync(b->counters, 0, 2 * sizeof(unsigned long long), b->stream));
@@ -2095,6 +2272,11 @@ static int run_sliced(rtmi_batch* b, std::pair<hipEvent_t, hipEvent_t>** evp) {
     if (b->p.dtype == RTMI_F64) launch_sliced<double>(b, slice, capacity);
     else launch_sliced<float>(b, slice, capacity);
     HIP_TRY(hipGetLastError());
+    if (b->rt) {       // critical rays: re-traced beside the launch (the persistent blocks leave room only as they drain: mostly after it)
+        b->rt->pending = true;
+        const int rcd = retrace_drain(b, true);
+        if (rcd) return rcd;
+    }
     HIP_TRY(hipEventRecord(ev->second, b->stream));
     b->launches++; b->total_launches++;
     b->mode_used = RTMI_LAUNCH_SLICED;
@@ -2112,13 +2294,260 @@ static int run_sliced(rtmi_batch* b, std::pair<hipEvent_t, hipEvent_t>** evp) {
 
 static int run_plain(rtmi_batch* b, std::pair<hipEvent_t, hipEvent_t>** evp) {
     // one lane per ray to completion: a single launch covers every remaining row
-    int rc = rtmi_step(b, b->p.max_size);
+    int rc = step_impl(b, b->p.max_size, true);
     if (rc) return rc;
     *evp = &b->events[b->ev_used - 1];
     rc = read_counters(b);
     if (rc) return rc;
     if (b->h_counters[1] != 0) return fail(RTMI_ERR_STATE, "rtmi_run: rays still live after a full-length launch");
     return RTMI_OK;
+}
+
+
+// ------------------------------------------------------------------ critical rays: implementation (see struct Retrace)
+static bool retrace_wanted(const rtmi_batch* b) {
+    const rtmi_params& p = b->p;
+    return !b->is_retrace_sub && !p.no_retrace && p.dtype == RTMI_F64 && b->field->steep_cells > 0 &&
+           (p.reference_order == RTMI_ORDER_DEFAULT || p.reference_order == RTMI_ORDER_FAST_FIELD) &&
+           rt::rotates_unit(p.method, true) && !getenv("RTMI_NO_RETRACE");
+}
+// slots of the queue: a few hundred rays of a million are critical on the interface fan; room for 1/128 of the batch
+static unsigned retrace_capacity(int64_t R) {
+    const int64_t c = (R / 128 + 63) / 64 * 64;
+    return (unsigned)std::min<int64_t>(std::max<int64_t>(c, 256), 65536);
+}
+// slots [lo, hi) of the queue: launch conditions (and per-ray steps) of the queued rays into the sub-batch, initial conditions
+template <typename T>
+__global__ void k_retrace_prepare(BatchDev<T> s, BatchDev<T> m, double* sx0, double* sy0, double* sth0, T* svstep, T* svstep2h, int* svmax,
+                                  const unsigned long long* rq, unsigned lo, unsigned hi) {
+    const unsigned j = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= hi) return;
+    const long k = (long)(rq[1 + j] & 0xffffffffull);
+    if (k >= m.R) { s.alive[j] = 0; s.istep[j] = 0; return; }          // (never expected: an entry is a slot of the main batch)
+    sx0[j] = m.x0[k]; sy0[j] = m.y0[k]; sth0[j] = m.th0[k];
+    if (m.vstep && svstep) { svstep[j] = m.vstep[k]; svstep2h[j] = m.vstep2h[k]; svmax[j] = m.vmax[k]; }
+    init_ray(s, (long)j);
+}
+// ... and back: the re-traced ray's rows and final state over the fused ones.  A row the fused run wrote past the re-traced
+// ray's last row (the two may leave the box a row apart) reads 0 like every row past a ray's end (:802).
+template <typename T>
+__global__ void k_retrace_scatter(BatchDev<T> m, BatchDev<T> s, const unsigned long long* rq, unsigned lo, unsigned hi) {
+    const unsigned j = lo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= hi) return;
+    const unsigned long long e = rq[1 + j];
+    const long k = (long)(e & 0xffffffffull);
+    if (k >= m.R) return;
+    const int fused_last = (int)(e >> 32), si = s.istep[j];
+    if (m.stride) {
+        const long rs = si / m.stride < s.rec_rows - 1 ? si / m.stride : s.rec_rows - 1;       // last recorded row of the re-trace
+        long top = fused_last / m.stride > rs ? fused_last / m.stride : rs;
+        top = top < m.rec_rows - 1 ? top : m.rec_rows - 1;
+        for (long row = blockIdx.y; row <= top; row += gridDim.y) {
+#pragma unroll
+            for (int q = 0; q < 6; q++)
+                m.s_ray[((size_t)row * 6 + q) * m.R + k] = row <= rs ? s.s_ray[((size_t)row * 6 + q) * s.R + j] : T(0);
+            if (m.n_ray) m.n_ray[(size_t)row * m.R + k] = (row <= rs && s.n_ray) ? s.n_ray[(size_t)row * s.R + j] : T(0);
+        }
+    }
+    if (blockIdx.y == 0) {
+        for (int q = 0; q < 6; q++) m.acc(q)[k] = s.acc(q)[j];
+        for (int q = 0; q < 3; q++) m.aux(q)[k] = s.aux(q)[j];
+        if (m.rot) {       // the unit tangent the fused batch carries as state: the reference's own cos / sin of the final angle
+            m.unit(0)[k] = (T)rt::ex::cos_((double)s.acc(2)[j]);
+            m.unit(1)[k] = (T)rt::ex::sin_((double)s.acc(2)[j]);
+        }
+        m.istep[k] = si;
+        m.alive[k] = 0;
+    }
+}
+
+static void retrace_destroy(rtmi_batch* b) {
+    Retrace* t = b->rt;
+    if (!t) return;
+    if (t->aux) (void)hipStreamSynchronize(t->aux);
+    if (t->sub) rtmi_batch_destroy(t->sub);
+    (void)hipFree(t->rq); (void)hipFree(t->hov);
+    if (t->host_count) (void)hipHostFree(t->host_count);
+    if (t->ev_main) (void)hipEventDestroy(t->ev_main);
+    if (t->ev_aux) (void)hipEventDestroy(t->ev_aux);
+    if (t->aux) (void)hipStreamDestroy(t->aux);
+    delete t;
+    b->rt = nullptr;
+}
+
+static int retrace_create(rtmi_batch* b, const double* x0, const double* y0, const double* theta0) {
+    Retrace* t = new (std::nothrow) Retrace();
+    if (!t) return fail(RTMI_ERR_ALLOC, "rtmi_batch_create: host allocation failed");
+    b->rt = t;                                  // rtmi_batch_destroy frees whatever is there if anything below fails
+    t->cap = retrace_capacity(b->R);
+    const size_t Rs = (size_t)t->cap + 256;     // + a block of padding: offset views of the sub-batch read alive[] up to a block past their end
+    HIP_TRY(hipMalloc(&t->rq, (1 + (size_t)t->cap) * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(t->rq, 0, (1 + (size_t)t->cap) * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&t->hov, (size_t)b->R * sizeof(float)));
+    HIP_TRY(hipHostMalloc(&t->host_count, 4 * sizeof(unsigned)));
+    t->host_count[0] = t->host_count[1] = t->host_count[2] = t->host_count[3] = 0;
+    int lo = 0, hi = 0;
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));           // hi is the numerically lowest = highest priority
+    HIP_TRY(hipStreamCreateWithPriority(&t->aux, hipStreamNonBlocking, hi));
+    HIP_TRY(hipEventCreateWithFlags(&t->ev_main, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&t->ev_aux, hipEventDisableTiming));
+    // the hidden batch: same field, method, steps, box and record layout, reference order, one plain launch per chunk
+    rtmi_params ps = b->p;
+    ps.reference_order = RTMI_ORDER_REFERENCE;
+    ps.launch_mode = RTMI_LAUNCH_PLAIN;
+    ps.sort_rays = 0; ps.ext_s_ray = nullptr; ps.ext_n_ray = nullptr; ps.lazy_clear = 1; ps.no_retrace = 1; ps.field_path = 1; ps.block_size = 0;
+    ps.no_n_ray = b->n_ray ? 0 : 1;
+    std::vector<double> hx, hy, ht;
+    try {
+        hx.assign(Rs, x0[0]); hy.assign(Rs, y0[0]); ht.assign(Rs, theta0[0]);    // placeholders: every slot is re-initialised when it is used
+    } catch (const std::exception& e) {
+        return fail(RTMI_ERR_ALLOC, std::string("rtmi_batch_create: ") + e.what());
+    }
+    const int rc = rtmi_batch_create(b->field, &ps, (int64_t)Rs, hx.data(), hy.data(), ht.data(), (void*)t->aux, &t->sub);
+    if (rc) { t->sub = nullptr; return rc; }
+    t->sub->is_retrace_sub = true;
+    HIP_TRY(hipMemsetAsync(t->sub->alive, 0, Rs, t->aux));        // no slot holds a ray yet
+    HIP_TRY(hipStreamSynchronize(t->aux));
+    return RTMI_OK;
+}
+
+// rtmi_batch_reset / create: an empty queue.  A kernel of the pass before may still be publishing counts (rtmi_step is
+// asynchronous): wait for it first.
+static int retrace_reset(rtmi_batch* b) {
+    Retrace* t = b->rt;
+    if (t->pending) HIP_TRY(hipStreamSynchronize(b->stream));
+    HIP_TRY(hipStreamSynchronize(t->aux));
+    HIP_TRY(hipMemsetAsync(t->rq, 0, sizeof(unsigned long long), b->stream));
+    t->host_count[0] = 0;
+    t->launched = t->scattered = 0; t->pending = false; t->overflow = 0;
+    return RTMI_OK;
+}
+
+// queue slots [lo, hi) -> the sub-batch, to completion, on `st`
+static int retrace_launch_chunk(rtmi_batch* b, unsigned lo, unsigned hi, hipStream_t st) {
+    Retrace* t = b->rt;
+    rtmi_batch* sb = t->sub;
+    if (b->vstep && !sb->vstep) {     // the main batch got per-ray steps (rtmi_batch_set_per_ray): the sub-batch needs the arrays too
+        const size_t Rs = (size_t)sb->R;
+        HIP_TRY(hipMalloc(&sb->vstep, Rs * 8)); HIP_TRY(hipMalloc(&sb->vstep2h, Rs * 8)); HIP_TRY(hipMalloc(&sb->vmax, Rs * sizeof(int)));
+        HIP_TRY(hipMemsetAsync(sb->vstep, 0, Rs * 8, st)); HIP_TRY(hipMemsetAsync(sb->vstep2h, 0, Rs * 8, st)); HIP_TRY(hipMemsetAsync(sb->vmax, 0, Rs * sizeof(int), st));
+    }
+    const BatchDev<double> m = batch_dev<double>(b);
+    BatchDev<double> s = batch_dev<double>(sb);
+    const unsigned n = hi - lo;
+    const size_t Rs = (size_t)sb->R;
+    hipLaunchKernelGGL(k_retrace_prepare<double>, dim3((n + 255) / 256), dim3(256), 0, st, s, m, sb->launch, sb->launch + Rs, sb->launch + 2 * Rs,
+                       (double*)sb->vstep, (double*)sb->vstep2h, sb->vmax, (const unsigned long long*)t->rq, lo, hi);
+    HIP_TRY(hipGetLastError());
+    // the advance kernel on an offset view of the sub-batch: slot lo is the view's ray 0 (same pitch R: every array moves by lo)
+    BatchDev<double> v = s;
+    v.st += lo; v.istep += lo; v.alive += lo;
+    if (v.s_ray) v.s_ray += lo;
+    if (v.n_ray) v.n_ray += lo;
+    v.x0 += lo; v.y0 += lo; v.th0 += lo;
+    if (v.vstep) { v.vstep += lo; v.vstep2h += lo; v.vmax += lo; }
+    sb->kfn = pick_advance(sb);
+    int nsteps = sb->p.max_size;
+    void* args[] = {&v, &nsteps};
+    HIP_TRY(hipLaunchKernel(sb->kfn, dim3((n + 255) / 256), dim3(256), args, 0, st));
+    return RTMI_OK;
+}
+
+// Hand the queued rays to the sub-batch and copy the results back.
+// overlap: called between the main kernel's launch and the event that closes its timing -- the host polls the published count
+// while the kernel runs and launches chunks on the high-priority stream beside it; otherwise (a read after rtmi_step) the main
+// stream is drained first and everything runs in order on it.
+static int retrace_drain(rtmi_batch* b, bool overlap) {
+    Retrace* t = b->rt;
+    unsigned count = 0;
+    auto read_count = [&]() -> int {      // the authoritative count (device memory), once the main stream is idle
+        HIP_TRY(hipMemcpyAsync(t->host_count + 2, t->rq, sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        unsigned long long c = 0;
+        memcpy(&c, t->host_count + 2, sizeof c);
+        t->overflow = c > t->cap ? (unsigned)(c - t->cap) : 0u;
+        count = (unsigned)std::min<unsigned long long>(c, t->cap);
+        return RTMI_OK;
+    };
+    std::pair<hipEvent_t, hipEvent_t>* evp = nullptr;
+    if (overlap) {
+        HIP_TRY(hipEventRecord(t->ev_main, b->stream));
+        auto last_change = std::chrono::steady_clock::now();
+        unsigned seen = t->launched;
+        for (;;) {
+            const hipError_t q = hipEventQuery(t->ev_main);
+            if (q != hipSuccess && q != hipErrorNotReady) return fail(RTMI_ERR_HIP, std::string("rtmi_run: ") + hipGetErrorString(q));
+            const bool done = q == hipSuccess;
+            if (done) { const int rc = read_count(); if (rc) return rc; }
+            else { const unsigned hc = *(volatile unsigned*)t->host_count; count = hc < t->cap ? hc : t->cap; }
+            const auto now = std::chrono::steady_clock::now();
+            if (count > seen) { seen = count; last_change = now; }
+            // a chunk: what has arrived once the main kernel is done, a wave's worth, or whatever there is when nothing has come for 100 us
+            if (count > t->launched && (done || count - t->launched >= 64 || now - last_change > std::chrono::microseconds(100))) {
+                const int rc = retrace_launch_chunk(b, t->launched, count, t->aux);
+                if (rc) return rc;
+                t->launched = count;
+            }
+            if (done) break;
+            std::this_thread::sleep_for(std::chrono::microseconds(20));
+        }
+        if (t->launched > t->scattered) {
+            HIP_TRY(hipEventRecord(t->ev_aux, t->aux));
+            HIP_TRY(hipStreamWaitEvent(b->stream, t->ev_aux, 0));
+        }
+    } else {
+        const int rc = read_count();
+        if (rc) return rc;
+        if (count > t->launched) {
+            const int rc2 = next_event_pair(b, &evp);      // this work is advance-kernel time too
+            if (rc2) return rc2;
+            HIP_TRY(hipEventRecord(evp->first, b->stream));
+            const int rc3 = retrace_launch_chunk(b, t->launched, count, b->stream);
+            if (rc3) return rc3;
+            t->launched = count;
+        }
+    }
+    if (t->launched > t->scattered) {
+        const unsigned n = t->launched - t->scattered;
+        const long rows = b->p.record_stride ? (long)b->p.rec_rows : 1;
+        const dim3 g((n + 63) / 64, (unsigned)std::min<long>(rows, 1024)), blk(64);
+        hipLaunchKernelGGL(k_retrace_scatter<double>, g, blk, 0, b->stream, batch_dev<double>(b), batch_dev<double>(t->sub),
+                           (const unsigned long long*)t->rq, t->scattered, t->launched);
+        HIP_TRY(hipGetLastError());
+        t->total += n;
+        t->scattered = t->launched;
+    }
+    if (evp) HIP_TRY(hipEventRecord(evp->second, b->stream));
+    t->pending = false;
+    return RTMI_OK;
+}
+
+// ---- RTMI_LAUNCH_AUTO: which schedule a re-run batch keeps (pure host functions; rtmi_debug_auto_rule exposes them to the tests)
+// Slicing wins by up to 25 % where whole bundles would be dispatched in rounds (cfg3) and loses a few per cent where they would
+// not (the interface fan), so a batch that is re-run from its launch conditions is timed under both.
+// What the samples must survive: a recording kernel runs the package into its power limit within a few passes (2.4 -> 1.7 GHz,
+// DESIGN.md 5.1), so every pass of a fresh batch is a little slower than the one before and a batch's very first pass is cold
+// besides (clocks, caches, page tables).  Hence (a) the two schedules' samples are taken INTERLEAVED and mirrored -- sliced,
+// plain, plain, sliced, sliced, plain: positions 1 4 5 against 2 3 6, so a steady drift weighs on both alike -- never a fresh
+// sample of one against a stale one of the other (round 4 re-timed only the schedule it had kept: on one box the plain launch
+// was kept on the strength of an early sample and then ran 16.3 ms where the sliced one runs 15.3); (b) each schedule is
+// judged by the MEDIAN of its three (the cold pass is the one that falls out); (c) the decision is made once and kept --
+// launch_mode_used no longer changes inside a caller's timed passes; (d) the plain launch is kept only when it is more than
+// 3 % ahead: slicing is the schedule that does not depend on how a fan's lengths fall into dispatch rounds.
+#define RTMI_AUTO_RUNS (2 * RTMI_AUTO_SAMPLES)
+static int auto_next(const int n[2]) {       // 0 sliced, 1 plain, -1: exploration over
+    static const int order[RTMI_AUTO_RUNS] = {0, 1, 1, 0, 0, 1};
+    const int k = n[0] + n[1];
+    return k < RTMI_AUTO_RUNS ? order[k] : -1;
+}
+static double auto_median(const double* v, int n) {
+    double a[RTMI_AUTO_SAMPLES];
+    for (int i = 0; i < n; i++) a[i] = v[i];
+    std::sort(a, a + n);
+    return n == 0 ? 1e30 : (n & 1) ? a[n / 2] : 0.5 * (a[n / 2 - 1] + a[n / 2]);
+}
+static int auto_decide(const double* sliced_ms, int ns, const double* plain_ms, int np) {
+    return auto_median(plain_ms, np) < 0.97 * auto_median(sliced_ms, ns) ? RTMI_LAUNCH_PLAIN : RTMI_LAUNCH_SLICED;
 }
 
 RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
@@ -2135,6 +2564,11 @@ RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
         if (b->p.dtype == RTMI_F64) launch_refill<double>(b);
         else launch_refill<float>(b);
         HIP_TRY(hipGetLastError());
+        if (b->rt) {
+            b->rt->pending = true;
+            const int rcd = retrace_drain(b, true);
+            if (rcd) return rcd;
+        }
         HIP_TRY(hipEventRecord(ev->second, b->stream));
         b->launches++; b->total_launches++;
         b->mode_used = RTMI_LAUNCH_REFILL;
@@ -2143,39 +2577,46 @@ RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
     // per-ray DELTA_S or rays at rows of their own (the VAR build's cases) always run the plain launch
     if (b->p.launch_mode == RTMI_LAUNCH_SLICED) return sliced_ready(b) ? run_sliced(b, &ev) : run_plain(b, &ev);
     if (b->p.launch_mode == RTMI_LAUNCH_PLAIN || !sliced_ready(b)) return run_plain(b, &ev);
-    // RTMI_LAUNCH_AUTO on a batch with more bundles than resident blocks.  Slicing first: it wins by up to 25 % where whole
-    // bundles would be dispatched in rounds (cfg3) and loses a few per cent where they would not.  A run
-    // that starts from the launch conditions is timed; once both schedules have a time the faster one is kept.
+    // RTMI_LAUNCH_AUTO on a batch with more bundles than resident blocks: auto_next / auto_decide above.  Only a run that
+    // starts from the launch conditions is a sample.
     const bool fresh = b->launches == 0 && !b->dirty_state;
-    // explore: sliced, plain, sliced, plain (a batch's very first run is cold -- clocks, caches, page tables -- so one sample
-    // each would favour whichever ran second); then each schedule's SECOND time, slicing kept unless the plain launch is more
-    // than 1 % ahead (it is the schedule that does not depend on how the fan's lengths fall into rounds).  Not the smaller of
-    // the two: a recording kernel runs into the package's power limit within a few passes (2.4 -> 1.7 GHz), so
-    // an early sample flatters the schedule it belongs to -- on one box the plain launch was kept for the headline on the strength
-    // of its second-pass time and then ran 16.3 ms where the sliced one runs 15.3.
-    int pick;
-    if (b->auto_n[0] + b->auto_n[1] < 4 && b->auto_ms[0] < 1e29) pick = b->auto_n[0] <= b->auto_n[1] ? 0 : 1;
-    else pick = b->auto_ms[1] < 0.99 * b->auto_ms[0] ? 1 : 0;
+    int pick = b->auto_kept >= 0 ? b->auto_kept : auto_next(b->auto_n);
+    const bool exploring = b->auto_kept < 0;
     rc = pick == 0 ? run_sliced(b, &ev) : run_plain(b, &ev);
     if (rc == RTMI_ERR_STATE && pick == 0) {
         // the sliced launch gave up a wait (it reports instead of hanging); what it advanced is valid state: finish plainly
-        b->auto_ms[0] = 1e30; b->auto_n[0] = 4;
+        b->auto_kept = 1;
         b->auto_fallbacks++;           // countable (rtmi_stats.auto_fallbacks): a wait-bound trip is a scheduler defect signal
         if (getenv("RTMI_DEBUG")) fprintf(stderr, "rtmi: RTMI_LAUNCH_AUTO: the sliced launch gave up a wait (%s); finishing with the plain kernel\n", g_err.c_str());
         return run_plain(b, &ev);
     }
-    if (rc == RTMI_OK && fresh && ev) {
+    if (rc == RTMI_OK && exploring && fresh && ev) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev->first, ev->second) == hipSuccess) {   // the stream is idle (read_counters)
-            b->auto_ms[pick] = (double)ms;
-            b->auto_n[pick]++;
+            b->auto_ms[pick][b->auto_n[pick]++] = (double)ms;
+            if (auto_next(b->auto_n) < 0) {
+                b->auto_kept = auto_decide(b->auto_ms[0], b->auto_n[0], b->auto_ms[1], b->auto_n[1]) == RTMI_LAUNCH_PLAIN ? 1 : 0;
+                if (getenv("RTMI_DEBUG"))
+                    fprintf(stderr, "rtmi: RTMI_LAUNCH_AUTO: sliced %.3f %.3f %.3f ms, plain %.3f %.3f %.3f ms -> %s\n", b->auto_ms[0][0], b->auto_ms[0][1],
+                            b->auto_ms[0][2], b->auto_ms[1][0], b->auto_ms[1][1], b->auto_ms[1][2], b->auto_kept ? "plain" : "sliced");
+            }
         }
     }
     return rc;
 }
 
+RTMI_EXPORT int rtmi_debug_auto_rule(const double* sliced_ms, int ns, const double* plain_ms, int np, int* next, int* decision) {
+    ARG_TRY(ns >= 0 && np >= 0 && ns <= RTMI_AUTO_SAMPLES && np <= RTMI_AUTO_SAMPLES && (sliced_ms || ns == 0) && (plain_ms || np == 0),
+            "rtmi_debug_auto_rule: at most RTMI_AUTO_SAMPLES samples per schedule");
+    const int n[2] = {ns, np};
+    if (next) { const int k = auto_next(n); *next = k < 0 ? -1 : k == 0 ? RTMI_LAUNCH_SLICED : RTMI_LAUNCH_PLAIN; }
+    if (decision) *decision = auto_decide(sliced_ms, ns, plain_ms, np);
+    return RTMI_OK;
+}
+
 RTMI_EXPORT int rtmi_sync(rtmi_batch* b) {
     ARG_TRY(b, "rtmi_sync: null");
+    RETRACE_FLUSH(b);
     HIP_TRY(hipStreamSynchronize(b->stream));
     return RTMI_OK;
 }
@@ -2183,6 +2624,7 @@ RTMI_EXPORT int rtmi_sync(rtmi_batch* b) {
 RTMI_EXPORT int rtmi_read_d_ray(rtmi_batch* b, double* d_ray) {
     ARG_TRY(b && d_ray, "rtmi_read_d_ray: null");
     DEVICE_TRY(b->field, "rtmi_read_d_ray");
+    RETRACE_FLUSH(b);
     const size_t nb = 3 * (size_t)b->R * sizeof(double);
     void* stg = nullptr;
     int rc = batch_staging(b, nb, &stg);
@@ -2201,6 +2643,7 @@ RTMI_EXPORT int rtmi_read_d_ray(rtmi_batch* b, double* d_ray) {
 RTMI_EXPORT int rtmi_read_final(rtmi_batch* b, double* final9) {
     ARG_TRY(b && final9, "rtmi_read_final: null");
     DEVICE_TRY(b->field, "rtmi_read_final");
+    RETRACE_FLUSH(b);
     const size_t nb = 9 * (size_t)b->R * sizeof(double);
     void* stg = nullptr;
     int rc = batch_staging(b, nb, &stg);
@@ -2219,6 +2662,7 @@ RTMI_EXPORT int rtmi_read_final(rtmi_batch* b, double* final9) {
 int rtmi_internal_pack_device(rtmi_batch* b, int what, double* dst, void* stream) {
     ARG_TRY(b && dst, "rtmi_internal_pack_device: null");
     DEVICE_TRY(b->field, "rtmi_shard read-back");
+    RETRACE_FLUSH(b);
     HIP_TRY(hipStreamSynchronize(b->stream));
     hipStream_t st = (hipStream_t)stream;
     const dim3 g((unsigned)((b->R + 255) / 256)), blk(256);
@@ -2247,6 +2691,7 @@ RTMI_EXPORT int rtmi_read_rows(rtmi_batch* b, int64_t row0, int64_t nrows, doubl
     ARG_TRY(row0 >= 0 && nrows >= 0 && row0 + nrows <= b->p.rec_rows, "rtmi_read_rows: row range outside rec_rows");
     ARG_TRY(!(n_ray && !b->n_ray), "rtmi_read_rows: n_ray requested but the batch keeps none (params.no_n_ray)");
     DEVICE_TRY(b->field, "rtmi_read_rows");
+    RETRACE_FLUSH(b);
     if (nrows == 0) return RTMI_OK;
     const size_t R = (size_t)b->R;
     for (int which = 0; which < 2; which++) {
@@ -2336,6 +2781,7 @@ RTMI_EXPORT int rtmi_metric(rtmi_batch* b, int kind, double* out) {
                 "rtmi_metric: the exit-angle metric needs the full trajectory (record_stride 1, rec_rows >= max_size)");
     if (kind == RTMI_METRIC_PX_CV) ARG_TRY(b->p.record_stride >= 1, "rtmi_metric: the p_x metric needs recorded rows");
     DEVICE_TRY(b->field, "rtmi_metric");
+    RETRACE_FLUSH(b);
     const size_t nb = (size_t)b->R * sizeof(double);
     void* stg = nullptr;
     int rc = batch_staging(b, nb, &stg);
@@ -2434,6 +2880,7 @@ int rtmi_internal_isochrones_device(rtmi_batch* b, int32_t ntimes, const double*
     ARG_TRY(ntimes > 0 && ntimes <= 4096, "rtmi_isochrones: ntimes must be in [1, 4096]");
     ARG_TRY(b->p.record_stride == 1, "rtmi_isochrones: needs the full trajectory (record_stride 1)");
     DEVICE_TRY(b->field, "rtmi_isochrones");
+    RETRACE_FLUSH(b);
     double *d = nullptr, *dt = nullptr;
     const size_t nb = (size_t)ntimes * 3 * (size_t)b->R * sizeof(double);
     HIP_TRY(hipMalloc(&d, nb));
@@ -2470,6 +2917,7 @@ RTMI_EXPORT int rtmi_isochrones(rtmi_batch* b, int32_t ntimes, const double* tim
 
 RTMI_EXPORT int rtmi_batch_view(rtmi_batch* b, rtmi_device_view* v) {
     ARG_TRY(b && v, "rtmi_batch_view: null");
+    RETRACE_FLUSH(b);
     const size_t R = (size_t)b->R, e = b->esz;
     double* acc = (double*)b->state;
     char* aux = (char*)(acc + 6 * R);
@@ -2483,6 +2931,7 @@ RTMI_EXPORT int rtmi_batch_view(rtmi_batch* b, rtmi_device_view* v) {
 
 RTMI_EXPORT int rtmi_batch_stats(rtmi_batch* b, rtmi_stats* s) {
     ARG_TRY(b && s, "rtmi_batch_stats: null");
+    RETRACE_FLUSH(b);
     int rc = fold_events(b);
     if (rc) return rc;
     rc = read_counters(b);
@@ -2494,7 +2943,14 @@ RTMI_EXPORT int rtmi_batch_stats(rtmi_batch* b, rtmi_stats* s) {
     s->kernel_ms_total = b->total_kernel_ms;
     s->launches_total = b->total_launches;
     s->auto_fallbacks = b->auto_fallbacks;
-    s->reserved_ = 0;
+    s->retraced = b->rt ? b->rt->scattered : 0u;
+    s->retrace_overflow = b->rt ? b->rt->overflow : 0u;
+    s->retraced_total = b->rt ? b->rt->total : 0ull;
+    s->auto_kept = b->auto_kept < 0 ? 0 : b->auto_kept == 0 ? RTMI_LAUNCH_SLICED : RTMI_LAUNCH_PLAIN;
+    for (int k = 0; k < 2; k++) {
+        s->auto_n[k] = (uint32_t)b->auto_n[k];
+        for (int i = 0; i < RTMI_AUTO_SAMPLES; i++) s->auto_ms[k][i] = i < b->auto_n[k] ? b->auto_ms[k][i] : 0.0;
+    }
     hipFuncAttributes fa;
     s->vgprs = s->sgprs = s->lds_bytes = 0;
     s->launch_mode_used = (uint32_t)b->mode_used;

@@ -18,6 +18,9 @@
 
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <cstdint>
 #include <cstring>
 #include <new>
@@ -44,6 +47,17 @@ int fail(int code, const std::string& msg) { return rtmi_internal_fail(code, msg
     do {                                                \
         if (!(cond)) return fail(RTMI_ERR_ARG, (msg));  \
     } while (0)
+
+// Every rtmi_shard_* entry walks over the shard's devices with hipSetDevice; the caller's current device is put back on every
+// exit path (the rest of the ABI rejects handles whose field lives on another device, and a caller's torch tensors would land
+// on whichever device the last call happened to leave current).
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) { dev = -1; (void)hipGetLastError(); } }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
 
 // ---- the few RCCL entry points used, resolved at run time (rccl.h: ncclCommInitAll :236, ncclGather :745)
 typedef void* nccl_comm;
@@ -105,6 +119,20 @@ __global__ void k_interleave(const double* gathered, long R, int ndev, long nvec
 
 }  // namespace
 
+// One worker thread per device for the life of the shard (started by rtmi_shard_create when ndev > 1): it makes its device
+// current once and then runs the jobs rtmi_shard_run / rtmi_shard_reset hand it.
+struct ShardWorkers {
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::function<int(rtmi_batch*)> job;
+    uint64_t generation = 0;      // bumped per job
+    int pending = 0;              // workers that have not finished the present job
+    bool stop = false;
+    std::vector<std::thread> threads;
+    std::vector<int> rcs;
+    std::vector<std::string> msgs;
+};
+
 struct rtmi_shard {
     int ndev = 0;
     int64_t R = 0, Rmax = 0;
@@ -121,6 +149,7 @@ struct rtmi_shard {
     std::vector<nccl_comm> comms;            // RCCL communicators (transport 1)
     int transport = RTMI_SHARD_COPY;
     double run_seconds = 0;                  // wall time of the last rtmi_shard_run
+    ShardWorkers* workers = nullptr;         // ndev > 1: one thread per device, kept until rtmi_shard_destroy
 };
 
 namespace {
@@ -153,13 +182,18 @@ template <typename Pack> int gather_vecs(rtmi_shard* s, long nvec, Pack pack) {
     if (rc) return rc;
     if (s->transport == RTMI_SHARD_RCCL) {
         Rccl& N = rccl();
+        // nothing returns between GroupStart and GroupEnd: a group left open would swallow every later RCCL call of the thread
         int nrc = N.GroupStart();
-        for (int i = 0; i < s->ndev && nrc == 0; i++) {
-            HIP_TRY(hipSetDevice(s->devices[i]));
-            nrc = N.Gather(s->send[i], s->recv, block, kNcclFloat64, 0, s->comms[i], s->streams[i]);
+        hipError_t he = hipSuccess;
+        if (nrc == 0) {
+            for (int i = 0; i < s->ndev && nrc == 0 && he == hipSuccess; i++) {
+                he = hipSetDevice(s->devices[i]);
+                if (he == hipSuccess) nrc = N.Gather(s->send[i], s->recv, block, kNcclFloat64, 0, s->comms[i], s->streams[i]);
+            }
+            const int erc = N.GroupEnd();
+            if (nrc == 0) nrc = erc;
         }
-        const int erc = N.GroupEnd();
-        if (nrc == 0) nrc = erc;
+        if (he != hipSuccess) return fail(RTMI_ERR_HIP, std::string("ncclGather: hipSetDevice: ") + hipGetErrorString(he));
         if (nrc != 0) return fail(RTMI_ERR_HIP, std::string("ncclGather: ") + N.GetErrorString(nrc));
     } else {
         for (int i = 0; i < s->ndev; i++) {
@@ -189,8 +223,13 @@ int to_host(rtmi_shard* s, double* host, size_t n) {
 
 }  // namespace
 
+static int start_workers(rtmi_shard* s);
+static void stop_workers(rtmi_shard* s);
+
 RTMI_EXPORT void rtmi_shard_destroy(rtmi_shard* s) {
     if (!s) return;
+    DeviceGuard guard;
+    stop_workers(s);
     for (int i = 0; i < (int)s->batches.size(); i++) {
         if ((size_t)i < s->devices.size()) (void)hipSetDevice(s->devices[i]);
         rtmi_batch_destroy(s->batches[i]);
@@ -229,6 +268,7 @@ RTMI_EXPORT int rtmi_shard_create(int scenario, double xi, double xs, double yi,
         for (int j = 0; j < i; j++) distinct = distinct && devices[j] != devices[i];
     }
     ARG_TRY(!(transport == RTMI_SHARD_RCCL && !distinct), "rtmi_shard_create: RCCL needs one distinct GPU per shard");
+    DeviceGuard guard;
     rtmi_shard* s = new (std::nothrow) rtmi_shard();
     if (!s) return fail(RTMI_ERR_ALLOC, "rtmi_shard_create: host allocation failed");
     int rc = RTMI_OK;
@@ -271,10 +311,13 @@ RTMI_EXPORT int rtmi_shard_create(int scenario, double xi, double xs, double yi,
                 if (devices[i] == devices[0]) continue;
                 HIP_TRY(hipSetDevice(devices[i]));
                 const hipError_t e = hipDeviceEnablePeerAccess(devices[0], 0);
-                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();   // the copy is staged by the runtime then
+                // "already enabled" (a second shard on these devices, or torch got there first) and "not possible" (the runtime
+                // then stages the copy) are both fine -- but either leaves the thread's last error set, and the next
+                // hipGetLastError() after a kernel launch on this thread would report it: cleared in every case
+                if (e != hipSuccess) (void)hipGetLastError();
             }
         }
-        return RTMI_OK;
+        return start_workers(s);
     };
     try {
         rc = body();
@@ -290,27 +333,74 @@ RTMI_EXPORT int rtmi_shard_create(int scenario, double xi, double xs, double yi,
     return RTMI_OK;
 }
 
-// `fn(batch)` on every shard at once: one worker thread per device (each makes its device current), joined before returning.
+// `fn(batch)` on every shard at once, each on its device's worker thread (started once, in rtmi_shard_create); returns when
+// every shard has finished.  One shard: the calling thread itself.
+static void worker_main(rtmi_shard* s, int i) {
+    ShardWorkers& W = *s->workers;
+    const hipError_t e0 = hipSetDevice(s->devices[i]);       // once: the thread keeps its device
+    uint64_t seen = 0;
+    for (;;) {
+        std::function<int(rtmi_batch*)> job;
+        {
+            std::unique_lock<std::mutex> lk(W.mu);
+            W.cv_job.wait(lk, [&] { return W.stop || W.generation != seen; });
+            if (W.stop) return;
+            seen = W.generation;
+            job = W.job;
+        }
+        int rc = RTMI_OK;
+        std::string msg;
+        if (e0 != hipSuccess) { rc = RTMI_ERR_HIP; msg = hipGetErrorString(e0); }
+        else {
+            rc = job(s->batches[i]);
+            if (rc) msg = rtmi_last_error();                  // thread-local: copied out here
+        }
+        {
+            std::lock_guard<std::mutex> lk(W.mu);
+            W.rcs[i] = rc; W.msgs[i] = msg;
+            if (--W.pending == 0) W.cv_done.notify_all();
+        }
+    }
+}
+static int start_workers(rtmi_shard* s) {
+    if (s->ndev <= 1) return RTMI_OK;
+    s->workers = new (std::nothrow) ShardWorkers();
+    if (!s->workers) return fail(RTMI_ERR_ALLOC, "rtmi_shard_create: host allocation failed");
+    s->workers->rcs.assign(s->ndev, RTMI_OK);
+    s->workers->msgs.assign(s->ndev, std::string());
+    for (int i = 0; i < s->ndev; i++) s->workers->threads.emplace_back(worker_main, s, i);     // may throw: caught by the caller
+    return RTMI_OK;
+}
+static void stop_workers(rtmi_shard* s) {
+    if (!s->workers) return;
+    {
+        std::lock_guard<std::mutex> lk(s->workers->mu);
+        s->workers->stop = true;
+    }
+    s->workers->cv_job.notify_all();
+    for (auto& t : s->workers->threads) t.join();
+    delete s->workers;
+    s->workers = nullptr;
+}
 template <typename Fn> static int on_every_device(rtmi_shard* s, const char* who, Fn fn) {
     std::vector<int> rcs(s->ndev, RTMI_OK);
     std::vector<std::string> msgs(s->ndev);
-    auto work = [&](int i) {
-        hipError_t e = hipSetDevice(s->devices[i]);
-        if (e != hipSuccess) { rcs[i] = RTMI_ERR_HIP; msgs[i] = hipGetErrorString(e); return; }
-        rcs[i] = fn(s->batches[i]);
-        if (rcs[i]) msgs[i] = rtmi_last_error();          // thread-local: copied out before the thread ends
-    };
-    if (s->ndev == 1) {
-        work(0);
-    } else {
-        std::vector<std::thread> th;
-        try {
-            for (int i = 0; i < s->ndev; i++) th.emplace_back(work, i);
-        } catch (const std::exception& e) {
-            for (auto& t : th) t.join();
-            return fail(RTMI_ERR_ALLOC, std::string(who) + ": " + e.what());
+    if (s->ndev == 1 || !s->workers) {
+        for (int i = 0; i < s->ndev; i++) {
+            const hipError_t e = hipSetDevice(s->devices[i]);
+            if (e != hipSuccess) { rcs[i] = RTMI_ERR_HIP; msgs[i] = hipGetErrorString(e); continue; }
+            rcs[i] = fn(s->batches[i]);
+            if (rcs[i]) msgs[i] = rtmi_last_error();
         }
-        for (auto& t : th) t.join();
+    } else {
+        ShardWorkers& W = *s->workers;
+        std::unique_lock<std::mutex> lk(W.mu);
+        W.job = fn;
+        W.pending = s->ndev;
+        W.generation++;
+        W.cv_job.notify_all();
+        W.cv_done.wait(lk, [&] { return W.pending == 0; });
+        rcs = W.rcs; msgs = W.msgs;
     }
     for (int i = 0; i < s->ndev; i++)
         if (rcs[i]) return fail(rcs[i], std::string(who) + ": shard " + std::to_string(i) + " (device " + std::to_string(s->devices[i]) + "): " + msgs[i]);
@@ -319,6 +409,7 @@ template <typename Fn> static int on_every_device(rtmi_shard* s, const char* who
 
 RTMI_EXPORT int rtmi_shard_run(rtmi_shard* s) {
     ARG_TRY(s, "rtmi_shard_run: null");
+    DeviceGuard guard;
     const auto t0 = std::chrono::steady_clock::now();
     const int rc = on_every_device(s, "rtmi_shard_run", [](rtmi_batch* b) { return rtmi_run(b); });
     s->run_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -327,17 +418,20 @@ RTMI_EXPORT int rtmi_shard_run(rtmi_shard* s) {
 
 RTMI_EXPORT int rtmi_shard_reset(rtmi_shard* s) {
     ARG_TRY(s, "rtmi_shard_reset: null");
+    DeviceGuard guard;
     return on_every_device(s, "rtmi_shard_reset", [](rtmi_batch* b) { return rtmi_batch_reset(b); });
 }
 
 RTMI_EXPORT int rtmi_shard_read_d_ray(rtmi_shard* s, double* d_ray) {
     ARG_TRY(s && d_ray, "rtmi_shard_read_d_ray: null");
+    DeviceGuard guard;
     const int rc = gather_vecs(s, 3, [&](int i, double* dst) { return rtmi_internal_pack_device(s->batches[i], 0, dst, s->streams[i]); });
     return rc ? rc : to_host(s, d_ray, 3 * (size_t)s->R);
 }
 
 RTMI_EXPORT int rtmi_shard_read_final(rtmi_shard* s, double* final9) {
     ARG_TRY(s && final9, "rtmi_shard_read_final: null");
+    DeviceGuard guard;
     const int rc = gather_vecs(s, 9, [&](int i, double* dst) { return rtmi_internal_pack_device(s->batches[i], 1, dst, s->streams[i]); });
     return rc ? rc : to_host(s, final9, 9 * (size_t)s->R);
 }
@@ -346,6 +440,7 @@ RTMI_EXPORT int rtmi_shard_gather_rows(rtmi_shard* s, int64_t row0, int64_t nrow
     ARG_TRY(s && rows_dev, "rtmi_shard_gather_rows: null");
     ARG_TRY(s->p.record_stride > 0, "rtmi_shard_gather_rows: the batches keep no trajectory (record_stride = 0)");
     ARG_TRY(every >= 1 && nrows >= 1 && row0 >= 0, "rtmi_shard_gather_rows: need row0 >= 0, nrows >= 1, every >= 1");
+    DeviceGuard guard;
     rtmi_device_view v0;
     int rc = rtmi_batch_view(s->batches[0], &v0);
     if (rc) return rc;
@@ -372,6 +467,7 @@ RTMI_EXPORT int rtmi_shard_gather_rows(rtmi_shard* s, int64_t row0, int64_t nrow
 
 RTMI_EXPORT int rtmi_shard_read_rows(rtmi_shard* s, int64_t row0, int64_t nrows, int64_t every, double* s_ray) {
     ARG_TRY(s_ray, "rtmi_shard_read_rows: null");
+    DeviceGuard guard;
     double* dev = nullptr;
     const int rc = rtmi_shard_gather_rows(s, row0, nrows, every, &dev);
     return rc ? rc : to_host(s, s_ray, (size_t)nrows * 6 * (size_t)s->R);
@@ -379,6 +475,7 @@ RTMI_EXPORT int rtmi_shard_read_rows(rtmi_shard* s, int64_t row0, int64_t nrows,
 
 RTMI_EXPORT int rtmi_shard_info(rtmi_shard* s, rtmi_shard_stats* st) {
     ARG_TRY(s && st, "rtmi_shard_info: null");
+    DeviceGuard guard;
     memset(st, 0, sizeof *st);
     st->ndev = s->ndev; st->transport = s->transport; st->run_seconds = s->run_seconds; st->R = s->R;
     for (int i = 0; i < s->ndev; i++) {

@@ -14,6 +14,9 @@ import numpy as np
 from . import _lib
 from ._lib import Params, Stats, DeviceView, check, dptr, lib, LAUNCH_MODES, LAUNCH_NAMES, LAUNCH_AUTO, LAUNCH_REFILL, LAUNCH_SLICED, LAUNCH_PLAIN
 
+# re-runs of one batch (reset + run) RTMI_LAUNCH_AUTO spends timing its two schedules before it keeps one (rtmi.h: RTMI_AUTO_SAMPLES each)
+AUTO_EXPLORE_RUNS = 2 * _lib.AUTO_SAMPLES
+
 # --------------------------------------------------------------------------- constants (:59-97)
 THCK_PARAM = 0.005                                   # :59
 SIGMA = 0.05293304824724534                          # :60-61 (value of -2*THCK*log((A-1)/(sqrt2-A)) under numpy)
@@ -285,7 +288,7 @@ class Batch:
     def __init__(self, field, method, step, max_size, box, gamma, thetas, x0, y0, record_stride=1, rec_rows=0,
                  gamma_step=None, stream=None, ext_s_ray=None, ext_n_ray=None, block_size=0, launch_mode="auto",
                  refill_min=0, exact_basis=0, field_path=0, sort_rays=False, lazy_clear=False, keep_n_ray=True, slice_steps=0,
-                 reference_order=False):
+                 reference_order=False, retrace=True):
         self.field = field
         th = np.ascontiguousarray(thetas, dtype=np.float64)
         self.R = len(th)
@@ -316,6 +319,9 @@ class Batch:
         # op1/2/6/7/8 (fp64: the oracle's bits, slower); "fused" / 2 fused forms throughout, op7 included; "fast_field" / 3 op7's
         # reference-order step on the fused field lookup
         p.reference_order = ORDERS[reference_order] if isinstance(reference_order, str) else int(reference_order)
+        # retrace (default on): a fused fp64 op1/2/6/8 batch re-traces its critical rays -- those running along a sharp
+        # transition of the medium -- in reference order by itself (rtmi_params.no_retrace)
+        p.no_retrace = int(not retrace)
         self.params = p
         self._h = C.c_void_p()
         check(lib().rtmi_batch_create(field._h, C.byref(p), self.R, dptr(x0), dptr(y0), dptr(th), stream,
@@ -427,8 +433,13 @@ class Batch:
     def stats(self):
         s = Stats()
         check(lib().rtmi_batch_stats(self._h, C.byref(s)))
-        out = {k: getattr(s, k) for k, _ in Stats._fields_}
+        out = {k: getattr(s, k) for k, _ in Stats._fields_ if not k.startswith("auto_")}     # incl. retraced, retrace_overflow
         out["launch_mode_used"] = LAUNCH_NAMES.get(out["launch_mode_used"], out["launch_mode_used"])
+        out["auto_fallbacks"] = s.auto_fallbacks
+        # RTMI_LAUNCH_AUTO's exploration record: kernel ms of each timed run per schedule, and the schedule kept (None: still exploring / no choice)
+        out["auto_exploration"] = {"sliced_ms": [s.auto_ms[0][i] for i in range(s.auto_n[0])],
+                                   "plain_ms": [s.auto_ms[1][i] for i in range(s.auto_n[1])],
+                                   "kept": LAUNCH_NAMES.get(s.auto_kept) if s.auto_kept else None}
         return out
 
     def view(self):

@@ -72,15 +72,36 @@ def test_plain_start_with_two_gpus_runs_two_ranks_on_the_gpu_box():
     """`python3 bench.py --gpus 2 ...` as a plain subprocess: rc 0 and ONE JSON line with n_gpus 2 (both ranks share the box's
     one MI355X; gloo carries the collectives because RCCL wants one GPU per rank)."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--all-on-device", "0",
-                        "--rays", "65536", "--steps", "2", "--cpu-seconds", "0", "--gather-rows", "256"],
+                        "--steps", "2", "--cpu-seconds", "0", "--gather-rows", "64", "--record", "stride:16"],
                        capture_output=True, text=True, env=_env_without_rank_variables(), timeout=850)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
     out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak"
-    assert out["config"]["rays_total"] == 2 * 65536
+    # the default N > 1 line is the north-star run: the STRONG split of the 1 048 576-ray fan (SURVEY.md 8d)
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["rays_total"] == 1048576 and out["config"]["rays_rank0"] == 524288
     g = out["config"]["dist"]["gather"]
-    assert g["world"] == 2 and g["rays"] == 2 * 65536 and "error" not in g
+    assert g["world"] == 2 and g["rays"] == 1048576 and "error" not in g
+    assert g["trajectory"]["shape"] == [3, 6, 1048576]          # every 64th of 192 kept rows, both ranks' rays in ray order
+    assert out["parity_check"]["ok"]
+    # ... with the weak configuration (1 048 576 rays per GPU) as the secondary record of the same line
+    w = out["weak"]
+    assert "error" not in w, w
+    assert w["scaling"] == "weak" and w["rays_total"] == 2 * 1048576 and w["value"] > 0 and w["steps"] == 2
+    assert out["config"]["auto_exploration"]["kept"] in ("sliced", "plain", None)
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_rays_per_gpu_asks_for_the_weak_line():
+    """--rays R: R rays per GPU (weak scaling) is the line's value, no secondary record."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--all-on-device", "0",
+                        "--rays", "65536", "--steps", "2", "--cpu-seconds", "0", "--gather-rows", "256"],
+                       capture_output=True, text=True, env=_env_without_rank_variables(), timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["rays_total"] == 2 * 65536 and "weak" not in out
+    g = out["config"]["dist"]["gather"]
     assert g["trajectory"]["shape"] == [12, 6, 2 * 65536]          # every 256th of 3 072 rows, both ranks' rays in ray order
     assert out["parity_check"]["ok"]

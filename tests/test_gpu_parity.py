@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from bench import parity_relerr
+from bench import parity_relerr, parity_relerr_elementwise
 from conftest import LIMITS, golden, sub_rows, traj_fixtures, traj_inputs
 
 pytestmark = pytest.mark.gpu
@@ -45,11 +45,13 @@ def gpu_fields(rb):
 
 def relerr(a, b, floor=None):
     """Arrays [.., quantity, ray] (final state, d_ray, recorded rows): bench.parity_relerr -- relative to each quantity's own
-    largest magnitude over the fixture, so that 1e-9 means 1e-9 of p_x ~ 0.05 or T ~ 0.4 too.  With `floor` (flat vectors of
-    mixed quantities): element-wise |a - b| / max(|b|, floor)."""
+    largest magnitude over the fixture, so that 1e-9 means 1e-9 of p_x ~ 0.05 or T ~ 0.4 too -- AND the element-wise
+    |a - b| / max(|b|, 1) of rounds 1-3 (an absolute 1e-9 below 1): the larger of the two, so a bound holds under both.  With
+    `floor` (flat vectors of mixed quantities): element-wise |a - b| / max(|b|, floor)."""
     if floor is not None:
         return np.max(np.abs(a - b) / np.maximum(np.abs(b), floor))
-    return parity_relerr(a, b)
+    # BOTH measures (the larger): per quantity relative to that quantity's scale, and rounds 1-3's |a - b| / max(|b|, 1)
+    return max(parity_relerr(a, b), parity_relerr_elementwise(a, b))
 
 
 # ------------------------------------------------------------------ field (SURVEY 8a: a1-a5)
@@ -985,14 +987,27 @@ def test_random_rays_through_grid_ends_vs_oracle(scen, m, rb, gpu_fields, oracle
     b.close()
     o = O.trazar(oracle_fields(scen), m, gam, step, ms, lim, x0, y0, th, record_stride=0, nthreads=8)
     same = d[2] == o["d_ray"][2]
-    assert same.mean() > 0.99                        # a ray grazing the rim may leave one step apart
-    err = np.abs(fin[:, same] - o["final"][:, same]) / np.maximum(np.abs(o["final"][:, same]), 1.0)
-    print(f"{scen} op{m}: {same.sum()}/{R} same step count, max rel err {err.max():.2e}")
-    if m in (3, 4, 5, 9, 10, 11):
-        # reference-order methods on a field whose coefficients are the oracle's bits (all scenarios): every ray bit-identical
-        assert same.all() and np.array_equal(fin, o["final"])
-        return
-    assert err.max() < REL                          # op7 included: it steps in the reference's operation order by default
+    err = relerr(fin[:, same], o["final"][:, same])
+    print(f"{scen} op{m}: {same.sum()}/{R} same step count, max rel err {err:.2e}")
+    if m in (3, 4, 5, 7, 9, 10, 11):
+        # reference-order methods (op7 by default too) on a field whose coefficients are the oracle's bits: the step count is
+        # an integer RESULT and must be the oracle's on every ray
+        assert same.all(), f"step counts differ on rays {np.flatnonzero(~same)[:8]}"
+        if m != 7:
+            assert np.array_equal(fin, o["final"])   # every ray bit-identical
+            return
+    else:
+        # fused forms (~1e-13 from the reference): a ray whose last point lies within that of the box's rim may leave one row
+        # apart.  Reported, not dropped: each such ray must differ by exactly one row, and the point where the shorter run
+        # stopped must be on the rim to the fused forms' distance from the reference
+        for k in np.flatnonzero(~same):
+            dk, ok_ = int(d[2, k]), int(o["d_ray"][2, k])
+            short = fin[:, k] if dk < ok_ else o["final"][:, k]
+            rim = min(abs(short[0] - lim[0]), abs(short[0] - lim[1]), abs(short[1] - lim[2]), abs(short[1] - lim[3]))
+            print(f"  ray {k}: {dk} rows here, {ok_} in the oracle; the shorter run stopped {rim:.2e} from the rim")
+            assert abs(dk - ok_) == 1 and rim < 1e-9
+        assert same.mean() > 0.99
+    assert err < REL
 
 
 @pytest.mark.parametrize("qx,qy", [(8, 8), (12, 10), (40, 17)])

@@ -41,8 +41,11 @@ print(f"# interface scenario, {R} rays; windows of {W} contiguous rays around ea
 print("# columns x y / p / T / theta: largest difference from the oracle over the window, relative to the quantity's largest magnitude")
 print(f"# '> 1e-9': rays with any quantity beyond 1e-9; 'ill': those of them whose ORACLE rows move more than that when theta_0 becomes theta_0 (1 + {PERT:g});")
 print("# 'worst ratio': the largest (difference from the oracle) / (the oracle's own movement under that perturbation) over the rays beyond 1e-9")
-print(f"{'op':>3s} {'order':10s} {'split at':>9s} {'same steps':>10s} {'x y':>9s} {'p':>9s} {'T':>9s} {'theta':>9s} {'final':>9s} {'> 1e-9':>7s} {'ill':>5s} {'worst ratio':>11s}")
-for m in (1, 2, 6, 8, 7):
+print("# 'default': the library's default (critical rays re-traced in reference order by themselves, rtmi_params.no_retrace = 0); 'noretrace': the fused")
+print("# forms alone (no_retrace = 1: what the default was until round 4); 'retraced': rays the default handed over (rtmi_stats.retraced)")
+print(f"{'op':>3s} {'order':10s} {'split at':>9s} {'same steps':>10s} {'x y':>9s} {'p':>9s} {'T':>9s} {'theta':>9s} {'final':>9s} {'> 1e-9':>7s} {'ill':>5s} {'worst ratio':>11s} {'retraced':>8s} {'ms':>8s}")
+METHODS = [int(v) for v in os.environ.get("METHODS", "1,2,6,8,7").split(",")]
+for m in METHODS:
     b = rb.Batch(F, m, rb.DELTA_S, ms, lim, 1, th[::64], -2.0, -2.0, record_stride=0, reference_order="fused")
     b.run()
     fin = b.final()
@@ -55,10 +58,12 @@ for m in (1, 2, 6, 8, 7):
     o1 = O.trazar(OF, m, 1, rb.DELTA_S, ms, lim, -2.0, -2.0, th[win] * (1 + PERT), nthreads=threads, **kw)
     moved = per_ray(o1["s_ray"], o["s_ray"]).max(axis=0)                 # the oracle's own movement under the perturbation, per ray
     moved[o1["d_ray"][2] != o["d_ray"][2]] = np.inf                      # (a different number of steps: any difference goes)
-    for order in (("default", "fast_field", "fused") if m == 7 else ("default", "reference")):
-        b = rb.Batch(F, m, rb.DELTA_S, ms, lim, 1, th[win], -2.0, -2.0, reference_order=order, **kw)
+    for order in (("default", "fast_field", "fused") if m == 7 else ("default", "noretrace", "reference")):
+        b = rb.Batch(F, m, rb.DELTA_S, ms, lim, 1, th[win], -2.0, -2.0, reference_order="default" if order == "noretrace" else order,
+                     retrace=order != "noretrace", **kw)
         b.run()
         s, d, fin = b.rows(), b.d_ray(), b.final()
+        stt = b.stats()
         b.close()
         same = d[2] == o["d_ray"][2]
         e = per_ray(s[:, :, same], o["s_ray"][:, :, same])
@@ -68,7 +73,9 @@ for m in (1, 2, 6, 8, 7):
         ratio = (dev[over] / np.maximum(moved[same][over], 1e-300)).max() if over.any() else 0.0
         ef = parity_relerr(fin[:, same], o["final"][:, same])
         print(f"{m:3d} {order:10s} {np.degrees(th[k * 64 + 32]):9.4f} {int(same.sum()):10d} " + " ".join(f"{c:9.1e}" for c in e.max(axis=1)) +
-              f" {ef:9.1e} {int(over.sum()):7d} {int(ill.sum()):5d} {ratio:11.3f}", flush=True)
+              f" {ef:9.1e} {int(over.sum()):7d} {int(ill.sum()):5d} {ratio:11.3f} {stt['retraced']:8d} {stt['kernel_ms']:8.3f}", flush=True)
+        if stt["retrace_overflow"]:
+            print(f"#      retrace_overflow {stt['retrace_overflow']}")
         for r in np.flatnonzero(over)[:8] if order != "fused" else ():
             print(f"#      ray {i0 + np.flatnonzero(same)[r]} ({np.degrees(th[i0 + np.flatnonzero(same)[r]]):.6f} deg): {dev[r]:.1e} from the oracle; the oracle itself moves {moved[same][r]:.1e}")
 F.close()
