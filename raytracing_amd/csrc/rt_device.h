@@ -243,6 +243,9 @@ template <typename T> struct FieldDev {
     // FITPACK's fpbspl divides by there, then the cell's knots and the differences themselves (rt_exact.h: axis_exact reads the
     // reciprocals per lane, AxisTab the whole entry for a wave in one cell); nullptr in fp32 fields (the reference-order path is fp64)
     const double *rdx, *rdy;
+    // gflat: what FITPACK's gradient evaluates to at most in a FLAT cell of the map (2^-72 of the grid's largest gradient-spline
+    // coefficient; rt_exact.h, the reference-order step where the medium is constant)
+    T gflat;
 };
 
 // Rare branches of the step loop (a lookup near the grid's rim, re-staging the LDS tile, a lane falling back to a global
@@ -1083,10 +1086,10 @@ template <typename T> struct Ray {
     Acc dsim, dreal, tt;     // simulated / expected arclength, traveltime (accumulators)
     T mx, my;                // momenta of the current row (output only)
     T hx0, hy0, hx1, hy1;    // op7: the two positions before (x,y), oldest first (VECTOR_LIST, Q11)
+    bool gstale, curflat;    // reference-order op1/2/6/8 (rt_exact.h, the flat path): gx, gy have not been evaluated at (x, y) yet; (x, y) lies in a flat cell
     float hov;               // fused fp64 op1/2/6/8 on a field with steep cells: sum of the steepness of the cells in which the ray
-                             // ran nearly along the iso-lines (hover_update); times DELTA_S it estimates how far the ray's
-                             // trajectory amplifies a rounding difference (ln amp ~ 3.5 + 2.5 hov DELTA_S, calibrated on the
-                             // interface scenario's critical rays) -- past kHoverLimit the ray is re-traced in reference order
+                             // ran along the iso-lines (hover_update); times DELTA_S it grows with the factor by which the ray's
+                             // trajectory amplifies a rounding difference -- past kHoverLimit the ray is re-traced in reference order
 };
 template <typename T> constexpr bool kMixed = !__is_same(T, double);   // fp32 arithmetic on fp64 accumulators
 
@@ -1412,15 +1415,20 @@ inline bool rotates_unit(int method, bool f64) {
 // interface scenario's critical angle a million times (the reference's own rows move 1e-6 for a 1e-12 change of the launch
 // angle), and there a fused step -- ~1e-16 per step from the reference's roundings -- ends up past 1e-9.  Which rays those are
 // cannot be told from the launch conditions, but it shows on the way: they spend hundreds of steps in the few steep cells of the
-// grid (FlatBits: lambda >= lambda_0) heading within 0.1 rad of the iso-lines, where a ray that crosses the transition spends a
-// dozen.  hov adds the cells' steepness over exactly those steps.  (grad n . u)^2 < 0.01 |grad n|^2 with the gradient at the
-// new point and the tangent the step started with: five fp64 instructions, executed only when some lane of the wave is in a
-// steep cell.  Per lane from the ray's own values: independent of wave mates, schedule and partition.
-constexpr float kHoverLimit = 2.0f;      // hov * DELTA_S beyond which a ray is re-traced (amplification ~ 5e3, error ~ 2e-11)
+// grid (FlatBits: lambda >= lambda_0) heading within 0.02 rad of the iso-lines, where a ray that merely crosses or reflects
+// spends a handful.  hov adds the cells' steepness over exactly those steps: (grad n . u)^2 < 4e-4 |grad n|^2 with the gradient
+// at the new point and the tangent the step started with -- five fp64 instructions, executed only when some lane of the wave is
+// in a steep cell.  Per lane from the ray's own values: independent of wave mates, schedule and partition.
+// Calibration (the oracle's own trajectories of the 1 M-ray interface fan around each method's split, against the movement of
+// its rows under a 1e-12 change of the launch angle, tools/hover_calibration.py): hov * DELTA_S >= 2.0 holds for every ray whose
+// amplification exceeds 3e3 (op1: 2.06, op2: 2.32, op6: 2.10, op8: 2.14 is the smallest sum among them) and for 320-400 rays of the
+// million in all; the fused forms' rows leave 1e-9 from amplification 2.5e5 on (their distance from the reference's roundings
+// is 4e-15 of a launch angle), so the limit keeps a factor 80 in hand.
+constexpr float kHoverLimit = 2.0f;      // hov * DELTA_S beyond which a ray is re-traced in reference order
 template <typename T> __device__ __forceinline__ void hover_update(Ray<T>& r, bool active, float lam, T fgx, T fgy) {
     if (rt_ballot(lam != 0.f) == 0ull) return;
     const T d = fma_(fgy, r.uy, fgx * r.ux), g2 = fma_(fgy, fgy, fgx * fgx);
-    if (active && lam != 0.f && d * d < T(0.01) * g2) r.hov += lam;
+    if (active && lam != 0.f && d * d < T(4e-4) * g2) r.hov += lam;
 }
 
 template <typename T, int METHOD, bool ISO, typename G>

@@ -359,9 +359,10 @@ constexpr bool window_estimates(int method) { return method != 10 && method != 1
 // without a scalar load.  vert op7 +1.5 %, op3 +1.5 %, interface op5 +4 %, op7 +2 %; vert op9 -1.5 % (window_votes;
 // profiles/r04_ab_variants_not_kept.txt, call 50, where it was tried as a cure for the fisheye case and was not one).
 constexpr bool window_votes(int method) { return method != 9; }
+// cellp (optional): where the lookup landed, as the flat-cell map's index (jy * ncx + jx on the true knots)
 template <int PH = 1, bool EST = true, bool VOTE = false, typename G>
 __device__ __forceinline__ void n_gradient(const FieldDev<double>& F, G& gather, bool active, double x, double y,
-                                           double& n, double& gx, double& gy) {
+                                           double& n, double& gx, double& gy, int* cellp = nullptr) {
     if constexpr (RTMI_EXACT_UNIFORM && G::kUniformWindow) {
         const unsigned long long live = rt_ballot(active && F.window != 0);     // no lane is asked when the batch does not use the window
         if (live != 0ull) {
@@ -376,18 +377,19 @@ __device__ __forceinline__ void n_gradient(const FieldDev<double>& F, G& gather,
                 if constexpr (VOTE) others = (rt_ballot(jx != jx0 || jy != jy0) & live) != 0ull;
                 jx0 = jx0 < 0 ? 0 : (jx0 > F.qx - 2 ? F.qx - 2 : jx0);
                 jy0 = jy0 < 0 ? 0 : (jy0 > F.qy - 2 ? F.qy - 2 : jy0);
-                if (!others && lookup_uniform<true>(F, jx0, jy0, live, xv, yv, n, gx, gy)) return;
+                if (!others && lookup_uniform<true>(F, jx0, jy0, live, xv, yv, n, gx, gy)) { if (cellp) *cellp = jy0 * F.ncx + jx0; return; }
             } else {
                 double xv = x, yv = y, t0, t1;
                 const int jx = locate(xv, F.qx, F.ax, F.hx, F.bx, F.inv_hx, t0, t1);      // clamps in place
                 const int jy = locate(yv, F.qy, F.ay, F.hy, F.by, F.inv_hy, t0, t1);
                 const int jx0 = __builtin_amdgcn_readlane(jx, lead), jy0 = __builtin_amdgcn_readlane(jy, lead);
-                if ((rt_ballot(jx != jx0 || jy != jy0) & live) == 0ull && lookup_uniform<false>(F, jx0, jy0, live, xv, yv, n, gx, gy)) return;
+                if ((rt_ballot(jx != jx0 || jy != jy0) & live) == 0ull && lookup_uniform<false>(F, jx0, jy0, live, xv, yv, n, gx, gy)) { if (cellp) *cellp = jy0 * F.ncx + jx0; return; }
             }
         }
     }
     Cell<double> c;
     ex::field_locate(F, x, y, c);
+    if (cellp) *cellp = c.jy * F.ncx + c.jx;
     if constexpr (RTMI_EXACT_UNIFORM && G::kUniformWindow && PH > 1) {
         // the per-lane gather with the window consumed in groups of rows: fpbisp's sums run row by row anyway (same order, same
         // bits), and the kernel's register count is no longer set by 72 staging registers of a path a coherent wave rarely takes
@@ -882,12 +884,123 @@ __device__ __forceinline__ void derive(const Consts<double>& k, Ray<double>& r) 
     moments(r.n, r.coef, k.g2m1, r.ux, r.uy, r.mx, r.my);
 }
 
+// ---------------------------------------------------------------- the reference-order step where the medium is constant
+// op1/2/6/8 in the reference's operation order (rtmi_params.reference_order = 1; the automatic re-trace of critical rays, rtmi.hip)
+// on a field with FLAT cells (rt::poly_cell_flat: every gradient-spline coefficient of the cell at most 2^-80 of the grid's largest
+// -- both flanks of the interface scenario's sigmoid, three quarters of a ray's steps there).  In such a cell FITPACK's gradient
+// evaluates to at most gflat = 2^-72 of that scale (32 coefficients of at most 2^-80, weights in [0, 1], and the rounding of its sums),
+// and the reference's step then does nothing with it that survives a rounding:
+//   * the advancement (:330) adds (grad n - (grad n . u) u) DELTA_S^2 / 2n, at most gflat DELTA_S^2 / n, to r + u DELTA_S: below a
+//     quarter ulp of each coordinate the sum is r + u DELTA_S itself;
+//   * the new angle theta + (k1 + k2) / 2 (:374-391) with |k| <= 2 gflat DELTA_S / n is theta itself below a quarter ulp of theta --
+//     and then its sin / cos, the anisotropy factor and the unit tangent are the ones the ray already carries (same function, same
+//     argument, same bits).
+// What is left of the step is the index at the new point -- FITPACK's BILINEAR sum (fpbspl k = 1 on the true knots, fpbisp's
+// order: the four samples of a flat cell are equal, but their weights sum to 1 +- ulp and the reference's n, momenta and traveltime
+// carry that) -- the chord, the moments and the traveltime, in store_update's order.  No cubic basis (12 Markstein divisions), no
+// 4 x 4 window (18 loads, 96 flops), no sin / cos, no division by n: ~150 instructions off a 2-instruction dependent chain instead
+// of ~1 500 on a chain of ~400 -- what a lone wave of re-traced rays is bound by.  The three conditions are tested per lane and per
+// step with the ray's own numbers; a lane that fails one (a coordinate within 1e-9 of zero, a cell that is not flat) takes the
+// full step, which is the same bits by construction -- tests/test_gpu_exact.py holds both to the oracle's.
+// The gradient at the new point is not evaluated on this path (gstale): the full step evaluates it at the point it starts from when
+// it finds it missing, and so does whoever stores the ray's state (finish_state).  op1 / op8 form their new angle as
+// arctan2(n u_y + I_y, n u_x + I_x) (:407), which is not theta in the last bits even where the impulse vanishes: they keep numpy's
+// arctan2 and the sin / cos of its result and skip the rest.
+template <int METHOD> constexpr bool flat_shortcut() { return RTMI_FLAT_MAP && (METHOD == 1 || METHOD == 2 || METHOD == 6 || METHOD == 8); }
+template <typename G> struct IsGlobalGather { static constexpr bool value = false; };
+template <> struct IsGlobalGather<GlobalGather<double>> { static constexpr bool value = true; };
+
+// fpbspl for k = 1 on the cell's true knots (the linear part of axis_exact): j, and the two weights
+__device__ __forceinline__ int axis_linear(double v, int q, double a, double h, double b, double ih, const double* rd, double wl[2]) {
+    double t0, t1;
+    const int j = locate(v, q, a, h, b, ih, t0, t1);      // v is clamped in place (quirk Q4)
+    const double f = rd[(size_t)j * kAxisTab];             // 1.0 / (t1 - t0), correctly rounded (fp_axis_tab_build)
+    wl[0] = 0.0 + f * (t1 - v);
+    wl[1] = f * (v - t0);
+    return j;
+}
+// is the point's cell flat (the flat-cell map), and FITPACK's bilinear n there
+__device__ __forceinline__ bool flat_point(const FieldDev<double>& F, double x, double y, double& n) {
+    double lwx[2], lwy[2];
+    const int jx = axis_linear(x, F.qx, F.ax, F.hx, F.bx, F.inv_hx, F.rdx, lwx);
+    const int jy = axis_linear(y, F.qy, F.ay, F.hy, F.by, F.inv_hy, F.rdy, lwy);
+    double cf; float lam;
+    const bool flat = flat_lane(F, jy * F.ncx + jx, cf, lam);
+    const double* zp = F.zn + (size_t)jy * F.qx + jx;
+    double sp = 0.0;                                        // field_combine's first four lines
+    sp += zp[0] * lwy[0] * lwx[0];
+    sp += zp[1] * lwy[0] * lwx[1];
+    sp += zp[F.qx] * lwy[1] * lwx[0];
+    sp += zp[F.qx + 1] * lwy[1] * lwx[1];
+    n = sp;
+    return flat;
+}
+// the gradient at the point the ray is at, when the flat path left it out (the index there is r.n already: same function, same bits)
+template <int METHOD, typename G>
+__device__ __forceinline__ void finish_state(const FieldDev<double>& F, G& gather, Ray<double>& r) {
+    if constexpr (flat_shortcut<METHOD>() && IsGlobalGather<G>::value) {
+        if (r.gstale) {
+            double nn;
+            ex::n_gradient<fallback_phases(METHOD), window_estimates(METHOD), window_votes(METHOD)>(F, gather, true, (double)r.x, (double)r.y, nn, r.gx, r.gy);
+            r.gstale = false;
+        }
+    }
+}
+
 template <int METHOD, typename G>
 __device__ __forceinline__ bool ray_step(const FieldDev<double>& F, const Consts<double>& k, G& gather, bool active,
                                          Ray<double>& r, int i) {
+    if constexpr (flat_shortcut<METHOD>() && IsGlobalGather<G>::value) {
+        // tried only when some live lane of the wave stands in a flat cell (wave-uniform test on state the lanes carry: inside a
+        // transition band nothing is looked up twice)
+        if (F.flat != 0 && rt_ballot(active && r.curflat) != 0ull) {
+            // the step if nothing of the gradient survives: r + u DELTA_S (adv_first; adv_second's first bracket), theta kept
+            const double fx = r.x + r.ux * k.step, fy = r.y + r.uy * k.step;
+            double fn;
+            const bool newflat = flat_point(F, fx, fy, fn);
+            const double q = F.gflat * k.step2, sc = 0x1p-56;           // a quarter ulp of v is at least 2^-55 |v|; half of that in hand
+            bool ok = r.curflat && newflat && (METHOD == 1 || METHOD == 2 || (q < sc * __builtin_fabs(fx) * r.n && q < sc * __builtin_fabs(fy) * r.n));
+            if constexpr (METHOD == 2 || METHOD == 6)
+                ok = ok && F.gflat * k.step * (r.n + fn) < sc * __builtin_fabs(r.th) * r.n * fn;
+            else   // op1 / op8: the impulse DELTA_S (g + g') / 2 (:214) against n u_x and n u_y (:407)
+                ok = ok && F.gflat * k.step < sc * r.n * __builtin_fmin(__builtin_fabs(r.ux), __builtin_fabs(r.uy));
+            if (!active || ok) {       // (an idle lane: its stale state takes the short way too)
+                const double dist = norm2(r.x - fx, r.y - fy);
+                r.dsim += dist;
+                r.dreal += k.step;
+                double c = r.ux, s = r.uy, coef = r.coef, fth = r.th;
+                if constexpr (METHOD == 1 || METHOD == 8) {
+                    fth = atan2_(r.n * r.uy, r.n * r.ux);
+                    const SinCos u = sincos_(fth);
+                    c = u.c; s = u.s;
+                    coef = aniso(s, c, k.gamma);
+                }
+                moments(fn, coef, k.g2m1, c, s, r.mx, r.my);
+                r.hx0 = r.hx1; r.hy0 = r.hy1; r.hx1 = r.x; r.hy1 = r.y;
+                r.x = fx; r.y = fy; r.th = fth; r.n = fn;
+                r.ux = c; r.uy = s; r.coef = coef;
+                const double nray = coef * fn;
+                r.tt = r.tt + dist * (r.nray + nray) / 2.0;
+                r.nray = nray;
+                r.gstale = true; r.curflat = true;
+                r.hov = 0.f;           // a flat cell is not a steep one
+                return !outside(k, r);
+            }
+            finish_state<METHOD>(F, gather, r);      // the full step starts from the gradient at (r.x, r.y)
+        }
+    }
     double fx, fy, fn, fgx, fgy;
     const bool flag = ex::op_advance<METHOD>(k, r, fx, fy);
     if constexpr (IsPoly<G>::value) rt::n_gradient(F, gather, active, fx, fy, fn, fgx, fgy);   // kFastField: the cell's polynomial
+    else if constexpr (flat_shortcut<METHOD>() && IsGlobalGather<G>::value) {
+        // ... and whether the cell the lookup landed in is flat (one more load, in the shadow of the window's): the next step's
+        // short way starts from a flat cell
+        int cell = 0;
+        ex::n_gradient<fallback_phases(METHOD), window_estimates(METHOD), window_votes(METHOD)>(F, gather, active, fx, fy, fn, fgx, fgy, &cell);
+        r.curflat = false;
+        r.hov = 0.f;               // (in this order of stepping Ray::hov is free: it carries the steepness of the cell the ray arrived in)
+        if (F.flat != 0) { double cf; r.curflat = flat_lane(F, cell, cf, r.hov); }
+    }
     else ex::n_gradient<fallback_phases(METHOD), window_estimates(METHOD), window_votes(METHOD)>(F, gather, active, fx, fy, fn, fgx, fgy);
     const double fth = ex::op_angle<METHOD>(k, r, flag, fx, fy, fn, fgx, fgy, i);
     ex::store_update<inline_sincos(METHOD) || IsPoly<G>::value>(k, r, fx, fy, fth, fn, fgx, fgy);   // (IsPoly: op7 with RTMI_ORDER_FAST_FIELD, kFastField)

@@ -126,6 +126,7 @@ struct rtmi_field {
     void* poly_base = nullptr;   // the allocation: the flat-cell map ([flat_pad] of dtype, rt::FieldDev::flat), then the table
     long flat_pad = 0;           // elements from the map's start to the table's
     long flat_cells = 0;         // cells the map marks flat
+    double gmax = 0;             // the largest gradient-spline coefficient of the grid in magnitude (k_absmax)
     long steep_cells = 0;        // fp64 fields: cells whose map entry carries a steepness (k_polytab); with neither kind the kernels never look at the map
     double* rdiv = nullptr;      // [qx][24] then [qy][24]: reciprocals of the knot differences fpbspl divides by, knots, differences (rt_exact.h, AxisTab)
     hipStream_t stream = nullptr;
@@ -166,6 +167,7 @@ template <typename T> static rt::FieldDev<T> field_dev(const rtmi_field* f, int 
     F.rdx = f->rdiv;
     F.rdy = f->rdiv ? f->rdiv + (size_t)f->qx * rt::ex::kAxisTab : nullptr;
     F.window = 0;
+    F.gflat = (T)(f->gmax * 0x1p-72);
     return F;
 }
 
@@ -580,6 +582,7 @@ static int field_finish_impl(rtmi_field* f, double delta) {
             HIP_TRY(e);
             f->flat_cells = getenv("RTMI_NO_FLAT") ? 0 : (long)hcnt[1];     // RTMI_NO_FLAT=1: A/B without the map
             f->steep_cells = getenv("RTMI_NO_FLAT") ? 0 : (long)hcnt[2];
+            memcpy(&f->gmax, &hcnt[0], sizeof(double));
             if (getenv("RTMI_DEBUG")) fprintf(stderr, "rtmi: field %d x %d: %ld of %zu cells flat, %ld steep (lambda >= %.3g)\n", qx, qy, (long)hcnt[1], ncell, (long)hcnt[2], lam0);
         }
         HIP_TRY(hipStreamSynchronize(st));  // host vectors / LU buffers go out of scope
@@ -900,6 +903,7 @@ __device__ __forceinline__ void load_ray(const BatchDev<T>& a, long k, rt::Ray<T
     } else rt::derive<T, ISO>(a.K, r);
     if constexpr (HOV) r.hov = a.hov ? ld_state<COH>(a.hov + k) : 0.f;
     else r.hov = 0.f;
+    r.gstale = false; r.curflat = false;       // (the first step of a launch takes the full way; it finds out where the ray is)
     i = ld_state<COH>(a.istep + k);
 }
 template <typename T, int METHOD, bool COH = false, bool HOV = false>
@@ -926,6 +930,7 @@ template <typename T> __device__ __forceinline__ void idle_ray(const BatchDev<T>
     r.dsim = r.dreal = r.tt = r.mx = r.my = 0;
     r.hx0 = r.hx1 = r.x; r.hy0 = r.hy1 = r.y;
     r.hov = 0.f;
+    r.gstale = false; r.curflat = false;
 }
 
 // Gather policy of a step kernel.  Reference-order methods (rt_exact.h: FITPACK's sums on the B-spline window): the LDS tile
@@ -1108,7 +1113,10 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
                     return true;
                 }
             }
-            if (!alive) store_ray<T, METHOD, COH, HOV>(rare_batch(a), k, r, i, false);
+            if (!alive) {
+                if constexpr (rt::IsExact<T, METHOD>::value) rt::ex::finish_state<rt::base_method(METHOD)>(a.F, gather, r);   // the gradient at the end point, if the flat path left it out
+                store_ray<T, METHOD, COH, HOV>(rare_batch(a), k, r, i, false);
+            }
         }
         return true;
     };
@@ -1199,7 +1207,10 @@ __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, lon
     // step's row stores to be acknowledged.
     __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0), expcnt and lgkmcnt untouched
     advance_loop<T, METHOD, ISO, decltype(gather), !VAR, COH>(a, K, gather, r, k, i, alive, max_size, nsteps, blk);
-    if (alive) store_ray<T, METHOD, COH, HOV>(a, k, r, i, true);
+    if (alive) {
+        if constexpr (rt::IsExact<T, METHOD>::value) rt::ex::finish_state<rt::base_method(METHOD)>(a.F, gather, r);
+        store_ray<T, METHOD, COH, HOV>(a, k, r, i, true);
+    }
     return alive;
 }
 
@@ -1393,7 +1404,10 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : light_method(METHOD) ? RT
                         continue;
                     }
                 }
-                if (!alive) store_ray<T, METHOD, false, RHOV>(a, k, r, i, false);
+                if (!alive) {
+                    if constexpr (rt::IsExact<T, METHOD>::value) rt::ex::finish_state<rt::base_method(METHOD)>(a.F, gather, r);
+                    store_ray<T, METHOD, false, RHOV>(a, k, r, i, false);
+                }
             }
         }
     }
@@ -1497,17 +1511,21 @@ static void drop_graph(rtmi_batch* b);
 // when both have finished k_retrace_scatter copies the re-traced rays' rows and final state over the fused ones.
 // Result: every ray of a default batch is within 1e-9 of the reference, the critical ones bit for bit (the oracle's bits).
 struct Retrace {
-    rtmi_batch* sub = nullptr;            // the hidden reference-order batch: cap + 256 slots (the tail is padding for offset views)
+    rtmi_batch* sub = nullptr;            // the hidden batch: cap slots of state and rows (its own kernels never run: k_retrace fills it)
     unsigned cap = 0;                     // queue entries = slots that can be re-traced per pass
     unsigned long long* rq = nullptr;     // device: [0] rays pushed, [1 .. cap] entries
     unsigned* host_count = nullptr;       // pinned host: [0] the count as the kernels publish it, [1..2] scratch for reading rq[0]
     float* hov = nullptr;                 // device [R]: the main batch's hover sums (ray state)
-    hipStream_t aux = nullptr;            // high priority, non-blocking
-    hipEvent_t ev_main = nullptr, ev_aux = nullptr;
+    static constexpr int kAux = 4;
+    hipStream_t aux[kAux] = {nullptr, nullptr, nullptr, nullptr};   // high priority, non-blocking: successive chunks run side by side
+    hipEvent_t ev_main = nullptr, ev_aux[kAux] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned chunks = 0;                  // chunks launched since the last reset (chunk c goes to aux[c % kAux])
     unsigned launched = 0;                // slots handed to the sub-batch since the last reset
     unsigned scattered = 0;               // ... and copied back
     bool pending = false;                 // advance kernels ran since the queue was last drained
+    unsigned long long* dbg = nullptr;    // RTMI_DEBUG: device [8] statistics of k_retrace
     unsigned overflow = 0;                // rays that found the queue full this pass (they stay fused)
+    unsigned swept = 0;                   // rays whose fused tail hovered again and that were re-traced in reference order throughout
     uint64_t total = 0;                   // rays re-traced over the batch's life
 };
 static int retrace_create(rtmi_batch* b, const double* x0, const double* y0, const double* theta0);
@@ -2311,22 +2329,141 @@ static bool retrace_wanted(const rtmi_batch* b) {
            (p.reference_order == RTMI_ORDER_DEFAULT || p.reference_order == RTMI_ORDER_FAST_FIELD) &&
            rt::rotates_unit(p.method, true) && !getenv("RTMI_NO_RETRACE");
 }
-// slots of the queue: a few hundred rays of a million are critical on the interface fan; room for 1/128 of the batch
+// slots of the queue: a few hundred rays of a million are critical on the interface fan -- room for 1/128 of the batch, for 1 024 at
+// least (a small batch may be ALL window: 380 of the 4 096 rays around the interface fan's split), never for more than the batch
 static unsigned retrace_capacity(int64_t R) {
-    const int64_t c = (R / 128 + 63) / 64 * 64;
-    return (unsigned)std::min<int64_t>(std::max<int64_t>(c, 256), 65536);
+    const int64_t c = std::min<int64_t>(std::max<int64_t>((R / 128 + 63) / 64 * 64, 1024), 65536);
+    return (unsigned)std::min<int64_t>(c, (R + 63) / 64 * 64);
 }
-// slots [lo, hi) of the queue: launch conditions (and per-ray steps) of the queued rays into the sub-batch, initial conditions
-template <typename T>
-__global__ void k_retrace_prepare(BatchDev<T> s, BatchDev<T> m, double* sx0, double* sy0, double* sth0, T* svstep, T* svstep2h, int* svmax,
-                                  const unsigned long long* rq, unsigned lo, unsigned hi) {
-    const unsigned j = lo + blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= hi) return;
-    const long k = (long)(rq[1 + j] & 0xffffffffull);
-    if (k >= m.R) { s.alive[j] = 0; s.istep[j] = 0; return; }          // (never expected: an entry is a slot of the main batch)
-    sx0[j] = m.x0[k]; sy0[j] = m.y0[k]; sth0[j] = m.th0[k];
-    if (m.vstep && svstep) { svstep[j] = m.vstep[k]; svstep2h[j] = m.vstep2h[k]; svmax[j] = m.vmax[k]; }
-    init_ray(s, (long)j);
+// The re-trace of queue slots [lo, hi): one lane per ray, from its launch conditions (:809-826) --
+//   in the reference's operation order (rt::ex::ray_step: the oracle's bits, row for row) through the stretch that made the ray
+//   critical: until it has reached the row where the fused run stopped it AND has not hovered -- rt::hover_update's own test: in a
+//   steep cell, heading within 0.02 rad of the iso-lines -- for kRetraceOut steps;
+//   then in the fused form again (rt::ray_step, per-lane lookups) to its end: a ray that has turned away from the transition is as
+//   well conditioned as any other the fused kernels keep (the same measure says so), and the thousands of steps a refracted grazing
+//   ray still has to go to the box's far side (8 700 on the interface fan) cost 0.5 us each instead of 2.5.  Its rows from there on
+//   are the fused form's: ~1e-13 from the reference's.  Should the fused tail hover again (its sum starts from 0 at the hand-back)
+//   the lane starts over from the launch conditions with the reference-order part extended to the row it had reached.
+// Rows and final state go to the hidden batch's arrays s (slot j of every array), never to the main batch's: the main kernel is
+// still running.  m: the main batch (launch conditions, per-ray steps).  One wave per block, <= 168 registers: a block fits
+// wherever one of the main kernel's has retired.
+constexpr int kRetraceOut = 512;
+// Two kernels per chunk, one after the other on the chunk's stream (one wave per block; a lane = a queue slot):
+//   k_retrace_ref: the reference-order part.  A lane leaves its loop at the hand-back (state stored, alive = 1) or when its ray ends
+//   (alive = 0); no lane steps in two forms in one iteration.  marked_only: the final sweep for rays whose fused tail hovered again
+//   (alive = 2, see k_retrace_tail) -- those are taken in reference order to their END.
+//   k_retrace_tail: the fused part of the rays that were handed back, with the few-waves lookup (the wave's cell kept in vector
+//   registers, rt::kPolyCached): 0.75 us per step where per-lane loads two rows at a time take 3.
+template <int METHOD>
+__global__ __launch_bounds__(64, 3) void k_retrace_ref(BatchDev<double> s, BatchDev<double> m, const unsigned long long* rq, unsigned lo, unsigned hi,
+                                                       int marked_only, unsigned long long* dbg) {
+    typedef double T;
+    __builtin_amdgcn_s_setprio(3);          // beside the main kernel's waves: a handful of waves on the critical path of the call
+    const unsigned j = lo + blockIdx.x * 64u + threadIdx.x;
+    const bool valid = j < hi && (!marked_only || s.alive[j < hi ? j : lo] == 2);
+    const unsigned long long e = valid ? rq[1 + j] : 0ull;
+    long k = (long)(e & 0xffffffffull);
+    if (k >= m.R) k = 0;
+    rt::Consts<T> K = m.K;
+    int max_size = m.max_size;
+    if (m.vstep) { K.step = m.vstep[k]; K.step2h = m.vstep2h[k]; K.step2 = K.step2h * 2.0; max_size = m.vmax[k]; }
+    const int ref_until = marked_only ? 0x7fffffff : (int)(e >> 32);          // the row where the fused run stopped this ray
+    rt::GlobalGather<T> gg;
+    rt::Ray<T> r;
+    int i = 0, out = 0;
+    bool alive = valid && max_size > 1, handed = false;
+    if (valid) {                             // the initial conditions, as init_ray of a reference-order batch
+        r.x = m.x0[k]; r.y = m.y0[k]; r.th = m.th0[k];
+        rt::ex::n_gradient(s.F, gg, true, (T)r.x, (T)r.y, r.n, r.gx, r.gy);
+        rt::ex::derive(K, r);
+        r.dsim = 0; r.dreal = 0; r.tt = 0;
+        r.hx0 = r.hy0 = r.hx1 = r.hy1 = 0;
+        r.hov = 0.f; r.gstale = false; r.curflat = false;
+        if (s.stride && s.rec_rows > 0) write_row(s, 0, (long)j, r);
+    }
+    while (rt_ballot(alive && !handed) != 0ull) {
+        if (alive && !handed) {
+            ++i;
+            const T ux0 = r.ux, uy0 = r.uy;            // the tangent the step starts with
+            const bool inside = rt::ex::ray_step<METHOD>(s.F, K, gg, true, r, i);
+            // (reference order: Ray::hov is the steepness of the cell the ray arrived in, and the gradient there is current whenever
+            // that is not 0)
+            const T d = rt::fma_(r.gy, uy0, r.gx * ux0), g2 = rt::fma_(r.gy, r.gy, r.gx * r.gx);
+            out = (r.hov != 0.f && d * d < T(4e-4) * g2) ? 0 : out + 1;
+            if (s.stride && i % s.stride == 0 && i / s.stride < s.rec_rows) write_row(s, (long)(i / s.stride), (long)j, r);
+            alive = inside && (i + 1 < max_size);
+            handed = alive && i >= ref_until && out >= kRetraceOut;
+        }
+    }
+    if (valid) {
+        rt::ex::finish_state<METHOD>(s.F, gg, r);
+        s.acc(0)[j] = r.x; s.acc(1)[j] = r.y; s.acc(2)[j] = r.th; s.aux(0)[j] = r.n; s.aux(1)[j] = r.gx; s.aux(2)[j] = r.gy;
+        s.acc(3)[j] = r.dsim; s.acc(4)[j] = r.dreal; s.acc(5)[j] = r.tt;
+        s.istep[j] = i;
+        s.alive[j] = alive ? 1 : 0;
+        if (dbg) { atomicAdd(dbg, (unsigned long long)i); atomicMax(dbg + 3, (unsigned long long)i); }
+    }
+}
+template <int METHOD, bool ISO>
+__global__ __launch_bounds__(64, 2) void k_retrace_tail(BatchDev<double> s, BatchDev<double> m, const unsigned long long* rq, unsigned lo, unsigned hi,
+                                                        unsigned long long* dbg) {
+    typedef double T;
+    __builtin_amdgcn_s_setprio(3);
+    const unsigned j = lo + blockIdx.x * 64u + threadIdx.x;
+    const bool valid = j < hi && s.alive[j < hi ? j : lo] == 1;
+    long k = valid ? (long)(rq[1 + j] & 0xffffffffull) : 0;
+    if (k >= m.R) k = 0;
+    rt::Consts<T> K = m.K;
+    int max_size = m.max_size;
+    if (m.vstep) { K.step = m.vstep[k]; K.step2h = m.vstep2h[k]; K.step2 = K.step2h * 2.0; max_size = m.vmax[k]; }
+    const float hov_limit = m.hov_limit / (float)K.step;
+    rt::PolyGather<T, rt::kPolyCached, true> pg;
+    pg.init();
+    rt::Ray<T> r;
+    idle_ray(s, r);
+    int i = 0, i0 = 0;
+    if (valid) {
+        r.x = s.acc(0)[j]; r.y = s.acc(1)[j]; r.th = s.acc(2)[j]; r.n = s.aux(0)[j]; r.gx = s.aux(1)[j]; r.gy = s.aux(2)[j];
+        r.dsim = s.acc(3)[j]; r.dreal = s.acc(4)[j]; r.tt = s.acc(5)[j];
+        i = i0 = s.istep[j];
+        // the fused form continues from the reference's own state: the unit tangent it carries from here on is the reference's
+        // cos / sin of the angle
+        const rt::ex::SinCos u = rt::ex::sincos_(r.th);
+        r.ux = u.c; r.uy = u.s;
+        rt::derive<T, ISO, true>(K, r);
+    }
+    bool alive = valid;
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    // every lane runs every iteration (the kept-cell lookup votes); a lane whose ray has ended evolves a stale state nobody reads:
+    // what it leaves behind is stored the moment it ends
+    while (rt_ballot(alive) != 0ull) {
+        const bool active = alive;
+        const int row = i + 1;
+        const bool inside = rt::ray_step<T, METHOD, ISO>(s.F, K, pg, active, r, row);
+        if (active) {
+            i = row;
+            if (s.stride && i % s.stride == 0 && i / s.stride < s.rec_rows) write_row(s, (long)(i / s.stride), (long)j, r);
+            alive = inside && (i + 1 < max_size);
+            const bool again = r.hov > hov_limit;       // hovering again further on: the final sweep takes this ray in reference order throughout
+            if (again) alive = false;
+            if (!alive) {
+                s.acc(0)[j] = r.x; s.acc(1)[j] = r.y; s.acc(2)[j] = r.th; s.aux(0)[j] = r.n; s.aux(1)[j] = r.gx; s.aux(2)[j] = r.gy;
+                s.acc(3)[j] = r.dsim; s.acc(4)[j] = r.dreal; s.acc(5)[j] = r.tt;
+                s.istep[j] = i;
+                s.alive[j] = again ? 2 : 0;
+                if (again) atomicAdd(s.counters + 3, 1ull);          // the hidden batch's counters[3]: rays for the final sweep
+                if (dbg) { atomicAdd(dbg + 1, (unsigned long long)(i - i0)); atomicAdd(dbg + 2, again ? 1ull : 0ull); atomicMax(dbg + 4, (unsigned long long)i); }
+            }
+        }
+    }
+}
+static const void* retrace_ref_fn(int method) {
+    return method == 1 ? (const void*)k_retrace_ref<1> : method == 2 ? (const void*)k_retrace_ref<2> : method == 6 ? (const void*)k_retrace_ref<6> : (const void*)k_retrace_ref<8>;
+}
+static const void* retrace_tail_fn(int method, bool iso) {
+    static const void* const tab[4][2] = {{(const void*)k_retrace_tail<1, false>, (const void*)k_retrace_tail<1, true>}, {(const void*)k_retrace_tail<2, false>, (const void*)k_retrace_tail<2, true>},
+                                          {(const void*)k_retrace_tail<6, false>, (const void*)k_retrace_tail<6, true>}, {(const void*)k_retrace_tail<8, false>, (const void*)k_retrace_tail<8, true>}};
+    return tab[method == 1 ? 0 : method == 2 ? 1 : method == 6 ? 2 : 3][iso ? 1 : 0];
 }
 // ... and back: the re-traced ray's rows and final state over the fused ones.  A row the fused run wrote past the re-traced
 // ray's last row (the two may leave the box a row apart) reads 0 like every row past a ray's end (:802).
@@ -2364,13 +2501,13 @@ __global__ void k_retrace_scatter(BatchDev<T> m, BatchDev<T> s, const unsigned l
 static void retrace_destroy(rtmi_batch* b) {
     Retrace* t = b->rt;
     if (!t) return;
-    if (t->aux) (void)hipStreamSynchronize(t->aux);
+    for (hipStream_t a : t->aux) if (a) (void)hipStreamSynchronize(a);
     if (t->sub) rtmi_batch_destroy(t->sub);
-    (void)hipFree(t->rq); (void)hipFree(t->hov);
+    (void)hipFree(t->rq); (void)hipFree(t->hov); (void)hipFree(t->dbg);
     if (t->host_count) (void)hipHostFree(t->host_count);
     if (t->ev_main) (void)hipEventDestroy(t->ev_main);
-    if (t->ev_aux) (void)hipEventDestroy(t->ev_aux);
-    if (t->aux) (void)hipStreamDestroy(t->aux);
+    for (hipEvent_t e : t->ev_aux) if (e) (void)hipEventDestroy(e);
+    for (hipStream_t a : t->aux) if (a) (void)hipStreamDestroy(a);
     delete t;
     b->rt = nullptr;
 }
@@ -2380,17 +2517,21 @@ static int retrace_create(rtmi_batch* b, const double* x0, const double* y0, con
     if (!t) return fail(RTMI_ERR_ALLOC, "rtmi_batch_create: host allocation failed");
     b->rt = t;                                  // rtmi_batch_destroy frees whatever is there if anything below fails
     t->cap = retrace_capacity(b->R);
-    const size_t Rs = (size_t)t->cap + 256;     // + a block of padding: offset views of the sub-batch read alive[] up to a block past their end
+    const size_t Rs = (size_t)t->cap;
     HIP_TRY(hipMalloc(&t->rq, (1 + (size_t)t->cap) * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(t->rq, 0, (1 + (size_t)t->cap) * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(&t->hov, (size_t)b->R * sizeof(float)));
+    if (getenv("RTMI_DEBUG")) { HIP_TRY(hipMalloc(&t->dbg, 8 * sizeof(unsigned long long))); HIP_TRY(hipMemset(t->dbg, 0, 8 * sizeof(unsigned long long))); }
     HIP_TRY(hipHostMalloc(&t->host_count, 4 * sizeof(unsigned)));
     t->host_count[0] = t->host_count[1] = t->host_count[2] = t->host_count[3] = 0;
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));           // hi is the numerically lowest = highest priority
-    HIP_TRY(hipStreamCreateWithPriority(&t->aux, hipStreamNonBlocking, hi));
+    if (getenv("RTMI_DEBUG")) fprintf(stderr, "rtmi: retrace: stream priorities %d (lowest) .. %d (highest); queue of %u slots\n", lo, hi, t->cap);
+    for (int i = 0; i < Retrace::kAux; i++) {
+        HIP_TRY(hipStreamCreateWithPriority(&t->aux[i], hipStreamNonBlocking, hi));
+        HIP_TRY(hipEventCreateWithFlags(&t->ev_aux[i], hipEventDisableTiming));
+    }
     HIP_TRY(hipEventCreateWithFlags(&t->ev_main, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&t->ev_aux, hipEventDisableTiming));
     // the hidden batch: same field, method, steps, box and record layout, reference order, one plain launch per chunk
     rtmi_params ps = b->p;
     ps.reference_order = RTMI_ORDER_REFERENCE;
@@ -2403,11 +2544,11 @@ static int retrace_create(rtmi_batch* b, const double* x0, const double* y0, con
     } catch (const std::exception& e) {
         return fail(RTMI_ERR_ALLOC, std::string("rtmi_batch_create: ") + e.what());
     }
-    const int rc = rtmi_batch_create(b->field, &ps, (int64_t)Rs, hx.data(), hy.data(), ht.data(), (void*)t->aux, &t->sub);
+    const int rc = rtmi_batch_create(b->field, &ps, (int64_t)Rs, hx.data(), hy.data(), ht.data(), (void*)t->aux[0], &t->sub);
     if (rc) { t->sub = nullptr; return rc; }
     t->sub->is_retrace_sub = true;
-    HIP_TRY(hipMemsetAsync(t->sub->alive, 0, Rs, t->aux));        // no slot holds a ray yet
-    HIP_TRY(hipStreamSynchronize(t->aux));
+    HIP_TRY(hipMemsetAsync(t->sub->alive, 0, Rs, t->aux[0]));        // no slot holds a ray yet
+    HIP_TRY(hipStreamSynchronize(t->aux[0]));
     return RTMI_OK;
 }
 
@@ -2416,40 +2557,27 @@ static int retrace_create(rtmi_batch* b, const double* x0, const double* y0, con
 static int retrace_reset(rtmi_batch* b) {
     Retrace* t = b->rt;
     if (t->pending) HIP_TRY(hipStreamSynchronize(b->stream));
-    HIP_TRY(hipStreamSynchronize(t->aux));
+    for (hipStream_t a : t->aux) HIP_TRY(hipStreamSynchronize(a));
+    t->chunks = 0;
     HIP_TRY(hipMemsetAsync(t->rq, 0, sizeof(unsigned long long), b->stream));
     t->host_count[0] = 0;
+    HIP_TRY(hipMemsetAsync(t->sub->counters + 3, 0, sizeof(unsigned long long), b->stream));
     t->launched = t->scattered = 0; t->pending = false; t->overflow = 0;
     return RTMI_OK;
 }
 
-// queue slots [lo, hi) -> the sub-batch, to completion, on `st`
-static int retrace_launch_chunk(rtmi_batch* b, unsigned lo, unsigned hi, hipStream_t st) {
+// queue slots [lo, hi) re-traced to completion on `st`: the reference-order part, then the fused tails
+static int retrace_launch_chunk(rtmi_batch* b, unsigned lo, unsigned hi, hipStream_t st, int marked_only = 0) {
     Retrace* t = b->rt;
-    rtmi_batch* sb = t->sub;
-    if (b->vstep && !sb->vstep) {     // the main batch got per-ray steps (rtmi_batch_set_per_ray): the sub-batch needs the arrays too
-        const size_t Rs = (size_t)sb->R;
-        HIP_TRY(hipMalloc(&sb->vstep, Rs * 8)); HIP_TRY(hipMalloc(&sb->vstep2h, Rs * 8)); HIP_TRY(hipMalloc(&sb->vmax, Rs * sizeof(int)));
-        HIP_TRY(hipMemsetAsync(sb->vstep, 0, Rs * 8, st)); HIP_TRY(hipMemsetAsync(sb->vstep2h, 0, Rs * 8, st)); HIP_TRY(hipMemsetAsync(sb->vmax, 0, Rs * sizeof(int), st));
+    BatchDev<double> m = batch_dev<double>(b), s = batch_dev<double>(t->sub);
+    const unsigned long long* rq = t->rq;
+    unsigned long long* dbg = t->dbg;
+    void* args[] = {&s, &m, &rq, &lo, &hi, &marked_only, &dbg};
+    HIP_TRY(hipLaunchKernel(retrace_ref_fn(b->p.method), dim3((hi - lo + 63) / 64), dim3(64), args, 0, st));
+    if (!marked_only) {
+        void* targs[] = {&s, &m, &rq, &lo, &hi, &dbg};
+        HIP_TRY(hipLaunchKernel(retrace_tail_fn(b->p.method, b->p.gamma == 1.0), dim3((hi - lo + 63) / 64), dim3(64), targs, 0, st));
     }
-    const BatchDev<double> m = batch_dev<double>(b);
-    BatchDev<double> s = batch_dev<double>(sb);
-    const unsigned n = hi - lo;
-    const size_t Rs = (size_t)sb->R;
-    hipLaunchKernelGGL(k_retrace_prepare<double>, dim3((n + 255) / 256), dim3(256), 0, st, s, m, sb->launch, sb->launch + Rs, sb->launch + 2 * Rs,
-                       (double*)sb->vstep, (double*)sb->vstep2h, sb->vmax, (const unsigned long long*)t->rq, lo, hi);
-    HIP_TRY(hipGetLastError());
-    // the advance kernel on an offset view of the sub-batch: slot lo is the view's ray 0 (same pitch R: every array moves by lo)
-    BatchDev<double> v = s;
-    v.st += lo; v.istep += lo; v.alive += lo;
-    if (v.s_ray) v.s_ray += lo;
-    if (v.n_ray) v.n_ray += lo;
-    v.x0 += lo; v.y0 += lo; v.th0 += lo;
-    if (v.vstep) { v.vstep += lo; v.vstep2h += lo; v.vmax += lo; }
-    sb->kfn = pick_advance(sb);
-    int nsteps = sb->p.max_size;
-    void* args[] = {&v, &nsteps};
-    HIP_TRY(hipLaunchKernel(sb->kfn, dim3((n + 255) / 256), dim3(256), args, 0, st));
     return RTMI_OK;
 }
 
@@ -2473,6 +2601,8 @@ static int retrace_drain(rtmi_batch* b, bool overlap) {
     if (overlap) {
         HIP_TRY(hipEventRecord(t->ev_main, b->stream));
         auto last_change = std::chrono::steady_clock::now();
+        const auto t_start = last_change;
+        const bool dbg = getenv("RTMI_DEBUG") != nullptr;
         unsigned seen = t->launched;
         for (;;) {
             const hipError_t q = hipEventQuery(t->ev_main);
@@ -2484,16 +2614,24 @@ static int retrace_drain(rtmi_batch* b, bool overlap) {
             if (count > seen) { seen = count; last_change = now; }
             // a chunk: what has arrived once the main kernel is done, a wave's worth, or whatever there is when nothing has come for 100 us
             if (count > t->launched && (done || count - t->launched >= 64 || now - last_change > std::chrono::microseconds(100))) {
-                const int rc = retrace_launch_chunk(b, t->launched, count, t->aux);
+                const int rc = retrace_launch_chunk(b, t->launched, count, t->aux[t->chunks++ % Retrace::kAux]);
                 if (rc) return rc;
+                if (dbg) fprintf(stderr, "rtmi: retrace: slots [%u, %u) launched %.3f ms after the main kernel%s\n", t->launched, count,
+                                 std::chrono::duration<double, std::milli>(now - t_start).count(), done ? " (which had finished)" : "");
                 t->launched = count;
             }
-            if (done) break;
+            if (done) {
+                if (dbg) fprintf(stderr, "rtmi: retrace: main kernel done after %.3f ms; %u rays handed over, %u found the queue full\n",
+                                 std::chrono::duration<double, std::milli>(now - t_start).count(), t->launched, t->overflow);
+                break;
+            }
             std::this_thread::sleep_for(std::chrono::microseconds(20));
         }
         if (t->launched > t->scattered) {
-            HIP_TRY(hipEventRecord(t->ev_aux, t->aux));
-            HIP_TRY(hipStreamWaitEvent(b->stream, t->ev_aux, 0));
+            for (int i = 0; i < Retrace::kAux; i++) {
+                HIP_TRY(hipEventRecord(t->ev_aux[i], t->aux[i]));
+                HIP_TRY(hipStreamWaitEvent(b->stream, t->ev_aux[i], 0));
+            }
         }
     } else {
         const int rc = read_count();
@@ -2508,6 +2646,17 @@ static int retrace_drain(rtmi_batch* b, bool overlap) {
         }
     }
     if (t->launched > t->scattered) {
+        // rays whose fused tail hovered again (expected: none): in reference order to their end, now
+        HIP_TRY(hipMemcpyAsync(t->host_count + 2, t->sub->counters + 3, sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        unsigned long long again = 0;
+        memcpy(&again, t->host_count + 2, sizeof again);
+        if (again) {
+            HIP_TRY(hipMemsetAsync(t->sub->counters + 3, 0, sizeof(unsigned long long), b->stream));
+            const int rca = retrace_launch_chunk(b, t->scattered, t->launched, b->stream, 1);
+            if (rca) return rca;
+            t->swept += (unsigned)again;
+        }
         const unsigned n = t->launched - t->scattered;
         const long rows = b->p.record_stride ? (long)b->p.rec_rows : 1;
         const dim3 g((n + 63) / 64, (unsigned)std::min<long>(rows, 1024)), blk(64);
@@ -2516,6 +2665,13 @@ static int retrace_drain(rtmi_batch* b, bool overlap) {
         HIP_TRY(hipGetLastError());
         t->total += n;
         t->scattered = t->launched;
+        if (t->dbg) {
+            unsigned long long h[5] = {0, 0, 0, 0, 0};
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            HIP_TRY(hipMemcpy(h, t->dbg, sizeof h, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemset(t->dbg, 0, 8 * sizeof(unsigned long long)));
+            fprintf(stderr, "rtmi: retrace: %u rays: %llu reference-order steps (at most %llu per ray), %llu fused steps, longest ray %llu steps, %llu hovered again\n", n, h[0], h[3], h[1], h[4], h[2]);
+        }
     }
     if (evp) HIP_TRY(hipEventRecord(evp->second, b->stream));
     t->pending = false;

@@ -9,7 +9,7 @@ RTMI_DEBUG=1 timeout -k 10 600 python tools/critical_ray_window.py > $O/critical
 cat $O/critical.txt
 for nr in 0 1; do
   for rec in none full; do
-    RTMI_NO_RETRACE=$nr timeout -k 10 300 python bench.py --scenario interface --record $rec --steps 5 --cpu-seconds 0 --mode plain > $O/iface_${rec}_nr$nr.json 2> $O/iface_${rec}_nr$nr.err; echo "iface $rec noretrace=$nr rc $?"
+    $( [ $nr = 1 ] && echo env RTMI_NO_RETRACE=1 ) timeout -k 10 300 python bench.py --scenario interface --record $rec --steps 5 --cpu-seconds 0 --mode plain > $O/iface_${rec}_nr$nr.json 2> $O/iface_${rec}_nr$nr.err; echo "iface $rec noretrace=$nr rc $?"
   done
 done
 timeout -k 10 300 python bench.py --scenario interface --record none --steps 5 --cpu-seconds 0 > $O/iface_none_auto.json 2> $O/iface_none_auto.err; echo "iface auto rc $?"
