@@ -293,6 +293,7 @@ void rtmi_batch_destroy(rtmi_batch *b);
  * collective on the data path.  One host thread drives every GPU (the library starts one worker per device for the runs).
  * The read-back functions gather to devices[0] DEVICE TO DEVICE -- RCCL's ncclGather over xGMI between the communicators
  * of ncclCommInitAll, or peer copies -- and answer in the caller's ray order; results are the bits of an unsharded batch.
+ * Every rtmi_shard_* call leaves the calling thread's current HIP device as it found it.
  * (One process per GPU is the other way to spread a call: raytracing_amd/dist.py over torch.distributed.) */
 typedef struct rtmi_shard rtmi_shard;
 typedef enum {

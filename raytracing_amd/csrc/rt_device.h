@@ -513,7 +513,9 @@ __device__ __forceinline__ void lookup_global_rows(const FieldDev<T>& F, const C
 #define RTMI_GLOBAL_PHASES 2
 #endif
 // Gather policy 1: every lookup reads its 36 coefficients from global memory (L1/L2-resident in practice).
-template <typename T> struct GlobalGather {
+// FLATMAP (rt_exact.h, the reference-order step where the medium is constant): false in the builds for fields whose flat-cell map is
+// empty -- the flat path is not even compiled in there (as run-time tests it cost the vert_heterogeneous fan in reference order a third).
+template <typename T, bool FLATMAP = true> struct GlobalGather {
     static constexpr bool kUniformWindow = true;     // rt::ex::n_gradient: a wave in one cell reads the window through the scalar cache
     __device__ __forceinline__ void fetch(const FieldDev<T>& F, const Cell<T>& c, bool active, T z[4], Pair<T> g[4][4]) {
         // an idle lane reads the grid's first window instead of its stale cell: all idle lanes then share one
@@ -743,8 +745,8 @@ __device__ __forceinline__ void n_gradient(const FieldDev<T>& F, G& gather, bool
         gather.lookup(F, c, active, n, gx, gy);
     }
 }
-template <typename T>
-__device__ __forceinline__ void GlobalGather<T>::lookup(const FieldDev<T>& F, const Cell<T>& c, bool active, T& n, T& gx, T& gy) {
+template <typename T, bool FLATMAP>
+__device__ __forceinline__ void GlobalGather<T, FLATMAP>::lookup(const FieldDev<T>& F, const Cell<T>& c, bool active, T& n, T& gx, T& gy) {
     // The window in two halves of two rows: 9 loads in flight instead of 18, and the kernel fits three waves per SIMD
     // without spilling (143 instead of 168 VGPRs + 35 spilled).  A/B in one session: 15.0 vs 18.1 ms without recording,
     // 24.0 vs 30.2 ms with the full record (four phases / four waves per SIMD: 15.2 / 24.1 ms).

@@ -908,7 +908,7 @@ __device__ __forceinline__ void derive(const Consts<double>& k, Ray<double>& r) 
 // arctan2 and the sin / cos of its result and skip the rest.
 template <int METHOD> constexpr bool flat_shortcut() { return RTMI_FLAT_MAP && (METHOD == 1 || METHOD == 2 || METHOD == 6 || METHOD == 8); }
 template <typename G> struct IsGlobalGather { static constexpr bool value = false; };
-template <> struct IsGlobalGather<GlobalGather<double>> { static constexpr bool value = true; };
+template <> struct IsGlobalGather<GlobalGather<double, true>> { static constexpr bool value = true; };
 
 // fpbspl for k = 1 on the cell's true knots (the linear part of axis_exact): j, and the two weights
 __device__ __forceinline__ int axis_linear(double v, int q, double a, double h, double b, double ih, const double* rd, double wl[2]) {

@@ -939,12 +939,12 @@ template <typename T> __device__ __forceinline__ void idle_ray(const BatchDev<T>
 template <typename T, int METHOD> constexpr bool uses_poly() { return RTMI_POLY && (!rt::IsExact<T, METHOD>::value || (METHOD & rt::kFastField) != 0); }
 template <typename T, int METHOD, bool LDS> constexpr bool uses_tile() { return LDS && !uses_poly<T, METHOD>(); }
 // NOFLAT: the field has no flat cell (rt::PolyGather's FLAT false: the flat-cell map's tests compiled out).
-template <typename T, int METHOD, bool LDS, int PH = RTMI_TILE_PHASES, bool NOFLAT = false, bool POLY = uses_poly<T, METHOD>()> struct GatherOf { using type = rt::GlobalGather<T>; };
+template <typename T, int METHOD, bool LDS, int PH = RTMI_TILE_PHASES, bool NOFLAT = false, bool POLY = uses_poly<T, METHOD>()> struct GatherOf { using type = rt::GlobalGather<T, !NOFLAT>; };
 template <typename T, int METHOD, int PH, bool NOFLAT> struct GatherOf<T, METHOD, true, PH, NOFLAT, false> { using type = rt::LdsGather<T, PH>; };
 template <typename T, int METHOD, bool LDS, int PH, bool NOFLAT> struct GatherOf<T, METHOD, LDS, PH, NOFLAT, true> {
     using type = rt::PolyGather<T, !LDS ? rt::kPolyLane : PH == 1 ? rt::kPolyCached : rt::kPolyScalar, !NOFLAT>;   // PH 1: k_advance_lat
 };
-template <typename T, bool LDS> __device__ __forceinline__ void gather_init(rt::GlobalGather<T>&, T*) {}
+template <typename T, bool LDS, bool FM> __device__ __forceinline__ void gather_init(rt::GlobalGather<T, FM>&, T*) {}
 template <typename T, bool LDS, int MODE, bool FLAT> __device__ __forceinline__ void gather_init(rt::PolyGather<T, MODE, FLAT>& g, T*) { g.init(); }
 // LDS of a step kernel in units of T: the reference-order methods' tile; the polynomial lookup needs none.  (An L2 prefetch of
 // the cells ahead -- global_load_lds into a per-wave sink whenever the wave's cell changes -- was measured: interface 23.6 ->
@@ -1638,6 +1638,15 @@ constexpr bool iso_ok(int m) { return rt::base_method(m) < 10; }
 #define RTMI_SLICEDNF_(T, I) \
     {(const void*)k_advance_sliced<T, km<T>(I), false, true, uses_poly<T, km<T>(I)>()>, \
      (const void*)k_advance_sliced<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), true, uses_poly<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1)>()>}
+// ... and the per-lane-gather builds of op1/2/6/8 in reference order (kernel indices 11, 12, 13, 15) for a field whose map is empty: without
+// the flat path of the reference-order step (rt::GlobalGather's FLATMAP).  Every other index: the ordinary build again.
+constexpr bool ref1268(int idx) { return idx == 11 || idx == 12 || idx == 13 || idx == 15; }
+#define RTMI_ADVNF0_(T, I) \
+    {(const void*)k_advance<T, km<T>(I), false, false, false, sizeof(T) == 8 && ref1268(I)>, \
+     (const void*)k_advance<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), false, false, sizeof(T) == 8 && ref1268(I) && iso_ok(km<T>(I))>}
+#define RTMI_SLICEDNF0_(T, I) \
+    {(const void*)k_advance_sliced<T, km<T>(I), false, false, sizeof(T) == 8 && ref1268(I)>, \
+     (const void*)k_advance_sliced<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), false, sizeof(T) == 8 && ref1268(I) && iso_ok(km<T>(I))>}
 #define RTMI_ADVVAR_(T, I) \
     {(const void*)k_advance<T, km<T>(I), false, false, true>, (const void*)k_advance<T, (iso_ok(km<T>(I)) ? km<T>(I) : 1), iso_ok(km<T>(I)), false, true>}
 #define RTMI_REFILL_(T, I) \
@@ -1650,11 +1659,15 @@ constexpr bool iso_ok(int m) { return rt::base_method(m) < 10; }
 template <typename T> static const void* sliced_fn(int ki, bool iso, bool lds, bool noflat) {
     static const void* const tab[kKernelMethods][2][2] = {RTMI_ALL16_(RTMI_SLICED_, T)};
     static const void* const tabnf[kKernelMethods][2] = {RTMI_ALL16_(RTMI_SLICEDNF_, T)};
+    static const void* const tabnf0[kKernelMethods][2] = {RTMI_ALL16_(RTMI_SLICEDNF0_, T)};
+    if (!lds && noflat) return tabnf0[ki][iso ? 1 : 0];
     return lds && noflat ? tabnf[ki][iso ? 1 : 0] : tab[ki][iso ? 1 : 0][lds ? 1 : 0];
 }
 template <typename T> static const void* advance_fn(int ki, bool iso, bool lds, bool noflat) {
     static const void* const tab[kKernelMethods][2][2] = {RTMI_ALL16_(RTMI_ADV_, T)};
     static const void* const tabnf[kKernelMethods][2] = {RTMI_ALL16_(RTMI_ADVNF_, T)};
+    static const void* const tabnf0[kKernelMethods][2] = {RTMI_ALL16_(RTMI_ADVNF0_, T)};
+    if (!lds && noflat) return tabnf0[ki][iso ? 1 : 0];
     return lds && noflat ? tabnf[ki][iso ? 1 : 0] : tab[ki][iso ? 1 : 0][lds ? 1 : 0];
 }
 // per-ray DELTA_S / max_size builds (global gather only): [kernel method][iso]
@@ -1669,6 +1682,8 @@ template <typename T> static const void* refill_fn(int ki, bool iso, bool lds) {
 #undef RTMI_SLICED_
 #undef RTMI_ADV_
 #undef RTMI_ADVNF_
+#undef RTMI_ADVNF0_
+#undef RTMI_SLICEDNF0_
 #undef RTMI_SLICEDNF_
 #undef RTMI_ADVVAR_
 #undef RTMI_REFILL_

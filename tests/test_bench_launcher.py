@@ -105,3 +105,21 @@ def test_rays_per_gpu_asks_for_the_weak_line():
     g = out["config"]["dist"]["gather"]
     assert g["trajectory"]["shape"] == [12, 6, 2 * 65536]          # every 256th of 3 072 rows, both ranks' rays in ray order
     assert out["parity_check"]["ok"]
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_plain_start_with_two_real_gpus_over_rccl():
+    """`python3 bench.py --gpus 2` exactly as the driver types it, on a host with two GPUs: one rank per GPU, RCCL (nccl) for the
+    timing reductions and the device-to-device read-back gather.  A one-GPU box skips it."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--cpu-seconds", "0", "--record", "stride:16"],
+                       capture_output=True, text=True, env=_env_without_rank_variables(), timeout=850)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["rays_total"] == 1048576
+    g = out["config"]["dist"]
+    assert g["backend"] == "nccl" and g["gather"]["world"] == 2 and "error" not in g["gather"]
+    assert out["parity_check"]["ok"] and "error" not in out["weak"]

@@ -79,15 +79,17 @@ def _worker(rank, world, port, tmp):
 
 
 def _worker_rccl(rank, world, port, tmp):
-    """One rank, backend nccl (RCCL): trazar_sharded's device-to-device payload -- zero-copy views of the batch's HBM arrays
-    through dist.gather -- against the plain call.  (One GPU carries one RCCL rank; the N > 1 case is the same code.)"""
+    """Backend nccl (RCCL), one rank per GPU: trazar_sharded's device-to-device payload -- zero-copy views of the batch's HBM arrays
+    through dist.gather -- against the plain call.  world 1 on a one-GPU box (one GPU carries one RCCL rank); world >= 2 -- real
+    peers over xGMI, ragged splits, a rank-0 gather of other devices' blocks -- where the host has the GPUs."""
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
     torch.cuda.init()
-    torch.cuda.set_device(0)
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    torch.cuda.set_device(rank)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     try:
         from raytracing_amd import dist as rd
         from raytracing_amd import rt_bench as rb
@@ -98,7 +100,10 @@ def _worker_rccl(rank, world, port, tmp):
                  ("vert_heterogeneous", "3", rb.op6, np.linspace(0, np.pi / 2, 777), 8, rb.F32),
                  ("interface", "1", rb.op6, None, "full", rb.F64)]
         for scen, choice, op, th, record, dtype in cases:
-            res = rd.trazar_sharded(op, scen, False, rb.DELTA_S, 91, choice, thetas=th, record=record, dtype=dtype, device=0)
+            res = rd.trazar_sharded(op, scen, False, rb.DELTA_S, 91, choice, thetas=th, record=record, dtype=dtype, device=rank)
+            if rank != 0:
+                assert res is None
+                continue
             fld = rb.Field.build(scen, dtype=dtype)
             z, grd = rb.FieldSpline(fld, "n"), (rb.FieldSpline(fld, "dy"), rb.FieldSpline(fld, "dx"))
             ref = rb.trazar(op, z, grd, False, rb.DELTA_S, 91, choice, thetas=th, record=record)
@@ -108,7 +113,9 @@ def _worker_rccl(rank, world, port, tmp):
                 assert res[0].shape == ref[0].shape and np.array_equal(res[0], ref[0]), (scen, record)
             else:
                 assert res[0] is None
-        open(os.path.join(tmp, "ok"), "w").write("ok")
+        if rank == 0:
+            open(os.path.join(tmp, "ok"), "w").write("ok")
+        dist.barrier()
     finally:
         dist.destroy_process_group()
 
@@ -116,6 +123,22 @@ def _worker_rccl(rank, world, port, tmp):
 @pytest.mark.timeout(600)
 def test_trazar_sharded_device_gather_over_rccl(tmp_path):
     mp.spawn(_worker_rccl, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    assert (tmp_path / "ok").exists()
+
+
+def _gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [2, 4])
+def test_trazar_sharded_over_rccl_on_distinct_gpus(world, tmp_path):
+    """The N > 1 RCCL path proper: one rank per GPU, ncclGather between real peers.  Runs where the host has the GPUs (the
+    driver's multi-GPU node); a one-GPU box skips it."""
+    if _gpus() < world:
+        pytest.skip(f"needs {world} GPUs, this host has {_gpus()}")
+    mp.spawn(_worker_rccl, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     assert (tmp_path / "ok").exists()
 
 

@@ -44,6 +44,68 @@ def test_shard_equals_one_batch(devices, transport, expect, rb):
     sh.close()
 
 
+def _gpus():
+    from raytracing_amd import _lib
+    import ctypes as C
+    n = C.c_int(0)
+    _lib.check(_lib.lib().rtmi_device_count(C.byref(n)))
+    return n.value
+
+
+@pytest.mark.parametrize("devices,transport,expect", [([0, 1], "rccl", "rccl"), ([0, 1], "copy", "copy"), ([1, 0], "auto", "rccl"),
+                                                      ([0, 1, 2], "auto", "rccl"), ([0, 1, 2, 3], "copy", "copy")])
+def test_shard_on_distinct_devices(devices, transport, expect, rb):
+    """The shard split over DISTINCT GPUs -- ncclCommInitAll with several communicators, ncclGather between them,
+    hipMemcpyPeerAsync between devices, k_interleave on gathered remote blocks -- against one batch on device 0, bit for bit;
+    and the caller's current device is the one it was before every call (include/rtmi.h).  Runs where the host has the GPUs (the
+    driver's multi-GPU node); a one-GPU box skips it."""
+    if _gpus() <= max(devices):
+        pytest.skip(f"needs {max(devices) + 1} GPUs, this host has {_gpus()}")
+    import torch
+    from raytracing_amd import _lib
+    _lib.check(_lib.lib().rtmi_set_device(0))
+    scen, m, gam = "vert_heterogeneous", 6, 1
+    th = np.linspace(0, np.pi / 2, 1001)                 # ragged splits
+    ms, rows = 3100, 3100
+    d0, f0, s0, steps0 = _reference(rb, scen, m, rb.DELTA_S, ms, gam, th, -2.0, -2.0, 1, rows)
+    cur = torch.cuda.current_device()
+    sh = rb.Shard(scen, m, rb.DELTA_S, ms, LIMITS[scen], gam, th, -2.0, -2.0, devices, record_stride=1, rec_rows=rows, transport=transport)
+    assert torch.cuda.current_device() == cur
+    sh.run()
+    info = sh.info()
+    assert torch.cuda.current_device() == cur
+    assert info["transport"] == expect and info["ndev"] == len(devices) and info["ray_steps"] == steps0 and info["live_rays"] == 0
+    assert np.array_equal(sh.d_ray(), d0) and np.array_equal(sh.final(), f0)
+    assert np.array_equal(sh.rows(0, rows), s0) and np.array_equal(sh.rows(5, 40, every=64), s0[5::64][:40])
+    assert torch.cuda.current_device() == cur
+    sh.reset(); sh.run()
+    assert np.array_equal(sh.d_ray(), d0)
+    # a second shard on the same devices (peer access already enabled) and an ordinary batch afterwards on the caller's device
+    sh2 = rb.Shard(scen, m, rb.DELTA_S, ms, LIMITS[scen], gam, th[:333], -2.0, -2.0, devices, record_stride=0, transport="copy")
+    sh2.run()
+    assert np.array_equal(sh2.d_ray(), d0[:, :333])
+    sh2.close(); sh.close()
+    assert torch.cuda.current_device() == cur
+    d1, *_ = _reference(rb, scen, m, rb.DELTA_S, ms, gam, th[:64], -2.0, -2.0, 0, 0)
+    assert np.array_equal(d1, d0[:, :64])
+
+
+def test_shard_leaves_the_callers_device_alone(rb):
+    """One GPU: every rtmi_shard_* entry restores the calling thread's current device (a handle of the rest of the ABI made before
+    still works after), and a second shard right after the first does not trip over a stale HIP error."""
+    th = np.linspace(0, np.pi / 2, 257)
+    F = rb.Field.build("vert_heterogeneous")
+    b = rb.Batch(F, 6, rb.DELTA_S, 3100, LIMITS["vert_heterogeneous"], 1, th, -2.0, -2.0, record_stride=0)
+    for _ in range(2):
+        sh = rb.Shard("vert_heterogeneous", 6, rb.DELTA_S, 3100, LIMITS["vert_heterogeneous"], 1, th, -2.0, -2.0, [0, 0], record_stride=0)
+        sh.run()
+        d = sh.d_ray()
+        sh.info(); sh.close()
+    b.run()                                   # a batch made before the shard calls: its field's device is still current
+    assert np.array_equal(b.d_ray(), d)
+    b.close(); F.close()
+
+
 def test_shard_other_methods_and_precisions(rb):
     rng = np.random.default_rng(3)
     for scen, m, gam, dtype, th in (("anisotropy", 11, 3, 0, np.linspace(0, np.pi / 2, 130)),
