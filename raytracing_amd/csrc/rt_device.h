@@ -18,6 +18,9 @@
 #ifndef RTMI_FLAT_MAP
 #define RTMI_FLAT_MAP 1     // 0 compiles the flat-cell map's tests out of the lookups (A/B of what they cost a field without flat cells)
 #endif
+#ifndef RTMI_LAT_RELOAD
+#define RTMI_LAT_RELOAD 0   // k_advance_lat's kept cell: 0 reloaded with vector loads (vmcnt(0): also waits for the row stores before), 1 through the scalar cache + copies
+#endif
 #ifndef RTMI_POLY
 #define RTMI_POLY 1     // 1: the fast-form step methods look the field up as one polynomial per cell (PolyGather); 0: B-spline sums
 #endif
@@ -999,6 +1002,23 @@ template <typename T, int MODE, bool FLAT = true> struct PolyGather {
                 return;
             }
         }
+#if RTMI_LAT_RELOAD == 1
+        // through the scalar cache, three rows at a time, copied into the kept cell's vector registers: scalar loads count in
+        // lgkmcnt, so this reload does not wait for the trajectory stores of the steps before (vmcnt is one in-order counter)
+        {
+            ScalarRows p = (ScalarRows)(F.poly + (size_t)cu * kPolyStride);
+            asm volatile("" : "+s"(p));
+#pragma unroll
+            for (int g = 0; g < N; g += 3) {
+                Quad<T> a0 = p[g], a1 = p[g + 1 < N ? g + 1 : g], a2 = p[g + 2 < N ? g + 2 : g];
+                rows[g] = a0;
+                if (g + 1 < N) rows[g + 1] = a1;
+                if (g + 2 < N) rows[g + 2] = a2;
+                asm volatile("" : "+v"(rows[g]) : : "memory");
+            }
+            return;
+        }
+#endif
         // every lane loads the same 288 bytes (one address per instruction: a broadcast in the texture path)
         typedef const Quad<T> __attribute__((address_space(1)))* GlobalRows;
         GlobalRows p = (GlobalRows)(F.poly + (size_t)cu * kPolyStride);
@@ -1104,6 +1124,9 @@ template <typename T> struct Consts {
     // op10/op11 (rt_exact.h, golden_filtered phase T): suprema over all angles of the k-th derivatives (k = 1..4) of the unit
     // momentum curve (cos t, gamma_s^2 sin t)/a(t) -- [0..3], the larger of the two components -- and of a(t) -- [4..7]
     T gold_sup[8];
+    // critical rays (hover_update): the hover sum beyond which a fused fp64 op1/2/6/8 step ends its ray for the re-trace, in units of
+    // steepness (kHoverLimit / DELTA_S); +inf where nothing is handed over.  Set by the kernels from BatchDev::hov_limit.
+    float hov_limit;
 };
 
 // anisotropy(theta, gamma) (:118-119) from sin/cos.  ISO (gamma == 1): sqrt(s^2 + c^2), which is 1 +- ulp
@@ -1427,10 +1450,16 @@ inline bool rotates_unit(int method, bool f64) {
 // million in all; the fused forms' rows leave 1e-9 from amplification 2.5e5 on (their distance from the reference's roundings
 // is 4e-15 of a launch angle), so the limit keeps a factor 80 in hand.
 constexpr float kHoverLimit = 2.0f;      // hov * DELTA_S beyond which a ray is re-traced in reference order
-template <typename T> __device__ __forceinline__ void hover_update(Ray<T>& r, bool active, float lam, T fgx, T fgy) {
-    if (rt_ballot(lam != 0.f) == 0ull) return;
+// Returns false for a lane whose sum has passed the limit (Consts::hov_limit): the step then reports the ray as ended, with hov = +inf as
+// the mark -- the step loops have no test of their own for this on their hot path; they look at the mark where they store an ended ray.
+template <typename T> __device__ __forceinline__ bool hover_update(const Consts<T>& k, Ray<T>& r, bool active, float lam, T fgx, T fgy) {
+    if (rt_ballot(lam != 0.f) == 0ull) return true;
     const T d = fma_(fgy, r.uy, fgx * r.ux), g2 = fma_(fgy, fgy, fgx * fgx);
-    if (active && lam != 0.f && d * d < T(4e-4) * g2) r.hov += lam;
+    if (active && lam != 0.f && d * d < T(4e-4) * g2) {
+        r.hov += lam;
+        if (r.hov > k.hov_limit) { r.hov = INFINITY; return false; }
+    }
+    return true;
 }
 
 template <typename T, int METHOD, bool ISO, typename G>
@@ -1442,10 +1471,11 @@ __device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& 
     T fn, fgx, fgy;
     T eps;
     const bool flag = op_advance<T, METHOD>(k, r, fx, fy, eps);
+    bool calm = true;
     if constexpr (ReportsSteep<G>::value && RotatesUnit<T, METHOD>::value) {     // fp64 op1/2/6/8 with the flat-cell map compiled in
         float lam;
         n_gradient(F, gather, active, (T)fx, (T)fy, fn, fgx, fgy, lam);
-        hover_update(r, active, lam, fgx, fgy);
+        calm = hover_update(k, r, active, lam, fgx, fgy);
     } else {
         n_gradient(F, gather, active, (T)fx, (T)fy, fn, fgx, fgy);
     }
@@ -1464,7 +1494,7 @@ __device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& 
         store_update<T, ISO, true>(k, r, fx, fy, fth, fn, fgx, fgy, frn, eps, (i & (RotatesUnit<T, METHOD>::refresh - 1)) == 0);
     else
         store_update<T, ISO>(k, r, fx, fy, fth, fn, fgx, fgy, frn, eps);
-    return boot || !outside(k, r);
+    return calm && (boot || !outside(k, r));
     }
 }
 

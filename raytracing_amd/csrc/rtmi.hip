@@ -1077,9 +1077,9 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
         until = stride - (i % stride);   // steps until the next recorded row
         row = i / stride;
     }
-    // critical rays: the hover sum's limit in units of steepness (rt::kHoverLimit / DELTA_S); +inf when this batch hands nothing over
+    // critical rays: the step itself ends a ray whose hover sum passed Consts::hov_limit (rt::hover_update: `inside` comes back false and
+    // the sum +inf); which of the two it was is looked at where a ray's state is stored, off the loop's hot path
     constexpr bool HOV = rt::ReportsSteep<G>::value && rt::RotatesUnit<T, METHOD>::value;
-    float hov_limit = a.hov_limit / (float)K.step;
     // one DELTA_S step of every lane; false once no lane of the wave is live
     auto one_step = [&]() -> bool {
         if (rt_ballot(alive) == 0ull) return false;
@@ -1103,19 +1103,22 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
                 }
             }
             alive = inside && (i + 1 < max_size);
-            if constexpr (HOV) {
-                if (r.hov > hov_limit) {          // a critical ray (rare: a few hundred of a million on the interface fan, none elsewhere)
-                    const BatchDev<T> ab = rare_batch(a);
-                    store_ray<T, METHOD, COH, true>(ab, k, r, i, false);
-                    __builtin_amdgcn_s_waitcnt(0x0F70);
-                    if (push_critical(ab, k, i)) alive = false;          // the re-trace takes it from its launch conditions
-                    else { r.hov = -INFINITY; if (alive) st_state<COH>(ab.alive + k, (unsigned char)1); }   // queue full: carries on, fused
-                    return true;
-                }
-            }
             if (!alive) {
                 if constexpr (rt::IsExact<T, METHOD>::value) rt::ex::finish_state<rt::base_method(METHOD)>(a.F, gather, r);   // the gradient at the end point, if the flat path left it out
-                store_ray<T, METHOD, COH, HOV>(rare_batch(a), k, r, i, false);
+                const BatchDev<T> ab = rare_batch(a);
+                if constexpr (HOV) {
+                    if (r.hov == INFINITY) {      // a critical ray (a few hundred of a million on the interface fan, none elsewhere)
+                        store_ray<T, METHOD, COH, true>(ab, k, r, i, false);
+                        __builtin_amdgcn_s_waitcnt(0x0F70);
+                        if (!push_critical(ab, k, i)) {          // queue full: the ray carries on in the fused form (counted)
+                            r.hov = -INFINITY;
+                            alive = !rt::outside(K, r) && (i + 1 < max_size);
+                            if (alive) st_state<COH>(ab.alive + k, (unsigned char)1);
+                        }
+                        return true;
+                    }
+                }
+                store_ray<T, METHOD, COH, HOV>(ab, k, r, i, false);
             }
         }
         return true;
@@ -1175,10 +1178,11 @@ void k_advance(BatchDev<T> a, int nsteps) {
 // on latency (launch bound: two waves per SIMD, 218 VGPRs): the wave keeps its cell's 36 polynomial coefficients in vector
 // registers and reloads them when the cell changes (rt::PolyGather, CACHED); a lookup in the kept cell touches no memory.
 // Same arithmetic as every other build: same bits.  (RTMI_POLY 0: the LDS tile's 4x4 window read in one go.)
-template <typename T, int METHOD, bool ISO>
+// NOFLAT: for a field whose flat-cell map is empty (vert_heterogeneous, fisheye): neither the map's tests nor the hover sum are compiled in
+template <typename T, int METHOD, bool ISO, bool NOFLAT = false>
 __global__ __launch_bounds__(256, 2) void k_advance_lat(BatchDev<T> a, int nsteps) {
     __shared__ __attribute__((aligned(16))) T lds[uses_tile<T, METHOD, true>() ? 4 * rt::LdsGather<T, 1>::ELEMS : 2];
-    advance_bundle<T, METHOD, ISO, true, false, false, 1>(a, lds, (long)blockIdx.x * blockDim.x, nsteps);
+    advance_bundle<T, METHOD, ISO, true, false, false, 1, NOFLAT>(a, lds, (long)blockIdx.x * blockDim.x, nsteps);
 }
 template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool COH, int PH, bool NOFLAT>
 __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, long blk, int nsteps) {
@@ -1195,6 +1199,7 @@ __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, lon
     rt::Consts<T> K = a.K;
     int max_size = a.max_size;
     if (VAR && a.vstep && k < a.R) { K.step = a.vstep[k]; K.step2h = a.vstep2h[k]; K.step2 = K.step2h * T(2); max_size = a.vmax[k]; }
+    K.hov_limit = a.hov_limit / (float)K.step;       // critical rays: the hover sum's limit in units of steepness (+inf: nothing is handed over)
     constexpr bool HOV = rt::ReportsSteep<decltype(gather)>::value && rt::RotatesUnit<T, METHOD>::value;
     if (alive) load_ray<T, METHOD, ISO, COH, HOV>(a, k, r, i);
     else idle_ray(a, r);
@@ -1346,6 +1351,8 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : light_method(METHOD) ? RT
     }
     const bool RECORD = a.stride != 0;
     constexpr bool RHOV = rt::ReportsSteep<typename GatherOf<T, METHOD, LDS>::type>::value && rt::RotatesUnit<T, METHOD>::value;
+    rt::Consts<T> K = a.K;
+    K.hov_limit = a.hov_limit / (float)K.step;
     const unsigned lane = threadIdx.x & 63;
     rt::Ray<T> r;
     idle_ray(a, r);
@@ -1385,7 +1392,7 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : light_method(METHOD) ? RT
             if (rt_ballot(alive) == 0ull) break;
             const bool active = alive;
             ++i;
-            const bool inside = rt::ray_step<T, METHOD, ISO>(a.F, a.K, gather, active, r, i);
+            const bool inside = rt::ray_step<T, METHOD, ISO>(a.F, K, gather, active, r, i);
             if (active) {
                 if (RECORD) {
                     if (--until == 0) {
@@ -1396,11 +1403,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : light_method(METHOD) ? RT
                 }
                 alive = inside && (i + 1 < a.max_size);
                 if constexpr (RHOV) {
-                    if (r.hov > a.hov_limit / (float)a.K.step) {          // a critical ray: see advance_loop
+                    if (!alive && r.hov == INFINITY) {          // a critical ray: see advance_loop
                         store_ray<T, METHOD, false, true>(a, k, r, i, false);
                         __builtin_amdgcn_s_waitcnt(0x0F70);
-                        if (push_critical(a, k, i)) alive = false;
-                        else { r.hov = -INFINITY; if (alive) a.alive[k] = 1; }
+                        if (!push_critical(a, k, i)) {
+                            r.hov = -INFINITY;
+                            alive = !rt::outside(K, r) && (i + 1 < a.max_size);
+                            if (alive) a.alive[k] = 1;
+                        }
                         continue;
                     }
                 }
@@ -1592,6 +1602,7 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     a.K.gamma_s = (T)p.gamma_step; a.K.g2m1_s = (T)(p.gamma_step * p.gamma_step - 1.0);
     for (int i = 0; i < 4; i++) a.K.box[i] = (T)p.box[i];
     for (int i = 0; i < 8; i++) a.K.gold_sup[i] = (T)b->gold_sup[i];
+    a.K.hov_limit = INFINITY;        // (the step kernels set it from BatchDev::hov_limit and the ray's DELTA_S)
     a.R = b->R; a.max_size = p.max_size; a.stride = p.record_stride; a.rec_rows = p.rec_rows;
     const size_t R = (size_t)b->R;
     a.st = (double*)b->state; a.has_hist = p.method == 7;
@@ -1736,17 +1747,19 @@ static bool uniform_rows_ok(const rtmi_batch* b) {
     return b->p.record_stride == 0 || (!b->dirty_state && (double)b->R * (double)b->esz * 6.0 < 2147483647.0);
 }
 // op2/op6 fp64 tile builds for few waves (k_advance_lat): [method 2 | 6][iso]
-static const void* advance_lat_fn(int m, bool iso) {
-    static const void* const tab[2][2] = {{(const void*)k_advance_lat<double, 2, false>, (const void*)k_advance_lat<double, 2, true>},
-                                          {(const void*)k_advance_lat<double, 6, false>, (const void*)k_advance_lat<double, 6, true>}};
-    return tab[m == 6 ? 1 : 0][iso ? 1 : 0];
+static const void* advance_lat_fn(int m, bool iso, bool noflat) {
+    static const void* const tab[2][2][2] = {{{(const void*)k_advance_lat<double, 2, false, false>, (const void*)k_advance_lat<double, 2, false, true>},
+                                              {(const void*)k_advance_lat<double, 2, true, false>, (const void*)k_advance_lat<double, 2, true, true>}},
+                                             {{(const void*)k_advance_lat<double, 6, false, false>, (const void*)k_advance_lat<double, 6, false, true>},
+                                              {(const void*)k_advance_lat<double, 6, true, false>, (const void*)k_advance_lat<double, 6, true, true>}}};
+    return tab[m == 6 ? 1 : 0][iso ? 1 : 0][noflat ? 1 : 0];
 }
 static const void* pick_advance(const rtmi_batch* b) {
     const bool iso = b->p.gamma == 1.0 && b->p.method < 10, lds = use_lds_tile(b);
     // at most two waves per SIMD's worth of rays: the latency build (env RTMI_NO_LAT=1 keeps the throughput build, for A/B)
     if (lds && b->p.dtype == RTMI_F64 && (b->p.method == 2 || b->p.method == 6) && !b->vstep && uniform_rows_ok(b) &&
         !ref_order(b->p) && b->lat_waves_per_simd > 0 && (b->R + 63) / 64 <= (int64_t)2 * b->lat_simds && !getenv("RTMI_NO_LAT"))
-        return advance_lat_fn(b->p.method, iso);
+        return advance_lat_fn(b->p.method, iso, b->field->flat_cells == 0 && b->field->steep_cells == 0);
     // the VAR build: per-ray DELTA_S / max_size when set, and per-lane row bookkeeping always
     if (b->vstep || !uniform_rows_ok(b))
         return b->p.dtype == RTMI_F64 ? advance_var_fn<double>(batch_kernel_index(b), iso) : advance_var_fn<float>(batch_kernel_index(b), iso);
@@ -2431,7 +2444,7 @@ __global__ __launch_bounds__(64, 2) void k_retrace_tail(BatchDev<double> s, Batc
     rt::Consts<T> K = m.K;
     int max_size = m.max_size;
     if (m.vstep) { K.step = m.vstep[k]; K.step2h = m.vstep2h[k]; K.step2 = K.step2h * 2.0; max_size = m.vmax[k]; }
-    const float hov_limit = m.hov_limit / (float)K.step;
+    K.hov_limit = m.hov_limit / (float)K.step;
     rt::PolyGather<T, rt::kPolyCached, true> pg;
     pg.init();
     rt::Ray<T> r;
@@ -2459,8 +2472,7 @@ __global__ __launch_bounds__(64, 2) void k_retrace_tail(BatchDev<double> s, Batc
             i = row;
             if (s.stride && i % s.stride == 0 && i / s.stride < s.rec_rows) write_row(s, (long)(i / s.stride), (long)j, r);
             alive = inside && (i + 1 < max_size);
-            const bool again = r.hov > hov_limit;       // hovering again further on: the final sweep takes this ray in reference order throughout
-            if (again) alive = false;
+            const bool again = r.hov == INFINITY;       // hovering again further on (the step ended the ray): the final sweep takes it in reference order throughout
             if (!alive) {
                 s.acc(0)[j] = r.x; s.acc(1)[j] = r.y; s.acc(2)[j] = r.th; s.aux(0)[j] = r.n; s.aux(1)[j] = r.gx; s.aux(2)[j] = r.gy;
                 s.acc(3)[j] = r.dsim; s.acc(4)[j] = r.dreal; s.acc(5)[j] = r.tt;

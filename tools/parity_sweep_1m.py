@@ -11,7 +11,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from bench import parity_relerr                     # noqa: E402
+from bench import parity_relerr, parity_relerr_elementwise                     # noqa: E402
 from raytracing_amd import rt_bench as rb          # noqa: E402
 from oracle import rt_oracle as O                   # noqa: E402
 
@@ -25,7 +25,10 @@ def main():
     threads = min(O.max_threads(), os.cpu_count() or 1)
     print(f"# device (default schedule, default field path) vs oracle ({threads} host threads) at full size; tolerance of the north star: 1e-9 relative, step counts exactly")
     print("# op column: R = rtmi_params.reference_order 1 (op1/2/6/8 in the reference's operation order too; op7 always is)")
-    print(f"{'scenario':19s} {'op':>4s} {'rays':>8s} {'checked':>7s} {'rows':>5s} {'ray-steps':>11s} {'ms/pass':>8s} {'same steps':>10s} {'final':>9s} {'rows/16':>9s} {'bits':>5s}")
+    print("# ms: kernel time of the first and of the second pass of the batch (rtmi_stats); sched: the schedule the second pass ran (fb: sliced launches that")
+    print("# gave up a wait); retr: critical rays re-traced in reference order; final / rows: bench.parity_relerr (per quantity) and, after the slash, the")
+    print("# element-wise |a-b|/max(|b|,1) of rounds 1-3; 'window' lines: the 4 096 CONTIGUOUS rays of the same 1 M-ray batch around the interface fan's split")
+    print(f"{'scenario':19s} {'op':>4s} {'rays':>8s} {'checked':>7s} {'rows':>5s} {'ray-steps':>11s} {'ms 1st':>8s} {'ms 2nd':>8s} {'sched':>6s} {'fb':>2s} {'retr':>5s} {'same steps':>10s} {'final':>17s} {'rows/16':>17s} {'bits':>5s}")
     worst = worst_exact = 0.0
     all_bits = True
     t0 = time.time()
@@ -49,21 +52,38 @@ def main():
             for ref_order in ((0, 1) if m in (1, 2, 6, 8) else (0,)):
                 b = rb.Batch(F, m, step, ms, lim, gam, th, x0, y0, record_stride=16, rec_rows=rows, reference_order=ref_order, keep_n_ray=False)
                 b.run()
+                ms1 = b.stats()["kernel_ms"]
                 b.reset()
-                t1 = time.perf_counter()
                 b.run()
-                dt = (time.perf_counter() - t1) * 1e3
-                d, fin = b.d_ray()[:, sub], b.final()[:, sub]
-                got = b.device_tensors()["s_ray"][:, :, sub].cpu().numpy()
-                steps = int(b.stats()["ray_steps"])
-                b.close()
+                st = b.stats()
+                dall, fall = b.d_ray(), b.final()
+                d, fin = dall[:, sub], fall[:, sub]
+                dev_rows = b.device_tensors()["s_ray"]
+                got = dev_rows[:, :, sub].cpu().numpy()
+                steps = int(st["ray_steps"])
                 same = d[2] == o["d_ray"][2]
-                ef = parity_relerr(fin[:, same], o["final"][:, same])
-                er = parity_relerr(got[:, :, same], o["s_ray"][:, :, same])
+                ef = parity_relerr(fin[:, same], o["final"][:, same]), parity_relerr_elementwise(fin[:, same], o["final"][:, same])
+                er = parity_relerr(got[:, :, same], o["s_ray"][:, :, same]), parity_relerr_elementwise(got[:, :, same], o["s_ray"][:, :, same])
                 bits = bool(np.array_equal(fin, o["final"]) and np.array_equal(got, o["s_ray"]) and np.array_equal(d, o["d_ray"]))
                 want_bits = m in EXACT or ref_order == 1
-                print(f"{scen:19s} {m:3d}{' R'[ref_order]} {R:8d} {len(th[sub]):7d} {got.shape[0]:5d} {steps:11d} {dt:8.2f} {int(same.sum()):10d} {ef:9.1e} {er:9.1e} "
+                print(f"{scen:19s} {m:3d}{' R'[ref_order]} {R:8d} {len(th[sub]):7d} {got.shape[0]:5d} {steps:11d} {ms1:8.2f} {st['kernel_ms']:8.2f} {st['launch_mode_used']:>6s} "
+                      f"{st['auto_fallbacks']:2d} {st['retraced']:5d} {int(same.sum()):10d} {ef[0]:8.1e}/{ef[1]:8.1e} {er[0]:8.1e}/{er[1]:8.1e} "
                       f"{'yes' if bits else ('NO' if want_bits else '-'):>5s}", flush=True)
+                ef, er = max(ef), max(er)
+                if scen == "interface" and m in (1, 2, 6, 8) and ref_order == 0:
+                    # the critical rays: 4 096 contiguous rays around the split (final y jumps from the bottom of the box to its top)
+                    k = int(np.argmax(np.abs(np.diff(fall[1]))))
+                    w0 = min(max(0, k - 2048), R - 4096)
+                    win = slice(w0, w0 + 4096)
+                    ow = O.trazar(OF, m, gam, step, ms, lim, x0, y0, th[win], record_stride=16, rec_rows=rows or None, nthreads=threads)
+                    gw = dev_rows[:, :, win].cpu().numpy()
+                    sw = dall[2, win] == ow["d_ray"][2]
+                    ewf = parity_relerr(fall[:, win][:, sw], ow["final"][:, sw]), parity_relerr_elementwise(fall[:, win][:, sw], ow["final"][:, sw])
+                    ewr = parity_relerr(gw[:, :, sw], ow["s_ray"][:, :, sw]), parity_relerr_elementwise(gw[:, :, sw], ow["s_ray"][:, :, sw])
+                    print(f"{'  window at ' + format(np.degrees(th[k]), '.4f') + ' deg':19s} {m:3d}  {R:8d} {4096:7d} {gw.shape[0]:5d} {'':11s} {'':8s} {'':8s} {'':6s} {'':2s} {'':5s} "
+                          f"{int(sw.sum()):10d} {ewf[0]:8.1e}/{ewf[1]:8.1e} {ewr[0]:8.1e}/{ewr[1]:8.1e} {'-':>5s}", flush=True)
+                    ef, er = max(ef, *ewf), max(er, *ewr)
+                b.close()
                 if want_bits:
                     worst_exact = max(worst_exact, ef, er)
                     all_bits &= bits
