@@ -246,9 +246,9 @@ template <typename T> struct FieldDev {
     // FITPACK's fpbspl divides by there, then the cell's knots and the differences themselves (rt_exact.h: axis_exact reads the
     // reciprocals per lane, AxisTab the whole entry for a wave in one cell); nullptr in fp32 fields (the reference-order path is fp64)
     const double *rdx, *rdy;
-    // gflat: what FITPACK's gradient evaluates to at most in a FLAT cell of the map (2^-72 of the grid's largest gradient-spline
-    // coefficient; rt_exact.h, the reference-order step where the medium is constant)
-    T gflat;
+    // (128 bytes in fp64, and it stays that: the struct heads every step kernel's argument segment, and the register allocation of the
+    // kernels at their register cap follows the offsets of what comes after it -- one more member here, 8 bytes, cost interface x op9 12 %:
+    // profiles/r05_bisect_iface_op9.txt)
 };
 
 // Rare branches of the step loop (a lookup near the grid's rim, re-staging the LDS tile, a lane falling back to a global
@@ -519,6 +519,9 @@ __device__ __forceinline__ void lookup_global_rows(const FieldDev<T>& F, const C
 // FLATMAP (rt_exact.h, the reference-order step where the medium is constant): false in the builds for fields whose flat-cell map is
 // empty -- the flat path is not even compiled in there (as run-time tests it cost the vert_heterogeneous fan in reference order a third).
 template <typename T, bool FLATMAP = true> struct GlobalGather {
+    // gflat: what FITPACK's gradient evaluates to at most in a FLAT cell of the map (2^-72 of the grid's largest gradient-spline
+    // coefficient; rt_exact.h, the reference-order step where the medium is constant); set by the kernels from BatchDev::gflat
+    double gflat = 0.0;
     static constexpr bool kUniformWindow = true;     // rt::ex::n_gradient: a wave in one cell reads the window through the scalar cache
     __device__ __forceinline__ void fetch(const FieldDev<T>& F, const Cell<T>& c, bool active, T z[4], Pair<T> g[4][4]) {
         // an idle lane reads the grid's first window instead of its stale cell: all idle lanes then share one
@@ -724,6 +727,8 @@ template <typename T, int PHASES = RTMI_TILE_PHASES> struct LdsGather {
 template <typename G> struct IsPoly { static constexpr bool value = false; };
 template <typename T, int MODE, bool FLAT> struct PolyGather;
 template <typename T, int MODE, bool FLAT> struct IsPoly<PolyGather<T, MODE, FLAT>> { static constexpr bool value = true; };
+template <typename G> struct HasFlatMap { static constexpr bool value = false; };
+template <typename T, int MODE, bool FLAT> struct HasFlatMap<PolyGather<T, MODE, FLAT>> { static constexpr bool value = RTMI_FLAT_MAP && FLAT; };
 template <typename G> struct ReportsSteep { static constexpr bool value = false; };
 template <typename T, int MODE, bool FLAT> struct ReportsSteep<PolyGather<T, MODE, FLAT>> { static constexpr bool value = RTMI_FLAT_MAP && FLAT && sizeof(T) == 8; };
 // ... and the steepness of the cell (flat-cell map, FlatBits): 0 for every lookup that is not a PolyGather with the map compiled in
@@ -980,6 +985,9 @@ template <typename T, int MODE, bool FLAT = true> struct PolyGather {
     // scalar cache with 72 copies into the vector registers (no vmcnt wait behind the trajectory stores): 2.54 vs 2.25 ms.
     int tagA;
     float lamA;           // CACHED: the kept cell's steepness
+    // critical rays (hover_update): the hover sum beyond which a fused fp64 op1/2/6/8 step ends its ray for the re-trace, in units of
+    // steepness (kHoverLimit / DELTA_S); +inf where nothing is handed over.  Set by the kernels from BatchDev::hov_limit.
+    float hov_limit = __builtin_inff();
     Quad<T> rowsA[NA];
     // Does this lookup report steepness?  Only where the map's tests are compiled in, and only fp64 (the fp32 map has no room
     // for it and fp32 batches have no reference to be re-traced against).
@@ -1108,7 +1116,6 @@ template <typename T> struct Ray {
     Acc dsim, dreal, tt;     // simulated / expected arclength, traveltime (accumulators)
     T mx, my;                // momenta of the current row (output only)
     T hx0, hy0, hx1, hy1;    // op7: the two positions before (x,y), oldest first (VECTOR_LIST, Q11)
-    bool gstale, curflat;    // reference-order op1/2/6/8 (rt_exact.h, the flat path): gx, gy have not been evaluated at (x, y) yet; (x, y) lies in a flat cell
     float hov;               // fused fp64 op1/2/6/8 on a field with steep cells: sum of the steepness of the cells in which the ray
                              // ran along the iso-lines (hover_update); times DELTA_S it grows with the factor by which the ray's
                              // trajectory amplifies a rounding difference -- past kHoverLimit the ray is re-traced in reference order
@@ -1124,9 +1131,8 @@ template <typename T> struct Consts {
     // op10/op11 (rt_exact.h, golden_filtered phase T): suprema over all angles of the k-th derivatives (k = 1..4) of the unit
     // momentum curve (cos t, gamma_s^2 sin t)/a(t) -- [0..3], the larger of the two components -- and of a(t) -- [4..7]
     T gold_sup[8];
-    // critical rays (hover_update): the hover sum beyond which a fused fp64 op1/2/6/8 step ends its ray for the re-trace, in units of
-    // steepness (kHoverLimit / DELTA_S); +inf where nothing is handed over.  Set by the kernels from BatchDev::hov_limit.
-    float hov_limit;
+    // (nothing is added here or to FieldDev lightly: both sit in front of the batch's members in every step kernel's argument segment,
+    // and the register allocation of the kernels at their register cap follows those offsets -- 8 bytes more cost interface x op9 5-12 %)
 };
 
 // anisotropy(theta, gamma) (:118-119) from sin/cos.  ISO (gamma == 1): sqrt(s^2 + c^2), which is 1 +- ulp
@@ -1450,14 +1456,15 @@ inline bool rotates_unit(int method, bool f64) {
 // million in all; the fused forms' rows leave 1e-9 from amplification 2.5e5 on (their distance from the reference's roundings
 // is 4e-15 of a launch angle), so the limit keeps a factor 80 in hand.
 constexpr float kHoverLimit = 2.0f;      // hov * DELTA_S beyond which a ray is re-traced in reference order
-// Returns false for a lane whose sum has passed the limit (Consts::hov_limit): the step then reports the ray as ended, with hov = +inf as
+// Returns false for a lane whose sum has passed the limit: the step then reports the ray as ended, with hov = +inf as
 // the mark -- the step loops have no test of their own for this on their hot path; they look at the mark where they store an ended ray.
-template <typename T> __device__ __forceinline__ bool hover_update(const Consts<T>& k, Ray<T>& r, bool active, float lam, T fgx, T fgy) {
+// (The limit travels with the gather object, PolyGather::hov_limit: see Consts for why not with the constants.)
+template <typename T> __device__ __forceinline__ bool hover_update(float hov_limit, Ray<T>& r, bool active, float lam, T fgx, T fgy) {
     if (rt_ballot(lam != 0.f) == 0ull) return true;
     const T d = fma_(fgy, r.uy, fgx * r.ux), g2 = fma_(fgy, fgy, fgx * fgx);
     if (active && lam != 0.f && d * d < T(4e-4) * g2) {
         r.hov += lam;
-        if (r.hov > k.hov_limit) { r.hov = INFINITY; return false; }
+        if (r.hov > hov_limit) { r.hov = INFINITY; return false; }
     }
     return true;
 }
@@ -1475,11 +1482,15 @@ __device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& 
     if constexpr (ReportsSteep<G>::value && RotatesUnit<T, METHOD>::value) {     // fp64 op1/2/6/8 with the flat-cell map compiled in
         float lam;
         n_gradient(F, gather, active, (T)fx, (T)fy, fn, fgx, fgy, lam);
-        calm = hover_update(k, r, active, lam, fgx, fgy);
+        calm = hover_update(gather.hov_limit, r, active, lam, fgx, fgy);
     } else {
         n_gradient(F, gather, active, (T)fx, (T)fy, fn, fgx, fgy);
     }
     const T frn = rcp_full(fn);
+    // (A "constant-medium step" -- where the gradient is exactly zero at both ends of the step the angle determination and the rotation
+    // of the unit tangent return what they were given, term by term, and can be skipped: 55 of the step's 135 vector instructions on
+    // three quarters of the interface fan's steps -- was built, proven bit-identical, and measured: 23.5 vs 23.1 ms.  The interface
+    // kernel waits for the flat-cell map's entry of each new position, not for arithmetic.  Not kept.)
     bool boot = false;
     if (METHOD == 7 && i <= 2) {
         T vx, vy;

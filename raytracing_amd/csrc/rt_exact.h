@@ -906,6 +906,12 @@ __device__ __forceinline__ void derive(const Consts<double>& k, Ray<double>& r) 
 // it finds it missing, and so does whoever stores the ray's state (finish_state).  op1 / op8 form their new angle as
 // arctan2(n u_y + I_y, n u_x + I_x) (:407), which is not theta in the last bits even where the impulse vanishes: they keep numpy's
 // arctan2 and the sin / cos of its result and skip the rest.
+// Two flags of the flat path travel in Ray::rn, which this order of stepping has no other use for (ex::derive clears it; the fused
+// forms keep 1/n there): 1 = the gradient has not been evaluated at (x, y) yet, 2 = (x, y) lies in a flat cell.  (Not members of
+// their own: the kernels at their register cap answer to every change of the structs they share, see rt_device.h, Consts.)
+__device__ __forceinline__ bool grad_stale(const Ray<double>& r) { return r.rn == 1.0 || r.rn == 3.0; }
+__device__ __forceinline__ bool in_flat_cell(const Ray<double>& r) { return r.rn >= 2.0; }
+__device__ __forceinline__ void set_flat_flags(Ray<double>& r, bool stale, bool flat) { r.rn = (flat ? 2.0 : 0.0) + (stale ? 1.0 : 0.0); }
 template <int METHOD> constexpr bool flat_shortcut() { return RTMI_FLAT_MAP && (METHOD == 1 || METHOD == 2 || METHOD == 6 || METHOD == 8); }
 template <typename G> struct IsGlobalGather { static constexpr bool value = false; };
 template <> struct IsGlobalGather<GlobalGather<double, true>> { static constexpr bool value = true; };
@@ -939,10 +945,10 @@ __device__ __forceinline__ bool flat_point(const FieldDev<double>& F, double x, 
 template <int METHOD, typename G>
 __device__ __forceinline__ void finish_state(const FieldDev<double>& F, G& gather, Ray<double>& r) {
     if constexpr (flat_shortcut<METHOD>() && IsGlobalGather<G>::value) {
-        if (r.gstale) {
+        if (grad_stale(r)) {
             double nn;
             ex::n_gradient<fallback_phases(METHOD), window_estimates(METHOD), window_votes(METHOD)>(F, gather, true, (double)r.x, (double)r.y, nn, r.gx, r.gy);
-            r.gstale = false;
+            set_flat_flags(r, false, in_flat_cell(r));
         }
     }
 }
@@ -953,17 +959,17 @@ __device__ __forceinline__ bool ray_step(const FieldDev<double>& F, const Consts
     if constexpr (flat_shortcut<METHOD>() && IsGlobalGather<G>::value) {
         // tried only when some live lane of the wave stands in a flat cell (wave-uniform test on state the lanes carry: inside a
         // transition band nothing is looked up twice)
-        if (F.flat != 0 && rt_ballot(active && r.curflat) != 0ull) {
+        if (F.flat != 0 && rt_ballot(active && in_flat_cell(r)) != 0ull) {
             // the step if nothing of the gradient survives: r + u DELTA_S (adv_first; adv_second's first bracket), theta kept
             const double fx = r.x + r.ux * k.step, fy = r.y + r.uy * k.step;
             double fn;
             const bool newflat = flat_point(F, fx, fy, fn);
-            const double q = F.gflat * k.step2, sc = 0x1p-56;           // a quarter ulp of v is at least 2^-55 |v|; half of that in hand
-            bool ok = r.curflat && newflat && (METHOD == 1 || METHOD == 2 || (q < sc * __builtin_fabs(fx) * r.n && q < sc * __builtin_fabs(fy) * r.n));
+            const double q = gather.gflat * k.step2, sc = 0x1p-56;           // a quarter ulp of v is at least 2^-55 |v|; half of that in hand
+            bool ok = in_flat_cell(r) && newflat && (METHOD == 1 || METHOD == 2 || (q < sc * __builtin_fabs(fx) * r.n && q < sc * __builtin_fabs(fy) * r.n));
             if constexpr (METHOD == 2 || METHOD == 6)
-                ok = ok && F.gflat * k.step * (r.n + fn) < sc * __builtin_fabs(r.th) * r.n * fn;
+                ok = ok && gather.gflat * k.step * (r.n + fn) < sc * __builtin_fabs(r.th) * r.n * fn;
             else   // op1 / op8: the impulse DELTA_S (g + g') / 2 (:214) against n u_x and n u_y (:407)
-                ok = ok && F.gflat * k.step < sc * r.n * __builtin_fmin(__builtin_fabs(r.ux), __builtin_fabs(r.uy));
+                ok = ok && gather.gflat * k.step < sc * r.n * __builtin_fmin(__builtin_fabs(r.ux), __builtin_fabs(r.uy));
             if (!active || ok) {       // (an idle lane: its stale state takes the short way too)
                 const double dist = norm2(r.x - fx, r.y - fy);
                 r.dsim += dist;
@@ -982,7 +988,7 @@ __device__ __forceinline__ bool ray_step(const FieldDev<double>& F, const Consts
                 const double nray = coef * fn;
                 r.tt = r.tt + dist * (r.nray + nray) / 2.0;
                 r.nray = nray;
-                r.gstale = true; r.curflat = true;
+                set_flat_flags(r, true, true);
                 r.hov = 0.f;           // a flat cell is not a steep one
                 return !outside(k, r);
             }
@@ -990,6 +996,7 @@ __device__ __forceinline__ bool ray_step(const FieldDev<double>& F, const Consts
         }
     }
     double fx, fy, fn, fgx, fgy;
+    [[maybe_unused]] bool arrived_flat = false;
     const bool flag = ex::op_advance<METHOD>(k, r, fx, fy);
     if constexpr (IsPoly<G>::value) rt::n_gradient(F, gather, active, fx, fy, fn, fgx, fgy);   // kFastField: the cell's polynomial
     else if constexpr (flat_shortcut<METHOD>() && IsGlobalGather<G>::value) {
@@ -997,13 +1004,13 @@ __device__ __forceinline__ bool ray_step(const FieldDev<double>& F, const Consts
         // short way starts from a flat cell
         int cell = 0;
         ex::n_gradient<fallback_phases(METHOD), window_estimates(METHOD), window_votes(METHOD)>(F, gather, active, fx, fy, fn, fgx, fgy, &cell);
-        r.curflat = false;
         r.hov = 0.f;               // (in this order of stepping Ray::hov is free: it carries the steepness of the cell the ray arrived in)
-        if (F.flat != 0) { double cf; r.curflat = flat_lane(F, cell, cf, r.hov); }
+        if (F.flat != 0) { double cf; arrived_flat = flat_lane(F, cell, cf, r.hov); }
     }
     else ex::n_gradient<fallback_phases(METHOD), window_estimates(METHOD), window_votes(METHOD)>(F, gather, active, fx, fy, fn, fgx, fgy);
     const double fth = ex::op_angle<METHOD>(k, r, flag, fx, fy, fn, fgx, fgy, i);
     ex::store_update<inline_sincos(METHOD) || IsPoly<G>::value>(k, r, fx, fy, fth, fn, fgx, fgy);   // (IsPoly: op7 with RTMI_ORDER_FAST_FIELD, kFastField)
+    if constexpr (flat_shortcut<METHOD>() && IsGlobalGather<G>::value) set_flat_flags(r, false, arrived_flat);
     return (METHOD == 7 && i <= 2) || !outside(k, r);     // no boundary test in op7's bootstrap rows
 }
 

@@ -167,7 +167,6 @@ template <typename T> static rt::FieldDev<T> field_dev(const rtmi_field* f, int 
     F.rdx = f->rdiv;
     F.rdy = f->rdiv ? f->rdiv + (size_t)f->qx * rt::ex::kAxisTab : nullptr;
     F.window = 0;
-    F.gflat = (T)(f->gmax * 0x1p-72);
     return F;
 }
 
@@ -783,6 +782,7 @@ template <typename T> struct BatchDev {
     unsigned long long* rq;
     unsigned* rq_host;
     int prio;                      // > 0: the kernel's waves raise their issue priority (the re-trace batch, beside the main kernel)
+    double gflat;                  // rt::GlobalGather::gflat (the reference-order step where the medium is constant, rt_exact.h)
 };
 
 // A fused ray whose hover sum passed the limit: queue it for the re-trace in reference order and stop it.  False when the
@@ -903,7 +903,6 @@ __device__ __forceinline__ void load_ray(const BatchDev<T>& a, long k, rt::Ray<T
     } else rt::derive<T, ISO>(a.K, r);
     if constexpr (HOV) r.hov = a.hov ? ld_state<COH>(a.hov + k) : 0.f;
     else r.hov = 0.f;
-    r.gstale = false; r.curflat = false;       // (the first step of a launch takes the full way; it finds out where the ray is)
     i = ld_state<COH>(a.istep + k);
 }
 template <typename T, int METHOD, bool COH = false, bool HOV = false>
@@ -930,7 +929,6 @@ template <typename T> __device__ __forceinline__ void idle_ray(const BatchDev<T>
     r.dsim = r.dreal = r.tt = r.mx = r.my = 0;
     r.hx0 = r.hx1 = r.x; r.hy0 = r.hy1 = r.y;
     r.hov = 0.f;
-    r.gstale = false; r.curflat = false;
 }
 
 // Gather policy of a step kernel.  Reference-order methods (rt_exact.h: FITPACK's sums on the B-spline window): the LDS tile
@@ -945,6 +943,9 @@ template <typename T, int METHOD, bool LDS, int PH, bool NOFLAT> struct GatherOf
     using type = rt::PolyGather<T, !LDS ? rt::kPolyLane : PH == 1 ? rt::kPolyCached : rt::kPolyScalar, !NOFLAT>;   // PH 1: k_advance_lat
 };
 template <typename T, bool LDS, bool FM> __device__ __forceinline__ void gather_init(rt::GlobalGather<T, FM>&, T*) {}
+// the per-lane gather of a build with the flat path compiled in (reference-order op1/2/6/8 on a field with flat cells) carries gflat
+template <typename T, typename G> __device__ __forceinline__ void gather_flat_bound(G&, const BatchDev<T>&) {}
+template <> __device__ __forceinline__ void gather_flat_bound<double, rt::GlobalGather<double, true>>(rt::GlobalGather<double, true>& g, const BatchDev<double>& a) { g.gflat = a.gflat; }
 template <typename T, bool LDS, int MODE, bool FLAT> __device__ __forceinline__ void gather_init(rt::PolyGather<T, MODE, FLAT>& g, T*) { g.init(); }
 // LDS of a step kernel in units of T: the reference-order methods' tile; the polynomial lookup needs none.  (An L2 prefetch of
 // the cells ahead -- global_load_lds into a per-wave sink whenever the wave's cell changes -- was measured: interface 23.6 ->
@@ -1077,7 +1078,7 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
         until = stride - (i % stride);   // steps until the next recorded row
         row = i / stride;
     }
-    // critical rays: the step itself ends a ray whose hover sum passed Consts::hov_limit (rt::hover_update: `inside` comes back false and
+    // critical rays: the step itself ends a ray whose hover sum passed PolyGather::hov_limit (rt::hover_update: `inside` comes back false and
     // the sum +inf); which of the two it was is looked at where a ray's state is stored, off the loop's hot path
     constexpr bool HOV = rt::ReportsSteep<G>::value && rt::RotatesUnit<T, METHOD>::value;
     // one DELTA_S step of every lane; false once no lane of the wave is live
@@ -1188,6 +1189,7 @@ template <typename T, int METHOD, bool ISO, bool LDS, bool VAR, bool COH, int PH
 __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, long blk, int nsteps) {
     typename GatherOf<T, METHOD, LDS, PH, NOFLAT>::type gather;
     gather_init<T, LDS>(gather, lds);
+    if constexpr (rt::IsExact<T, METHOD>::value && rt::ex::flat_shortcut<rt::base_method(METHOD)>()) gather_flat_bound<T>(gather, a);
     if constexpr (rt::IsExact<T, METHOD>::value) {
         if constexpr (rt::ex::inline_sincos(rt::base_method(METHOD)) || (METHOD & rt::kFastField) != 0) rt::ex::stage_sincos_tab();   // glibc's table into LDS (rt_exact.h)
     }
@@ -1199,8 +1201,8 @@ __device__ __forceinline__ bool advance_bundle(const BatchDev<T>& a, T* lds, lon
     rt::Consts<T> K = a.K;
     int max_size = a.max_size;
     if (VAR && a.vstep && k < a.R) { K.step = a.vstep[k]; K.step2h = a.vstep2h[k]; K.step2 = K.step2h * T(2); max_size = a.vmax[k]; }
-    K.hov_limit = a.hov_limit / (float)K.step;       // critical rays: the hover sum's limit in units of steepness (+inf: nothing is handed over)
     constexpr bool HOV = rt::ReportsSteep<decltype(gather)>::value && rt::RotatesUnit<T, METHOD>::value;
+    if constexpr (HOV) gather.hov_limit = a.hov_limit / (float)K.step;       // critical rays: the hover sum's limit in units of steepness (+inf: nothing is handed over)
     if (alive) load_ray<T, METHOD, ISO, COH, HOV>(a, k, r, i);
     else idle_ray(a, r);
     // Rows are recorded through the wave-uniform descriptor path (UROW) by every build except the VAR one: the host
@@ -1346,13 +1348,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? 4 : light_method(METHOD) ? RT
     __shared__ __attribute__((aligned(16))) T lds[kernel_lds_elems<T, METHOD, LDS>()];
     typename GatherOf<T, METHOD, LDS>::type gather;
     gather_init<T, LDS>(gather, lds);
+    if constexpr (rt::IsExact<T, METHOD>::value && rt::ex::flat_shortcut<rt::base_method(METHOD)>()) gather_flat_bound<T>(gather, a);
     if constexpr (rt::IsExact<T, METHOD>::value) {
         if constexpr (rt::ex::inline_sincos(rt::base_method(METHOD)) || (METHOD & rt::kFastField) != 0) rt::ex::stage_sincos_tab();
     }
     const bool RECORD = a.stride != 0;
     constexpr bool RHOV = rt::ReportsSteep<typename GatherOf<T, METHOD, LDS>::type>::value && rt::RotatesUnit<T, METHOD>::value;
     rt::Consts<T> K = a.K;
-    K.hov_limit = a.hov_limit / (float)K.step;
+    if constexpr (RHOV) gather.hov_limit = a.hov_limit / (float)K.step;
     const unsigned lane = threadIdx.x & 63;
     rt::Ray<T> r;
     idle_ray(a, r);
@@ -1602,7 +1605,6 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     a.K.gamma_s = (T)p.gamma_step; a.K.g2m1_s = (T)(p.gamma_step * p.gamma_step - 1.0);
     for (int i = 0; i < 4; i++) a.K.box[i] = (T)p.box[i];
     for (int i = 0; i < 8; i++) a.K.gold_sup[i] = (T)b->gold_sup[i];
-    a.K.hov_limit = INFINITY;        // (the step kernels set it from BatchDev::hov_limit and the ray's DELTA_S)
     a.R = b->R; a.max_size = p.max_size; a.stride = p.record_stride; a.rec_rows = p.rec_rows;
     const size_t R = (size_t)b->R;
     a.st = (double*)b->state; a.has_hist = p.method == 7;
@@ -1621,6 +1623,7 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     a.rq = b->rt ? b->rt->rq : nullptr;
     a.rq_host = b->rt ? b->rt->host_count : nullptr;
     a.prio = b->is_retrace_sub ? 1 : 0;
+    a.gflat = b->field->gmax * 0x1p-72;
     return a;
 }
 
@@ -2397,6 +2400,7 @@ __global__ __launch_bounds__(64, 3) void k_retrace_ref(BatchDev<double> s, Batch
     if (m.vstep) { K.step = m.vstep[k]; K.step2h = m.vstep2h[k]; K.step2 = K.step2h * 2.0; max_size = m.vmax[k]; }
     const int ref_until = marked_only ? 0x7fffffff : (int)(e >> 32);          // the row where the fused run stopped this ray
     rt::GlobalGather<T> gg;
+    gg.gflat = s.gflat;
     rt::Ray<T> r;
     int i = 0, out = 0;
     bool alive = valid && max_size > 1, handed = false;
@@ -2406,7 +2410,7 @@ __global__ __launch_bounds__(64, 3) void k_retrace_ref(BatchDev<double> s, Batch
         rt::ex::derive(K, r);
         r.dsim = 0; r.dreal = 0; r.tt = 0;
         r.hx0 = r.hy0 = r.hx1 = r.hy1 = 0;
-        r.hov = 0.f; r.gstale = false; r.curflat = false;
+        r.hov = 0.f;
         if (s.stride && s.rec_rows > 0) write_row(s, 0, (long)j, r);
     }
     while (rt_ballot(alive && !handed) != 0ull) {
@@ -2444,9 +2448,9 @@ __global__ __launch_bounds__(64, 2) void k_retrace_tail(BatchDev<double> s, Batc
     rt::Consts<T> K = m.K;
     int max_size = m.max_size;
     if (m.vstep) { K.step = m.vstep[k]; K.step2h = m.vstep2h[k]; K.step2 = K.step2h * 2.0; max_size = m.vmax[k]; }
-    K.hov_limit = m.hov_limit / (float)K.step;
     rt::PolyGather<T, rt::kPolyCached, true> pg;
     pg.init();
+    pg.hov_limit = m.hov_limit / (float)K.step;
     rt::Ray<T> r;
     idle_ray(s, r);
     int i = 0, i0 = 0;

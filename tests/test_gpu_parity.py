@@ -1241,6 +1241,30 @@ def test_critical_rays_of_the_1m_interface_fan(method, first, rb, gpu_fields, or
     assert st0["retraced"] == 0 and (dev0 > REL).sum() >= 1               # the window was chosen around the known offenders
 
 
+@pytest.mark.parametrize("method", [6, 1, 2, 8])
+def test_interface_rays_do_not_depend_on_their_wave_mates(method, rb, gpu_fields):
+    """A ray's bits must not depend on which rays share its wave: the wave-level layouts of the fused step -- the flat-cell map's
+    early answer when every live lane sits in one flat cell, the wave-uniform cell through the scalar cache, the votes of the
+    small-angle forms -- only pick code paths, never values.  The sorted interface fan (coherent waves) against the same rays
+    shuffled (every wave a mix of rays in different cells, flat and not): every recorded row, the final state and d_ray equal,
+    ray by ray."""
+    R = 4096
+    th = np.linspace(2 * np.pi / 60, np.pi / 2, R)
+    perm = np.random.default_rng(11).permutation(R)
+    lim = LIMITS["interface"]
+    ms = int(np.ceil(80 / rb.DELTA_S) + 1)
+    kw = dict(record_stride=64, rec_rows=160, launch_mode="plain", retrace=False)
+    a = rb.Batch(gpu_fields("interface"), method, rb.DELTA_S, ms, lim, 1, th, -2.0, -2.0, **kw)
+    a.run()
+    ra, fa, da = a.rows(), a.final(), a.d_ray()
+    a.close()
+    b = rb.Batch(gpu_fields("interface"), method, rb.DELTA_S, ms, lim, 1, th[perm], -2.0, -2.0, **kw)
+    b.run()
+    rb_, fb, db = b.rows(), b.final(), b.d_ray()
+    b.close()
+    assert np.array_equal(db, da[:, perm]) and np.array_equal(fb, fa[:, perm]) and np.array_equal(rb_, ra[:, :, perm])
+
+
 @pytest.mark.parametrize("mode", ["plain", "sliced", "refill", "steps"])
 def test_retrace_is_the_same_in_every_schedule(mode, rb, gpu_fields):
     """The automatic re-trace of critical rays is a property of the RAY (its own hover sum): the same rays are handed over and
