@@ -151,14 +151,18 @@ typedef struct {
                                 within 1e-9 of the reference */
     int32_t no_retrace;      /* 0 (default): a fused fp64 op1/2/6/8 batch on a field with a sharp transition (cells whose Hessian of n
                                 is large against the size of the grid: the interface scenario; none in fisheye / vert_heterogeneous)
-                                adds up, per ray, the steepness of the cells in which the ray runs nearly ALONG the iso-lines; a ray
-                                whose sum says its trajectory amplifies rounding differences more than ~5e3 times is stopped, queued
+                                adds up, per ray and step, the steepness of the cell times |v . g| (v the ray's normal, g the
+                                unit gradient): the exponent of the factor by which the trajectory amplifies a rounding
+                                difference along a wall.  A ray whose sum says more than ~1e3 times is stopped, queued
                                 and re-traced from its launch conditions in the reference's operation order (a hidden batch of the
                                 same parameters, launched beside the main kernel); its rows and final state replace the fused
-                                ones -- the oracle's bits.  A few hundred rays of a million on the interface fan, within 2 % of
+                                ones -- the oracle's bits.  A few hundred rays of a million on the interface fan, 7 % of
                                 the time; rays are independent (RT_bench.py:807), so no other ray's bits change.  rtmi_run does
                                 this before it returns; after rtmi_step it happens at the next call that reads results (rays handed
                                 over are no longer live, and are then at their END, ahead of the others).  1: never (A/B runs).
+                                The measure is calibrated on walls (the interface scenario's, also tilted against the grid);
+                                ill-conditioning of another kind -- e.g. the focusing of a strongly bent wall in a field given
+                                by samples -- is not seen by it: RTMI_ORDER_REFERENCE is the answer there.
                                 rtmi_stats.retraced counts them */
 } rtmi_params;
 

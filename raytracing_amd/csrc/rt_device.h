@@ -731,6 +731,9 @@ template <typename G> struct HasFlatMap { static constexpr bool value = false; }
 template <typename T, int MODE, bool FLAT> struct HasFlatMap<PolyGather<T, MODE, FLAT>> { static constexpr bool value = RTMI_FLAT_MAP && FLAT; };
 template <typename G> struct ReportsSteep { static constexpr bool value = false; };
 template <typename T, int MODE, bool FLAT> struct ReportsSteep<PolyGather<T, MODE, FLAT>> { static constexpr bool value = RTMI_FLAT_MAP && FLAT && sizeof(T) == 8; };
+template <typename T> struct PolyLaneKept;
+template <typename T> struct IsPoly<PolyLaneKept<T>> { static constexpr bool value = true; };
+template <typename T> struct ReportsSteep<PolyLaneKept<T>> { static constexpr bool value = sizeof(T) == 8; };
 // ... and the steepness of the cell (flat-cell map, FlatBits): 0 for every lookup that is not a PolyGather with the map compiled in
 template <typename T, typename G>
 __device__ __forceinline__ void n_gradient(const FieldDev<T>& F, G& gather, bool active, T x, T y, T& n, T& gx, T& gy, float& lam) {
@@ -1102,6 +1105,59 @@ template <typename T, int MODE, bool FLAT = true> struct PolyGather {
     }
 };
 
+// One lane, one ray, ITS OWN kept cell (k_retrace_tail: the fused tails of re-traced critical rays -- a lone wave whose 64 rays are
+// anywhere).  A lone wave's step is mostly the wait for its lookup: 1.4 us per step with per-lane loads (map entry, then the rows:
+// two round trips) where the arithmetic takes 0.5.  Here every lane keeps the nine rows and the map entry of the cell its ray is
+// in (a ray stays ~10 steps in a cell), all ten loads of a new cell go out together, and the step loop starts them a step AHEAD
+// (prefetch: where the ray will be after the next step if it goes on as it goes now), so they travel while the step's arithmetic
+// runs.  A wrong guess costs a reload at the point of use, never a wrong value: the tag is the cell the registers hold.
+// The polynomial is evaluated on vector registers exactly as PolyGather's kept cell is (the same Horner chain, the same bits);
+// a flat cell's entry overrides it with (constant, 0, 0) like flat_lane does.
+template <typename T> struct PolyLaneKept {
+    static constexpr bool kPoly = true;
+    typedef typename FlatBits<T>::type B;
+    int tag;
+    B ent;
+    Quad<T> rows[9];
+    float hov_limit = __builtin_inff();
+    __device__ __forceinline__ void init() {
+        tag = -1; ent = ~(B)0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) rows[k] = Quad<T>{T(0), T(0), T(0), T(0)};
+    }
+    __device__ __forceinline__ void load(const FieldDev<T>& F, int cell) {
+        tag = cell;
+        ent = F.flat ? reinterpret_cast<const B*>(F.poly)[(long)cell - (long)F.flat] : ~(B)0;
+        const Quad<T>* p = reinterpret_cast<const Quad<T>*>(F.poly + (size_t)cell * kPolyStride);
+#pragma unroll
+        for (int k = 0; k < 9; k++) rows[k] = p[k];
+    }
+    __device__ __forceinline__ void lookup_xy(const FieldDev<T>& F, bool active, T x, T y, T& n, T& gx, T& gy, float& lam) {
+        PolyCell<T> c;
+        poly_locate(F, x, y, rt_ballot(active), c);
+        if (active && c.cell != tag) load(F, c.cell);
+        auto row = [&](int k) -> Quad<T> { return rows[k]; };
+        gx = poly_bicubic<T, 0>(row, 0, c.u, c.v);
+        gy = poly_bicubic<T, 0>(row, 4, c.u, c.v);
+        n = poly_bilinear<T, 0>(rows[8], c.u, c.v);
+        const bool fl = flat_entry<T>(ent);
+        lam = fl ? 0.f : steep_of<T>(ent);
+        if (fl) { n = __builtin_bit_cast(T, ent); gx = T(0); gy = T(0); }
+        if (!active) { n = T(1); gx = T(0); gy = T(0); lam = 0.f; }      // what an idle lane steps on with (finite; nobody reads its state)
+    }
+    __device__ __forceinline__ void lookup_xy(const FieldDev<T>& F, bool active, T x, T y, T& n, T& gx, T& gy) {
+        float lam;
+        lookup_xy(F, active, x, y, n, gx, gy, lam);
+    }
+    __device__ __forceinline__ void prefetch(const FieldDev<T>& F, bool active, T xp, T yp) {
+        const T jfx = floor_((xp - F.ax) * F.inv_hx), jfy = floor_((yp - F.ay) * F.inv_hy);
+        if (active && jfx >= T(0) && jfx < (T)F.ncx && jfy >= T(0) && jfy < (T)(F.qy - 1)) {
+            const int cell = (int)jfy * F.ncx + (int)jfx;
+            if (cell != tag) load(F, cell);
+        }
+    }
+};
+
 // ---------------------------------------------------------------- per-ray state
 // The six quantities a ray ACCUMULATES over thousands of steps -- position, angle, the two arclengths, traveltime --
 // are fp64 in both precisions (in registers and in HBM).  With T = float the field, its lookup and the whole step
@@ -1445,25 +1501,40 @@ inline bool rotates_unit(int method, bool f64) {
 // Critical rays.  A ray that runs ALONG a sharp transition of the medium amplifies any rounding difference: at the
 // interface scenario's critical angle a million times (the reference's own rows move 1e-6 for a 1e-12 change of the launch
 // angle), and there a fused step -- ~1e-16 per step from the reference's roundings -- ends up past 1e-9.  Which rays those are
-// cannot be told from the launch conditions, but it shows on the way: they spend hundreds of steps in the few steep cells of the
-// grid (FlatBits: lambda >= lambda_0) heading within 0.02 rad of the iso-lines, where a ray that merely crosses or reflects
-// spends a handful.  hov adds the cells' steepness over exactly those steps: (grad n . u)^2 < 4e-4 |grad n|^2 with the gradient
-// at the new point and the tangent the step started with -- five fp64 instructions, executed only when some lane of the wave is
-// in a steep cell.  Per lane from the ray's own values: independent of wave mates, schedule and partition.
-// Calibration (the oracle's own trajectories of the 1 M-ray interface fan around each method's split, against the movement of
-// its rows under a 1e-12 change of the launch angle, tools/hover_calibration.py): hov * DELTA_S >= 2.0 holds for every ray whose
-// amplification exceeds 3e3 (op1: 2.06, op2: 2.32, op6: 2.10, op8: 2.14 is the smallest sum among them) and for 320-400 rays of the
-// million in all; the fused forms' rows leave 1e-9 from amplification 2.5e5 on (their distance from the reference's roundings
-// is 4e-15 of a launch angle), so the limit keeps a factor 80 in hand.
-constexpr float kHoverLimit = 2.0f;      // hov * DELTA_S beyond which a ray is re-traced in reference order
+// cannot be told from the launch conditions, but it shows on the way.  A displacement q across the ray obeys q'' = (n_vv / n) q
+// along it (n_vv: the second derivative of n across the ray), so it grows by at most exp(integral of sqrt(|n_vv| / n) ds); in a
+// wall the Hessian is n'' g g' (g the unit gradient), n_vv = n'' (v . g)^2, and with the cell's steepness lambda =
+// sqrt(|Hessian n|_inf / n) (FlatBits; kept for the few cells with lambda >= lambda_0) the exponent is the sum over the ray's steps
+// of lambda |v . g| DELTA_S.  hov adds lambda sqrt(1 - (g . u)^2) over the steps that end in a steep cell, with the gradient at the
+// new point and the tangent the step started with: a ray that crosses a wall squarely adds next to nothing, one that reflects a
+// few units, one that runs along it hundreds of steps' worth.  Five fp64 and four fp32 instructions, executed only when some lane
+// of the wave is in a steep cell; per lane from the ray's own values: independent of wave mates, schedule and partition.
+// Calibration (tools/hover_measures.py: the oracle's own trajectories around the split of the 1 M-ray fan, against the movement
+// of their rows under a 1e-12 change of the launch angle, for the interface scenario's wall as it is and tilted by 3 and 11
+// degrees): correlation of the sum with ln(amplification) 0.98-0.99 (0.88-0.92 for round 5's first form, which counted lambda
+// over the steps heading within 0.02 rad of the iso-lines: on a tilted wall the spline's gradient wobbles by more than that and
+// critical rays went uncounted); the smallest sum among the rays with amplification > 1e4 is 14.65 / 15.22 / 17.24, and a limit
+// there flags exactly those (352 / 352 / 384 of the million); no other ray of the fan comes near (reflecting rays at grazing
+// incidence reach 6-8).  The fused forms' rows leave 1e-9 from amplification 2.5e5 on (their distance from the reference's
+// roundings is 4e-15 of a launch angle): 12 -- amplification 1e3 on the straight wall, 2 016 rays of the million -- keeps a
+// factor 250 in hand.  What the sum does not see: sensitivity that is not
+// exponential growth along a wall (a bent wall's focusing: tools/tilted_interface_probe.py's arcs) -- reference_order = 1 is the
+// answer there.
+constexpr float kHoverLimit = 12.0f;     // hov * DELTA_S beyond which a ray is re-traced in reference order
 // Returns false for a lane whose sum has passed the limit: the step then reports the ray as ended, with hov = +inf as
 // the mark -- the step loops have no test of their own for this on their hot path; they look at the mark where they store an ended ray.
 // (The limit travels with the gather object, PolyGather::hov_limit: see Consts for why not with the constants.)
+// hover_weight: |v . g| from d = g . u (not normalised) and g2 = |g|^2; the same expression wherever a step is weighed.
+template <typename T> __device__ __forceinline__ float hover_weight(T d, T g2) {
+    const float q = (float)(d * d), g = (float)g2;
+    const float w = 1.f - q * __builtin_amdgcn_rcpf(g);
+    return g > 0.f && w > 0.f ? __builtin_amdgcn_sqrtf(w) : 0.f;
+}
 template <typename T> __device__ __forceinline__ bool hover_update(float hov_limit, Ray<T>& r, bool active, float lam, T fgx, T fgy) {
     if (rt_ballot(lam != 0.f) == 0ull) return true;
     const T d = fma_(fgy, r.uy, fgx * r.ux), g2 = fma_(fgy, fgy, fgx * fgx);
-    if (active && lam != 0.f && d * d < T(4e-4) * g2) {
-        r.hov += lam;
+    if (active && lam != 0.f) {
+        r.hov = fmaf(lam, hover_weight(d, g2), r.hov);
         if (r.hov > hov_limit) { r.hov = INFINITY; return false; }
     }
     return true;

@@ -789,13 +789,44 @@ template <typename T> struct BatchDev {
 // queue is full (the ray then carries on in the fused form and is counted: rtmi_stats.retrace_overflow).
 // The entry goes to the coherence point (device scope) and is acknowledged before the count is published to the host, which
 // launches the consumer only after it has read that count: the consumer kernel starts with the entry visible.
+// The count the host sees must never run ahead of the entries or fall behind for good (a stale count leaves its rays waiting
+// until the main kernel is done: 5 ms more per pass, measured).  So behind the entries sit three words -- committed entries, a
+// lock, the count last published -- and every wave, once its entries are acknowledged, takes the lock and publishes the committed
+// count if every reserved slot is committed and the count has grown: the stores to the host are one at a time, each acknowledged
+// before the lock is released, and the value only rises.
 template <typename T> __device__ __forceinline__ bool push_critical(const BatchDev<T>& a, long k, int row) {
     const unsigned long long slot = atomicAdd(a.rq, 1ull);
     if (slot >= (unsigned long long)a.rq_cap) return false;
     __hip_atomic_store(a.rq + 1 + slot, ((unsigned long long)(unsigned)row << 32) | (unsigned long long)(unsigned)k, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-    __hip_atomic_store(a.rq_host, (unsigned)(slot + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    unsigned long long* ctl = a.rq + 1 + a.rq_cap;
+    atomicAdd(ctl, 1ull);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    // One lane per wave takes the lock, for all of the wave's lanes that are here together (their entries are acknowledged and
+    // counted: the wave waits and counts as one).  Never a lane per ray: the compiler places a critical section BEHIND its
+    // spin loop, where a lane that has won would wait for its wave mates to leave the loop they can only leave after it.
+    // The spin is bounded: a wave that cannot get the lock leaves the publishing to the next one (the host reads the
+    // device's own count once the main kernel is done in any case).
+    const unsigned long long act = rt_ballot(true);
+    if (__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u)) == 0u) {
+        bool mine = false;
+        for (int spin = 0; spin < (1 << 16) && !mine; ++spin) {
+            mine = atomicCAS(ctl + 1, 0ull, 1ull) == 0ull;
+            if (!mine) __builtin_amdgcn_s_sleep(8);
+        }
+        if (mine) {
+            const unsigned long long c = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long rsv = __hip_atomic_load(a.rq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (rsv > (unsigned long long)a.rq_cap) rsv = a.rq_cap;
+            if (c == rsv && c > __hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(a.rq_host, (unsigned)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __builtin_amdgcn_s_waitcnt(0x0F70);
+                __hip_atomic_store(ctl + 2, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __hip_atomic_store(ctl + 1, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     return true;
 }
 
@@ -2368,8 +2399,8 @@ static unsigned retrace_capacity(int64_t R) {
 }
 // The re-trace of queue slots [lo, hi): one lane per ray, from its launch conditions (:809-826) --
 //   in the reference's operation order (rt::ex::ray_step: the oracle's bits, row for row) through the stretch that made the ray
-//   critical: until it has reached the row where the fused run stopped it AND has not hovered -- rt::hover_update's own test: in a
-//   steep cell, heading within 0.02 rad of the iso-lines -- for kRetraceOut steps;
+//   critical: until it has reached the row where the fused run stopped it AND has not hovered -- in a steep cell, heading within
+//   60 degrees of the iso-lines (rt::hover_weight > 0.5) -- for kRetraceOut steps;
 //   then in the fused form again (rt::ray_step, per-lane lookups) to its end: a ray that has turned away from the transition is as
 //   well conditioned as any other the fused kernels keep (the same measure says so), and the thousands of steps a refracted grazing
 //   ray still has to go to the box's far side (8 700 on the interface fan) cost 0.5 us each instead of 2.5.  Its rows from there on
@@ -2378,7 +2409,7 @@ static unsigned retrace_capacity(int64_t R) {
 // Rows and final state go to the hidden batch's arrays s (slot j of every array), never to the main batch's: the main kernel is
 // still running.  m: the main batch (launch conditions, per-ray steps).  One wave per block, <= 168 registers: a block fits
 // wherever one of the main kernel's has retired.
-constexpr int kRetraceOut = 512;
+constexpr int kRetraceOut = 256;
 // Two kernels per chunk, one after the other on the chunk's stream (one wave per block; a lane = a queue slot):
 //   k_retrace_ref: the reference-order part.  A lane leaves its loop at the hand-back (state stored, alive = 1) or when its ray ends
 //   (alive = 0); no lane steps in two forms in one iteration.  marked_only: the final sweep for rays whose fused tail hovered again
@@ -2421,7 +2452,7 @@ __global__ __launch_bounds__(64, 3) void k_retrace_ref(BatchDev<double> s, Batch
             // (reference order: Ray::hov is the steepness of the cell the ray arrived in, and the gradient there is current whenever
             // that is not 0)
             const T d = rt::fma_(r.gy, uy0, r.gx * ux0), g2 = rt::fma_(r.gy, r.gy, r.gx * r.gx);
-            out = (r.hov != 0.f && d * d < T(4e-4) * g2) ? 0 : out + 1;
+            out = (r.hov != 0.f && rt::hover_weight(d, g2) > 0.5f) ? 0 : out + 1;
             if (s.stride && i % s.stride == 0 && i / s.stride < s.rec_rows) write_row(s, (long)(i / s.stride), (long)j, r);
             alive = inside && (i + 1 < max_size);
             handed = alive && i >= ref_until && out >= kRetraceOut;
@@ -2448,7 +2479,7 @@ __global__ __launch_bounds__(64, 2) void k_retrace_tail(BatchDev<double> s, Batc
     rt::Consts<T> K = m.K;
     int max_size = m.max_size;
     if (m.vstep) { K.step = m.vstep[k]; K.step2h = m.vstep2h[k]; K.step2 = K.step2h * 2.0; max_size = m.vmax[k]; }
-    rt::PolyGather<T, rt::kPolyCached, true> pg;
+    rt::PolyLaneKept<T> pg;
     pg.init();
     pg.hov_limit = m.hov_limit / (float)K.step;
     rt::Ray<T> r;
@@ -2466,12 +2497,8 @@ __global__ __launch_bounds__(64, 2) void k_retrace_tail(BatchDev<double> s, Batc
     }
     bool alive = valid;
     __builtin_amdgcn_s_waitcnt(0x0F70);
-    // every lane runs every iteration (the kept-cell lookup votes); a lane whose ray has ended evolves a stale state nobody reads:
-    // what it leaves behind is stored the moment it ends
-    while (rt_ballot(alive) != 0ull) {
-        const bool active = alive;
-        const int row = i + 1;
-        const bool inside = rt::ray_step<T, METHOD, ISO>(s.F, K, pg, active, r, row);
+    // what a step leaves behind: the row, and the state the moment the ray ends
+    auto after = [&](bool active, bool inside, int row) {
         if (active) {
             i = row;
             if (s.stride && i % s.stride == 0 && i / s.stride < s.rec_rows) write_row(s, (long)(i / s.stride), (long)j, r);
@@ -2486,6 +2513,17 @@ __global__ __launch_bounds__(64, 2) void k_retrace_tail(BatchDev<double> s, Batc
                 if (dbg) { atomicAdd(dbg + 1, (unsigned long long)(i - i0)); atomicAdd(dbg + 2, again ? 1ull : 0ull); atomicMax(dbg + 4, (unsigned long long)i); }
             }
         }
+    };
+    // every lane runs every iteration; a lane whose ray has ended evolves a stale state nobody reads: what it leaves behind is
+    // stored the moment it ends
+    while (rt_ballot(alive) != 0ull) {
+        const bool active = alive;
+        const int row = i + 1;
+        const bool inside = rt::ray_step<T, METHOD, ISO>(s.F, K, pg, active, r, row);
+        after(active, inside, row);
+        // where the next step will look the field up, if the ray goes on as it goes now: a lane about to enter another cell
+        // starts that cell's loads here, a step's arithmetic ahead of their use
+        pg.prefetch(s.F, alive, (T)r.x + r.ux * K.step, (T)r.y + r.uy * K.step);
     }
 }
 static const void* retrace_ref_fn(int method) {
@@ -2549,8 +2587,8 @@ static int retrace_create(rtmi_batch* b, const double* x0, const double* y0, con
     b->rt = t;                                  // rtmi_batch_destroy frees whatever is there if anything below fails
     t->cap = retrace_capacity(b->R);
     const size_t Rs = (size_t)t->cap;
-    HIP_TRY(hipMalloc(&t->rq, (1 + (size_t)t->cap) * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(t->rq, 0, (1 + (size_t)t->cap) * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&t->rq, (4 + (size_t)t->cap) * sizeof(unsigned long long)));          // count, entries, push_critical's three words
+    HIP_TRY(hipMemset(t->rq, 0, (4 + (size_t)t->cap) * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(&t->hov, (size_t)b->R * sizeof(float)));
     if (getenv("RTMI_DEBUG")) { HIP_TRY(hipMalloc(&t->dbg, 8 * sizeof(unsigned long long))); HIP_TRY(hipMemset(t->dbg, 0, 8 * sizeof(unsigned long long))); }
     HIP_TRY(hipHostMalloc(&t->host_count, 4 * sizeof(unsigned)));
@@ -2591,6 +2629,7 @@ static int retrace_reset(rtmi_batch* b) {
     for (hipStream_t a : t->aux) HIP_TRY(hipStreamSynchronize(a));
     t->chunks = 0;
     HIP_TRY(hipMemsetAsync(t->rq, 0, sizeof(unsigned long long), b->stream));
+    HIP_TRY(hipMemsetAsync(t->rq + 1 + t->cap, 0, 3 * sizeof(unsigned long long), b->stream));
     t->host_count[0] = 0;
     HIP_TRY(hipMemsetAsync(t->sub->counters + 3, 0, sizeof(unsigned long long), b->stream));
     t->launched = t->scattered = 0; t->pending = false; t->overflow = 0;

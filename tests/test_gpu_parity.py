@@ -1241,6 +1241,54 @@ def test_critical_rays_of_the_1m_interface_fan(method, first, rb, gpu_fields, or
     assert st0["retraced"] == 0 and (dev0 > REL).sum() >= 1               # the window was chosen around the known offenders
 
 
+@pytest.mark.parametrize("tilt_deg, method", [(3.0, 6), (11.0, 6), (11.0, 1)])
+def test_critical_rays_of_a_tilted_wall(tilt_deg, method, rb):
+    """The hand-over must not lean on the interface scenario's wall lying along a grid line: the same sigmoid wall tilted against
+    the grid (both sides get the SAMPLES: rtmi_field_from_samples / the oracle's from_samples), where the spline's gradient
+    direction wobbles from cell to cell.  The split of the 1 048 576-ray fan is found on the device (every 64th ray), then the
+    1 024 contiguous rays around it are compared with the oracle, every 16th row: a default batch within 1e-9 on EVERY ray, equal
+    step counts, some rays re-traced.  (Round 5's first hover criterion -- an angle threshold of 0.02 rad -- left 3-5 rays of
+    4 096 beyond 1e-9 at 11 degrees: tools/tilted_interface_probe.py, profiles/r05_tilted_walls.txt.)"""
+    from oracle import rt_oracle as O
+    R, W = 1 << 20, 1024
+    lim = LIMITS["interface"]
+    ms = int(np.ceil(80 / rb.DELTA_S) + 1)
+    x, y = O.Field("interface", lim, rb.DELTA).arrays()[:2]
+    X, Y = np.meshgrid(x, y)
+    a = np.radians(tilt_deg)
+    d = -np.sin(a) * (X + 2.0) + np.cos(a) * Y
+    Z = np.sqrt(2.0) - (np.sqrt(2.0) - 1.0) / (1.0 + np.exp(-np.clip(d / 0.005, -700, 700)))
+    F = rb.Field.from_samples(x, y, Z, rb.DELTA)
+    OF = O.Field.from_samples(x, y, Z, rb.DELTA)
+    fan = np.linspace(2 * np.pi / 60, np.pi / 2, R)
+    b = rb.Batch(F, method, rb.DELTA_S, ms, lim, 1, fan[::64], -2.0, -2.0, record_stride=0)
+    b.run()
+    fin = b.final()
+    b.close()
+    k = int(np.argmax(np.abs(np.diff(fin[1])) + np.abs(np.diff(fin[0]))))
+    i0 = min(max(0, k * 64 + 32 - W // 2), R - W)
+    th = fan[i0:i0 + W]
+    kw = dict(record_stride=16, rec_rows=600)
+    o = O.trazar(OF, method, 1, rb.DELTA_S, ms, lim, -2.0, -2.0, th, nthreads=16, **kw)
+    assert np.ptp(o["final"][1]) > 1.0
+    out = {}
+    for retrace in (True, False):
+        b = rb.Batch(F, method, rb.DELTA_S, ms, lim, 1, th, -2.0, -2.0, retrace=retrace, **kw)
+        b.run()
+        s, dr, st = b.rows(), b.d_ray(), b.stats()
+        b.close()
+        same = dr[2] == o["d_ray"][2]
+        dev = np.array([np.abs(s[:, q][:, :, same] - o["s_ray"][:, q][:, :, same]).max(axis=(0, 1)) / np.abs(o["s_ray"][:, q]).max()
+                        for q in ([0, 1], [2, 3], [4], [5])]).max(axis=0)
+        out[retrace] = (int(same.sum()), dev, st)
+    F.close()
+    print(f"wall tilted {tilt_deg:g} deg, op{method}, split at ray {k * 64 + 32}: default {out[True][2]['retraced']} rays re-traced, largest "
+          f"{out[True][1].max():.1e}; no_retrace: {int((out[False][1] > REL).sum())} rays beyond 1e-9 (largest {out[False][1].max():.1e})")
+    n, dev, st = out[True]
+    assert n == W and (dev > REL).sum() == 0 and dev.max() < 2e-10
+    assert 0 < st["retraced"] < W and st["retrace_overflow"] == 0
+
+
 @pytest.mark.parametrize("method", [6, 1, 2, 8])
 def test_interface_rays_do_not_depend_on_their_wave_mates(method, rb, gpu_fields):
     """A ray's bits must not depend on which rays share its wave: the wave-level layouts of the fused step -- the flat-cell map's
