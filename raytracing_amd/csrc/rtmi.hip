@@ -2682,13 +2682,34 @@ static int retrace_drain(rtmi_batch* b, bool overlap) {
             else { const unsigned hc = *(volatile unsigned*)t->host_count; count = hc < t->cap ? hc : t->cap; }
             const auto now = std::chrono::steady_clock::now();
             if (count > seen) { seen = count; last_change = now; }
-            // a chunk: what has arrived once the main kernel is done, a wave's worth, or whatever there is when nothing has come for 100 us
-            if (count > t->launched && (done || count - t->launched >= 64 || now - last_change > std::chrono::microseconds(100))) {
-                const int rc = retrace_launch_chunk(b, t->launched, count, t->aux[t->chunks++ % Retrace::kAux]);
-                if (rc) return rc;
-                if (dbg) fprintf(stderr, "rtmi: retrace: slots [%u, %u) launched %.3f ms after the main kernel%s\n", t->launched, count,
-                                 std::chrono::duration<double, std::milli>(now - t_start).count(), done ? " (which had finished)" : "");
-                t->launched = count;
+            // A chunk = one launch (a block per 64 rays, the blocks side by side) on one of the aux streams; a stream runs its chunks
+            // one after the other and a chunk lasts as long as its slowest ray (10-20 ms), so a chunk must never queue behind
+            // another: it goes to an IDLE stream or waits.  While two or more streams are idle a wave's worth of rays is launched as
+            // it arrives (the first arrivals start their long reference-order stretch at once); the last idle stream is kept for
+            // what has gathered once nothing new has come for 200 us (a burst of arrivals spread over half a millisecond used to end
+            // as a fifth chunk behind the first: +11 ms on the full-record interface pass); with no stream idle the rays wait for
+            // one.  Once the main kernel is done everything left goes out on the first stream that is or becomes idle.
+            if (count > t->launched) {
+                int idle = 0, pick = -1;
+                for (int a = 0; a < Retrace::kAux; a++) {
+                    const hipError_t sq = hipStreamQuery(t->aux[a]);
+                    if (sq == hipSuccess) { if (pick < 0) pick = a; ++idle; }
+                    else if (sq != hipErrorNotReady) return fail(RTMI_ERR_HIP, std::string("rtmi_run (re-trace): ") + hipGetErrorString(sq));
+                }
+                const bool paused = now - last_change > std::chrono::microseconds(200);
+                const bool go = idle >= 2 ? (done || paused || count - t->launched >= 64) : idle == 1 ? (done || paused) : false;
+                if (go) {
+                    const int rc = retrace_launch_chunk(b, t->launched, count, t->aux[pick]);
+                    if (rc) return rc;
+                    ++t->chunks;
+                    if (dbg) fprintf(stderr, "rtmi: retrace: slots [%u, %u) launched %.3f ms after the main kernel%s (stream %d, %d idle)\n", t->launched, count,
+                                     std::chrono::duration<double, std::milli>(now - t_start).count(), done ? " (which had finished)" : "", pick, idle);
+                    t->launched = count;
+                }
+            }
+            if (done && count > t->launched) {          // every stream busy: wait for one (they all finish)
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
+                continue;
             }
             if (done) {
                 if (dbg) fprintf(stderr, "rtmi: retrace: main kernel done after %.3f ms; %u rays handed over, %u found the queue full\n",
