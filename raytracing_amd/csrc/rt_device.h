@@ -1505,8 +1505,8 @@ inline bool rotates_unit(int method, bool f64) {
 // along it (n_vv: the second derivative of n across the ray), so it grows by at most exp(integral of sqrt(|n_vv| / n) ds); in a
 // wall the Hessian is n'' g g' (g the unit gradient), n_vv = n'' (v . g)^2, and with the cell's steepness lambda =
 // sqrt(|Hessian n|_inf / n) (FlatBits; kept for the few cells with lambda >= lambda_0) the exponent is the sum over the ray's steps
-// of lambda |v . g| DELTA_S.  hov adds lambda sqrt(1 - (g . u)^2) over the steps that end in a steep cell, with the gradient at the
-// new point and the tangent the step started with: a ray that crosses a wall squarely adds next to nothing, one that reflects a
+// of lambda |v . g| DELTA_S.  hov adds lambda sqrt(1 - (g . u)^2) over the steps that end in a steep cell, with the gradient and
+// the unit tangent at the new point: a ray that crosses a wall squarely adds next to nothing, one that reflects a
 // few units, one that runs along it hundreds of steps' worth.  Five fp64 and four fp32 instructions, executed only when some lane
 // of the wave is in a steep cell; per lane from the ray's own values: independent of wave mates, schedule and partition.
 // Calibration (tools/hover_measures.py: the oracle's own trajectories around the split of the 1 M-ray fan, against the movement
@@ -1530,9 +1530,12 @@ template <typename T> __device__ __forceinline__ float hover_weight(T d, T g2) {
     const float w = 1.f - q * __builtin_amdgcn_rcpf(g);
     return g > 0.f && w > 0.f ? __builtin_amdgcn_sqrtf(w) : 0.f;
 }
-template <typename T> __device__ __forceinline__ bool hover_update(float hov_limit, Ray<T>& r, bool active, float lam, T fgx, T fgy) {
+template <typename T> __device__ __forceinline__ bool hover_update(float hov_limit, Ray<T>& r, bool active, float lam) {
     if (rt_ballot(lam != 0.f) == 0ull) return true;
-    const T d = fma_(fgy, r.uy, fgx * r.ux), g2 = fma_(fgy, fgy, fgx * fgx);
+    // at the END of the step, from the ray's own new state (gradient and unit tangent at the new point): nothing else of the step is
+    // live there -- weighed in the middle of the step, with the tangent the step started with, the sum's few temporaries sent
+    // op1's and op8's kernels, which sit at their 128 registers, into spilling 56 / 42 of them in the step loop (27 vs 22 ms)
+    const T d = fma_(r.gy, r.uy, r.gx * r.ux), g2 = fma_(r.gy, r.gy, r.gx * r.gx);
     if (active && lam != 0.f) {
         r.hov = fmaf(lam, hover_weight(d, g2), r.hov);
         if (r.hov > hov_limit) { r.hov = INFINITY; return false; }
@@ -1549,14 +1552,10 @@ __device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& 
     T fn, fgx, fgy;
     T eps;
     const bool flag = op_advance<T, METHOD>(k, r, fx, fy, eps);
-    bool calm = true;
-    if constexpr (ReportsSteep<G>::value && RotatesUnit<T, METHOD>::value) {     // fp64 op1/2/6/8 with the flat-cell map compiled in
-        float lam;
-        n_gradient(F, gather, active, (T)fx, (T)fy, fn, fgx, fgy, lam);
-        calm = hover_update(gather.hov_limit, r, active, lam, fgx, fgy);
-    } else {
-        n_gradient(F, gather, active, (T)fx, (T)fy, fn, fgx, fgy);
-    }
+    constexpr bool kHover = ReportsSteep<G>::value && RotatesUnit<T, METHOD>::value;     // fp64 op1/2/6/8 with the flat-cell map compiled in
+    float lam = 0.f;
+    if constexpr (kHover) n_gradient(F, gather, active, (T)fx, (T)fy, fn, fgx, fgy, lam);
+    else n_gradient(F, gather, active, (T)fx, (T)fy, fn, fgx, fgy);
     const T frn = rcp_full(fn);
     // (A "constant-medium step" -- where the gradient is exactly zero at both ends of the step the angle determination and the rotation
     // of the unit tangent return what they were given, term by term, and can be skipped: 55 of the step's 135 vector instructions on
@@ -1576,6 +1575,8 @@ __device__ __forceinline__ bool ray_step(const FieldDev<T>& F, const Consts<T>& 
         store_update<T, ISO, true>(k, r, fx, fy, fth, fn, fgx, fgy, frn, eps, (i & (RotatesUnit<T, METHOD>::refresh - 1)) == 0);
     else
         store_update<T, ISO>(k, r, fx, fy, fth, fn, fgx, fgy, frn, eps);
+    bool calm = true;
+    if constexpr (kHover) calm = hover_update(gather.hov_limit, r, active, lam);
     return calm && (boot || !outside(k, r));
     }
 }

@@ -775,7 +775,7 @@ template <typename T> struct BatchDev {
     // Critical rays (rt::hover_update, "retrace" below): hov[R] is the per-ray hover sum (state; nullptr: this batch flags nothing),
     // hov_limit = rt::kHoverLimit (the sum times DELTA_S beyond which a ray is handed over), rq the hand-over queue in device
     // memory -- [0] rays pushed so far (also those beyond rq_cap: they stay), [1..] entries (row where the ray stopped << 32 | ray
-    // slot) -- and rq_host the same count in pinned host memory, where the host polls it while the kernel runs.
+    // slot) -- and rq_host one flag per entry in pinned host memory, where the host counts them while the kernel runs (push_critical).
     float* hov;
     float hov_limit;
     unsigned rq_cap;
@@ -789,44 +789,18 @@ template <typename T> struct BatchDev {
 // queue is full (the ray then carries on in the fused form and is counted: rtmi_stats.retrace_overflow).
 // The entry goes to the coherence point (device scope) and is acknowledged before the count is published to the host, which
 // launches the consumer only after it has read that count: the consumer kernel starts with the entry visible.
-// The count the host sees must never run ahead of the entries or fall behind for good (a stale count leaves its rays waiting
-// until the main kernel is done: 5 ms more per pass, measured).  So behind the entries sit three words -- committed entries, a
-// lock, the count last published -- and every wave, once its entries are acknowledged, takes the lock and publishes the committed
-// count if every reserved slot is committed and the count has grown: the stores to the host are one at a time, each acknowledged
-// before the lock is released, and the value only rises.
+// The host learns of an entry through a flag of ITS OWN in pinned host memory (rq_host[slot], stored once the entry is
+// acknowledged) and counts the leading run of flags: no store depends on another's order.  (A count published by plain
+// stores of slot + 1 landed out of order now and then -- the host sat on a stale count until the main kernel was done, +5 ms
+// per pass -- and could run ahead of a slower lane's entry; a count published under a device lock was right but its loop and
+// loads cost the kernels that sit at 128 registers spills in the step loop.)
 template <typename T> __device__ __forceinline__ bool push_critical(const BatchDev<T>& a, long k, int row) {
-    const unsigned long long slot = atomicAdd(a.rq, 1ull);
-    if (slot >= (unsigned long long)a.rq_cap) return false;
+    const unsigned slot = atomicAdd(reinterpret_cast<unsigned*>(a.rq), 1u);       // the low word of the 64-bit count
+    if (slot >= a.rq_cap) return false;
     __hip_atomic_store(a.rq + 1 + slot, ((unsigned long long)(unsigned)row << 32) | (unsigned long long)(unsigned)k, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
     __builtin_amdgcn_s_waitcnt(0x0F70);      // vmcnt(0)
-    unsigned long long* ctl = a.rq + 1 + a.rq_cap;
-    atomicAdd(ctl, 1ull);
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    // One lane per wave takes the lock, for all of the wave's lanes that are here together (their entries are acknowledged and
-    // counted: the wave waits and counts as one).  Never a lane per ray: the compiler places a critical section BEHIND its
-    // spin loop, where a lane that has won would wait for its wave mates to leave the loop they can only leave after it.
-    // The spin is bounded: a wave that cannot get the lock leaves the publishing to the next one (the host reads the
-    // device's own count once the main kernel is done in any case).
-    const unsigned long long act = rt_ballot(true);
-    if (__builtin_amdgcn_mbcnt_hi((unsigned)(act >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)act, 0u)) == 0u) {
-        bool mine = false;
-        for (int spin = 0; spin < (1 << 16) && !mine; ++spin) {
-            mine = atomicCAS(ctl + 1, 0ull, 1ull) == 0ull;
-            if (!mine) __builtin_amdgcn_s_sleep(8);
-        }
-        if (mine) {
-            const unsigned long long c = __hip_atomic_load(ctl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned long long rsv = __hip_atomic_load(a.rq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (rsv > (unsigned long long)a.rq_cap) rsv = a.rq_cap;
-            if (c == rsv && c > __hip_atomic_load(ctl + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                __hip_atomic_store(a.rq_host, (unsigned)c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __builtin_amdgcn_s_waitcnt(0x0F70);
-                __hip_atomic_store(ctl + 2, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __hip_atomic_store(ctl + 1, 0ull, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
+    __hip_atomic_store(a.rq_host + slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     return true;
 }
 
@@ -1558,7 +1532,7 @@ struct Retrace {
     rtmi_batch* sub = nullptr;            // the hidden batch: cap slots of state and rows (its own kernels never run: k_retrace fills it)
     unsigned cap = 0;                     // queue entries = slots that can be re-traced per pass
     unsigned long long* rq = nullptr;     // device: [0] rays pushed, [1 .. cap] entries
-    unsigned* host_count = nullptr;       // pinned host: [0] the count as the kernels publish it, [1..2] scratch for reading rq[0]
+    unsigned* host_count = nullptr;       // pinned host: [0] the flags counted so far, [2..3] scratch for reading rq[0], [4 + slot] the kernels' per-slot flags
     float* hov = nullptr;                 // device [R]: the main batch's hover sums (ray state)
     static constexpr int kAux = 4;
     hipStream_t aux[kAux] = {nullptr, nullptr, nullptr, nullptr};   // high priority, non-blocking: successive chunks run side by side
@@ -1652,7 +1626,7 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     a.hov_limit = b->rt ? hover_limit() : INFINITY;
     a.rq_cap = b->rt ? b->rt->cap : 0u;
     a.rq = b->rt ? b->rt->rq : nullptr;
-    a.rq_host = b->rt ? b->rt->host_count : nullptr;
+    a.rq_host = b->rt ? b->rt->host_count + 4 : nullptr;
     a.prio = b->is_retrace_sub ? 1 : 0;
     a.gflat = b->field->gmax * 0x1p-72;
     return a;
@@ -2587,12 +2561,12 @@ static int retrace_create(rtmi_batch* b, const double* x0, const double* y0, con
     b->rt = t;                                  // rtmi_batch_destroy frees whatever is there if anything below fails
     t->cap = retrace_capacity(b->R);
     const size_t Rs = (size_t)t->cap;
-    HIP_TRY(hipMalloc(&t->rq, (4 + (size_t)t->cap) * sizeof(unsigned long long)));          // count, entries, push_critical's three words
-    HIP_TRY(hipMemset(t->rq, 0, (4 + (size_t)t->cap) * sizeof(unsigned long long)));
+    HIP_TRY(hipMalloc(&t->rq, (1 + (size_t)t->cap) * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(t->rq, 0, (1 + (size_t)t->cap) * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(&t->hov, (size_t)b->R * sizeof(float)));
     if (getenv("RTMI_DEBUG")) { HIP_TRY(hipMalloc(&t->dbg, 8 * sizeof(unsigned long long))); HIP_TRY(hipMemset(t->dbg, 0, 8 * sizeof(unsigned long long))); }
-    HIP_TRY(hipHostMalloc(&t->host_count, 4 * sizeof(unsigned)));
-    t->host_count[0] = t->host_count[1] = t->host_count[2] = t->host_count[3] = 0;
+    HIP_TRY(hipHostMalloc(&t->host_count, (4 + (size_t)t->cap) * sizeof(unsigned)));
+    memset(t->host_count, 0, (4 + (size_t)t->cap) * sizeof(unsigned));
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));           // hi is the numerically lowest = highest priority
     if (getenv("RTMI_DEBUG")) fprintf(stderr, "rtmi: retrace: stream priorities %d (lowest) .. %d (highest); queue of %u slots\n", lo, hi, t->cap);
@@ -2629,8 +2603,7 @@ static int retrace_reset(rtmi_batch* b) {
     for (hipStream_t a : t->aux) HIP_TRY(hipStreamSynchronize(a));
     t->chunks = 0;
     HIP_TRY(hipMemsetAsync(t->rq, 0, sizeof(unsigned long long), b->stream));
-    HIP_TRY(hipMemsetAsync(t->rq + 1 + t->cap, 0, 3 * sizeof(unsigned long long), b->stream));
-    t->host_count[0] = 0;
+    memset(t->host_count, 0, (4 + (size_t)t->cap) * sizeof(unsigned));
     HIP_TRY(hipMemsetAsync(t->sub->counters + 3, 0, sizeof(unsigned long long), b->stream));
     t->launched = t->scattered = 0; t->pending = false; t->overflow = 0;
     return RTMI_OK;
@@ -2679,7 +2652,13 @@ static int retrace_drain(rtmi_batch* b, bool overlap) {
             if (q != hipSuccess && q != hipErrorNotReady) return fail(RTMI_ERR_HIP, std::string("rtmi_run: ") + hipGetErrorString(q));
             const bool done = q == hipSuccess;
             if (done) { const int rc = read_count(); if (rc) return rc; }
-            else { const unsigned hc = *(volatile unsigned*)t->host_count; count = hc < t->cap ? hc : t->cap; }
+            else {          // the leading run of per-slot flags
+                const volatile unsigned* flags = t->host_count + 4;
+                unsigned n = t->host_count[0];
+                while (n < t->cap && flags[n] != 0u) ++n;
+                t->host_count[0] = n;
+                count = n;
+            }
             const auto now = std::chrono::steady_clock::now();
             if (count > seen) { seen = count; last_change = now; }
             // A chunk = one launch (a block per 64 rays, the blocks side by side) on one of the aux streams; a stream runs its chunks

@@ -2,7 +2,7 @@
 """The re-trace kernels ALONE on the chip: the 1 M-ray interface fan stepped with rtmi_step (asynchronous: nobody watches the queue),
 then one read -- the queued rays are re-traced in order on the batch's stream after the main kernel has finished.  Under
 rocprofv3 --kernel-trace this gives k_retrace_ref's and k_retrace_tail's durations without the main kernel's waves beside them
-(compare profiles/r05_iface_op6_retrace_timeline.txt, where they run beside it)."""
+(compare profiles/r05_iface_retrace_timelines.txt, where they run beside it)."""
 import os
 import sys
 
