@@ -561,7 +561,7 @@ def main():
                                    f"rays, interleaved across ranks), op{args.method}, DELTA_S={step:.12g}, "
                                    f"box={tuple(float(v) for v in lim)}, record={args.record}",
                        "rays_total": R_total, "rays_rank0": R_local, "ray_steps_per_pass_rank0": int(steps_per_pass),
-                       "method": f"op{args.method}", "record": args.record, "n_ray_rows": bool(args.n_ray and stride), "launch_mode": args.mode, "launch_mode_used": mode_used, "auto_fallbacks": int(st["auto_fallbacks"]), "retraced": int(st["retraced"]), "retrace_overflow": int(st["retrace_overflow"]), "reference_order": 3 if args.fast_field else 2 if args.fused else int(args.reference_order),
+                       "method": f"op{args.method}", "record": args.record, "n_ray_rows": bool(args.n_ray and stride), "launch_mode": args.mode, "launch_mode_used": mode_used, "auto_fallbacks": int(st["auto_fallbacks"]), "retraced": int(st["retraced"]), "retrace_overflow": int(st["retrace_overflow"]), "dispatch_first": int(st["dispatch_first"]), "reference_order": 3 if args.fast_field else 2 if args.fused else int(args.reference_order),
                        "ray_order": args.order, "sort_rays": bool(args.sort), "field_path": args.field_path,
                        "steps_per_launch": args.chunk or "all", "parallelism": f"ray-shard x{world}"},
             "roofline": roof,

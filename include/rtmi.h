@@ -284,6 +284,10 @@ typedef struct {
     uint32_t retrace_overflow;          /* ... and rays that qualified but found the hand-over queue full (1/128 of the batch, at least
                                            256): they stay in the fused form.  Expected 0 */
     uint64_t retraced_total;            /* re-traced over the batch's whole life */
+    uint32_t dispatch_first;            /* the 256-ray bundle the plain kernel's first hardware block takes: 0, or -- learnt from the batch's
+                                           first rtmi_run that handed critical rays over, kept for its re-runs like the AUTO schedule --
+                                           the first of the bundles that held them (their re-trace then starts with the kernel) */
+    uint32_t reserved_;
 } rtmi_stats;
 /* Synchronises the stream, then fills *s. */
 int rtmi_batch_stats(rtmi_batch *b, rtmi_stats *s);

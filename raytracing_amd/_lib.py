@@ -48,7 +48,8 @@ class Stats(C.Structure):
                 ("launch_mode_used", C.c_uint32), ("kernel_ms_total", C.c_double), ("launches_total", C.c_uint64),
                 ("auto_fallbacks", C.c_uint32), ("auto_kept", C.c_uint32),
                 ("auto_ms", (C.c_double * AUTO_SAMPLES) * 2), ("auto_n", C.c_uint32 * 2),
-                ("retraced", C.c_uint32), ("retrace_overflow", C.c_uint32), ("retraced_total", C.c_uint64)]
+                ("retraced", C.c_uint32), ("retrace_overflow", C.c_uint32), ("retraced_total", C.c_uint64),
+                ("dispatch_first", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class ShardStats(C.Structure):

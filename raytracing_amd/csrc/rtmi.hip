@@ -783,6 +783,7 @@ template <typename T> struct BatchDev {
     unsigned* rq_host;
     int prio;                      // > 0: the kernel's waves raise their issue priority (the re-trace batch, beside the main kernel)
     double gflat;                  // rt::GlobalGather::gflat (the reference-order step where the medium is constant, rt_exact.h)
+    unsigned blk_rot;              // k_advance, builds with the hover sum: the bundle the first hardware block takes (Retrace::rot)
 };
 
 // A fused ray whose hover sum passed the limit: queue it for the re-trace in reference order and stop it.  False when the
@@ -1177,7 +1178,14 @@ __global__ __launch_bounds__(256, sizeof(T) == 4 ? RTMI_F32_WAVES : LDS ? (light
 void k_advance(BatchDev<T> a, int nsteps) {
     __shared__ __attribute__((aligned(16))) T lds[kernel_lds_elems<T, METHOD, LDS>()];
     if (a.prio > 0) __builtin_amdgcn_s_setprio(3);     // the re-trace of a few hundred critical rays beside the main kernel's waves
-    advance_bundle<T, METHOD, ISO, LDS, VAR, false, RTMI_TILE_PHASES, NOFLAT>(a, lds, (long)xcd_grouped_block(blockIdx.x, gridDim.x) * blockDim.x, nsteps);
+    unsigned bundle = xcd_grouped_block(blockIdx.x, gridDim.x);
+    if constexpr (!NOFLAT && sizeof(T) == 8 && rt::rotating_method(METHOD)) {
+        // a re-run batch that handed critical rays over last time starts with THEIR bundles (Retrace::rot): the re-trace is one long
+        // dependent chain per ray and ends the pass the later the later it starts
+        bundle += a.blk_rot;
+        bundle = bundle >= gridDim.x ? bundle - gridDim.x : bundle;
+    }
+    advance_bundle<T, METHOD, ISO, LDS, VAR, false, RTMI_TILE_PHASES, NOFLAT>(a, lds, (long)bundle * blockDim.x, nsteps);
 }
 // The kernel built for FEW waves: a batch of <= 2 waves per SIMD (cfg2's 65 536 rays: one) has nothing to hide a step's
 // dependent chain behind -- 1 800 cycles per step at one wave per SIMD against 545 of issue -- so this build spends registers
@@ -1545,6 +1553,13 @@ struct Retrace {
     unsigned overflow = 0;                // rays that found the queue full this pass (they stay fused)
     unsigned swept = 0;                   // rays whose fused tail hovered again and that were re-traced in reference order throughout
     uint64_t total = 0;                   // rays re-traced over the batch's life
+    // Dispatch order learnt from the batch's first pass with critical rays (like RTMI_LAUNCH_AUTO's schedule: knowledge a re-run batch
+    // keeps).  Hardware blocks are dispatched in index order and take the ray bundles in fan order, so critical rays in the
+    // middle of a fan are found after 40 % of the kernel's time and their re-trace -- 15-20 ms of dependent steps per ray --
+    // outlasts the kernel by as much.  rot = the first bundle behind the largest gap (circular) between bundles that held
+    // critical rays: the plain kernel's block 0 starts there, every critical ray is handed over in the first milliseconds.
+    unsigned rot = 0;
+    bool rot_learned = false;
 };
 static int retrace_create(rtmi_batch* b, const double* x0, const double* y0, const double* theta0);
 static void retrace_destroy(rtmi_batch* b);
@@ -1629,6 +1644,7 @@ template <typename T> static BatchDev<T> batch_dev(const rtmi_batch* b) {
     a.rq_host = b->rt ? b->rt->host_count + 4 : nullptr;
     a.prio = b->is_retrace_sub ? 1 : 0;
     a.gflat = b->field->gmax * 0x1p-72;
+    a.blk_rot = (b->rt && !b->is_retrace_sub) ? b->rt->rot : 0u;
     return a;
 }
 
@@ -2395,7 +2411,7 @@ __global__ __launch_bounds__(64, 3) void k_retrace_ref(BatchDev<double> s, Batch
                                                        int marked_only, unsigned long long* dbg) {
     typedef double T;
     __builtin_amdgcn_s_setprio(3);          // beside the main kernel's waves: a handful of waves on the critical path of the call
-    const unsigned j = lo + blockIdx.x * 64u + threadIdx.x;
+    const unsigned j = lo + blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = j < hi && (!marked_only || s.alive[j < hi ? j : lo] == 2);
     const unsigned long long e = valid ? rq[1 + j] : 0ull;
     long k = (long)(e & 0xffffffffull);
@@ -2446,7 +2462,7 @@ __global__ __launch_bounds__(64, 2) void k_retrace_tail(BatchDev<double> s, Batc
                                                         unsigned long long* dbg) {
     typedef double T;
     __builtin_amdgcn_s_setprio(3);
-    const unsigned j = lo + blockIdx.x * 64u + threadIdx.x;
+    const unsigned j = lo + blockIdx.x * blockDim.x + threadIdx.x;
     const bool valid = j < hi && s.alive[j < hi ? j : lo] == 1;
     long k = valid ? (long)(rq[1 + j] & 0xffffffffull) : 0;
     if (k >= m.R) k = 0;
@@ -2616,10 +2632,11 @@ static int retrace_launch_chunk(rtmi_batch* b, unsigned lo, unsigned hi, hipStre
     const unsigned long long* rq = t->rq;
     unsigned long long* dbg = t->dbg;
     void* args[] = {&s, &m, &rq, &lo, &hi, &marked_only, &dbg};
-    HIP_TRY(hipLaunchKernel(retrace_ref_fn(b->p.method), dim3((hi - lo + 63) / 64), dim3(64), args, 0, st));
+    static const unsigned lanes = [] { const char* e = getenv("RTMI_RETRACE_LANES"); const int v = e ? atoi(e) : 64; return (unsigned)(v >= 1 && v <= 64 ? v : 64); }();
+    HIP_TRY(hipLaunchKernel(retrace_ref_fn(b->p.method), dim3((hi - lo + lanes - 1) / lanes), dim3(lanes), args, 0, st));
     if (!marked_only) {
         void* targs[] = {&s, &m, &rq, &lo, &hi, &dbg};
-        HIP_TRY(hipLaunchKernel(retrace_tail_fn(b->p.method, b->p.gamma == 1.0), dim3((hi - lo + 63) / 64), dim3(64), targs, 0, st));
+        HIP_TRY(hipLaunchKernel(retrace_tail_fn(b->p.method, b->p.gamma == 1.0), dim3((hi - lo + lanes - 1) / lanes), dim3(lanes), targs, 0, st));
     }
     return RTMI_OK;
 }
@@ -2734,6 +2751,24 @@ static int retrace_drain(rtmi_batch* b, bool overlap) {
                            (const unsigned long long*)t->rq, t->scattered, t->launched);
         HIP_TRY(hipGetLastError());
         t->total += n;
+        if (!t->rot_learned && overlap && t->scattered == 0 && !getenv("RTMI_NO_DISPATCH_ORDER")) {
+            // which bundles held the critical rays of this (whole) pass -> where the next pass's dispatch starts
+            std::vector<unsigned long long> ent(t->launched);
+            HIP_TRY(hipMemcpyAsync(ent.data(), t->rq + 1, ent.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+            HIP_TRY(hipStreamSynchronize(b->stream));
+            const unsigned NB = (unsigned)((b->R + 255) / 256);
+            std::vector<unsigned> bun;
+            for (unsigned long long e : ent) { const unsigned k = (unsigned)(e & 0xffffffffull); if ((int64_t)k < b->R) bun.push_back(k >> 8); }
+            std::sort(bun.begin(), bun.end());
+            bun.erase(std::unique(bun.begin(), bun.end()), bun.end());
+            if (!bun.empty() && NB > 1) {
+                unsigned best = bun[0], gap = bun[0] + NB - bun.back();            // the gap that wraps around
+                for (size_t i = 1; i < bun.size(); i++)
+                    if (bun[i] - bun[i - 1] > gap) { gap = bun[i] - bun[i - 1]; best = bun[i]; }
+                t->rot = best;
+            }
+            t->rot_learned = true;
+        }
         t->scattered = t->launched;
         if (t->dbg) {
             unsigned long long h[5] = {0, 0, 0, 0, 0};
@@ -3172,6 +3207,8 @@ RTMI_EXPORT int rtmi_batch_stats(rtmi_batch* b, rtmi_stats* s) {
     s->retraced = b->rt ? b->rt->scattered : 0u;
     s->retrace_overflow = b->rt ? b->rt->overflow : 0u;
     s->retraced_total = b->rt ? b->rt->total : 0ull;
+    s->dispatch_first = b->rt ? b->rt->rot : 0u;
+    s->reserved_ = 0;
     s->auto_kept = b->auto_kept < 0 ? 0 : b->auto_kept == 0 ? RTMI_LAUNCH_SLICED : RTMI_LAUNCH_PLAIN;
     for (int k = 0; k < 2; k++) {
         s->auto_n[k] = (uint32_t)b->auto_n[k];

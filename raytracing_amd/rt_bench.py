@@ -433,7 +433,7 @@ class Batch:
     def stats(self):
         s = Stats()
         check(lib().rtmi_batch_stats(self._h, C.byref(s)))
-        out = {k: getattr(s, k) for k, _ in Stats._fields_ if not k.startswith("auto_")}     # incl. retraced, retrace_overflow
+        out = {k: getattr(s, k) for k, _ in Stats._fields_ if not k.startswith("auto_") and k != "reserved_"}     # incl. retraced, retrace_overflow, dispatch_first
         out["launch_mode_used"] = LAUNCH_NAMES.get(out["launch_mode_used"], out["launch_mode_used"])
         out["auto_fallbacks"] = s.auto_fallbacks
         # RTMI_LAUNCH_AUTO's exploration record: kernel ms of each timed run per schedule, and the schedule kept (None: still exploring / no choice)

@@ -1241,6 +1241,30 @@ def test_critical_rays_of_the_1m_interface_fan(method, first, rb, gpu_fields, or
     assert st0["retraced"] == 0 and (dev0 > REL).sum() >= 1               # the window was chosen around the known offenders
 
 
+def test_a_rerun_batch_dispatches_its_critical_bundles_first(rb, gpu_fields):
+    """A batch that handed critical rays over remembers which 256-ray bundles held them and its next runs start there
+    (rtmi_stats.dispatch_first; the plain kernel's block order is rotated, nothing else): the same rays re-traced, every row,
+    final state and d_ray the same bits as the first run's."""
+    R = 1 << 16
+    th = np.linspace(2 * np.pi / 60, np.pi / 2, R)
+    lim = LIMITS["interface"]
+    ms = int(np.ceil(80 / rb.DELTA_S) + 1)
+    b = rb.Batch(gpu_fields("interface"), 6, rb.DELTA_S, ms, lim, 1, th, -2.0, -2.0, record_stride=64, rec_rows=150, launch_mode="plain")
+    b.run()
+    first = (b.rows(), b.final(), b.d_ray(), b.stats())
+    assert first[3]["retraced"] > 0 and first[3]["dispatch_first"] > 0
+    # the split of this fan is near 45 degrees: ray 0.464 R, bundle 0.464 R / 256
+    assert abs(first[3]["dispatch_first"] - 0.464 * R / 256) < 4
+    for _ in range(2):
+        b.reset()
+        b.run()
+        again = (b.rows(), b.final(), b.d_ray(), b.stats())
+        assert again[3]["retraced"] == first[3]["retraced"] and again[3]["dispatch_first"] == first[3]["dispatch_first"]
+        for a, c in zip(first[:3], again[:3]):
+            assert np.array_equal(a, c)
+    b.close()
+
+
 @pytest.mark.parametrize("tilt_deg, method", [(3.0, 6), (11.0, 6), (11.0, 1)])
 def test_critical_rays_of_a_tilted_wall(tilt_deg, method, rb):
     """The hand-over must not lean on the interface scenario's wall lying along a grid line: the same sigmoid wall tilted against
