@@ -1545,6 +1545,11 @@ struct Retrace {
     static constexpr int kAux = 4;
     hipStream_t aux[kAux] = {nullptr, nullptr, nullptr, nullptr};   // high priority, non-blocking: successive chunks run side by side
     hipEvent_t ev_main = nullptr, ev_aux[kAux] = {nullptr, nullptr, nullptr, nullptr};
+    // RTMI_RETRACE_CUS = n > 0: n compute units are set aside for the re-trace -- the aux streams carry a CU mask of those n, and a
+    // run with the host watching (rtmi_run) launches its main kernel on `masked`, a stream of the batch's own with the
+    // complementary mask, between two events on the caller's stream
+    hipStream_t masked = nullptr;
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
     unsigned chunks = 0;                  // chunks launched since the last reset (chunk c goes to aux[c % kAux])
     unsigned launched = 0;                // slots handed to the sub-batch since the last reset
     unsigned scattered = 0;               // ... and copied back
@@ -2271,6 +2276,38 @@ RTMI_EXPORT int rtmi_step_repeat(rtmi_batch* b, int32_t nsteps, int32_t count) {
 }
 
 // drain: the launch runs every ray to its end (rtmi_run) -- critical rays are re-traced beside it, inside its timing events
+// A run the host watches (rtmi_run) on a batch with compute units set aside for the re-trace (Retrace::masked): between the
+// opening and the closing event on the caller's stream, the batch's launches go to its own stream, whose CU mask is the
+// complement of the re-trace streams'.  enter() after the opening event, leave() before the closing one; an error path in
+// between only gets the caller's stream put back.
+struct OwnStream {
+    rtmi_batch* b = nullptr;
+    hipStream_t callers = nullptr;
+    bool on = false;
+    int enter(rtmi_batch* b_);
+    int leave();
+    ~OwnStream() { if (on) b->stream = callers; }
+};
+
+int OwnStream::enter(rtmi_batch* b_) {
+    b = b_;
+    callers = b->stream;
+    if (!b->rt || !b->rt->masked) return RTMI_OK;
+    HIP_TRY(hipEventRecord(b->rt->ev_in, callers));
+    HIP_TRY(hipStreamWaitEvent(b->rt->masked, b->rt->ev_in, 0));
+    b->stream = b->rt->masked;
+    on = true;
+    return RTMI_OK;
+}
+int OwnStream::leave() {
+    if (!on) return RTMI_OK;
+    b->stream = callers;
+    on = false;
+    HIP_TRY(hipEventRecord(b->rt->ev_out, b->rt->masked));
+    HIP_TRY(hipStreamWaitEvent(callers, b->rt->ev_out, 0));
+    return RTMI_OK;
+}
+
 static int step_impl(rtmi_batch* b, int32_t nsteps, bool drain) {
     ARG_TRY(b, "rtmi_step: null");
     ARG_TRY(nsteps > 0, "rtmi_step: nsteps must be > 0");
@@ -2282,6 +2319,8 @@ static int step_impl(rtmi_batch* b, int32_t nsteps, bool drain) {
     if (rc0) return rc0;
     auto& ev = *evp;
     HIP_TRY(hipEventRecord(ev.first, b->stream));
+    OwnStream own;
+    if (drain) { const int rco = own.enter(b); if (rco) return rco; }
     if (b->p.dtype == RTMI_F64) launch_advance<double>(b, nsteps);
     else launch_advance<float>(b, nsteps);
     HIP_TRY(hipGetLastError());
@@ -2289,6 +2328,7 @@ static int step_impl(rtmi_batch* b, int32_t nsteps, bool drain) {
         b->rt->pending = true;
         if (drain) { const int rcd = retrace_drain(b, true); if (rcd) return rcd; }
     }
+    { const int rco = own.leave(); if (rco) return rco; }
     HIP_TRY(hipEventRecord(ev.second, b->stream));
     b->launches++; b->total_launches++;
     b->mode_used = RTMI_LAUNCH_PLAIN;
@@ -2339,14 +2379,17 @@ static int run_sliced(rtmi_batch* b, std::pair<hipEvent_t, hipEvent_t>** evp) {
     const unsigned long long capacity = sliced_capacity(b, slice);
     HIP_TRY(hipMemsetAsync(b->sliced_ctl, 0, (4 + capacity) * sizeof(unsigned long long), b->stream));
     HIP_TRY(hipEventRecord(ev->first, b->stream));
+    OwnStream own;
+    { const int rco = own.enter(b); if (rco) return rco; }
     if (b->p.dtype == RTMI_F64) launch_sliced<double>(b, slice, capacity);
     else launch_sliced<float>(b, slice, capacity);
     HIP_TRY(hipGetLastError());
-    if (b->rt) {       // critical rays: re-traced beside the launch (the persistent blocks leave room only as they drain: mostly after it)
+    if (b->rt) {       // critical rays: re-traced beside the launch
         b->rt->pending = true;
         const int rcd = retrace_drain(b, true);
         if (rcd) return rcd;
     }
+    { const int rco = own.leave(); if (rco) return rco; }
     HIP_TRY(hipEventRecord(ev->second, b->stream));
     b->launches++; b->total_launches++;
     b->mode_used = RTMI_LAUNCH_SLICED;
@@ -2400,6 +2443,7 @@ static unsigned retrace_capacity(int64_t R) {
 // still running.  m: the main batch (launch conditions, per-ray steps).  One wave per block, <= 168 registers: a block fits
 // wherever one of the main kernel's has retired.
 constexpr int kRetraceOut = 256;
+constexpr int kRetraceCus = 8;         // compute units set aside for the re-trace streams (retrace_create)
 // Two kernels per chunk, one after the other on the chunk's stream (one wave per block; a lane = a queue slot):
 //   k_retrace_ref: the reference-order part.  A lane leaves its loop at the hand-back (state stored, alive = 1) or when its ray ends
 //   (alive = 0); no lane steps in two forms in one iteration.  marked_only: the final sweep for rays whose fused tail hovered again
@@ -2567,6 +2611,9 @@ static void retrace_destroy(rtmi_batch* b) {
     if (t->ev_main) (void)hipEventDestroy(t->ev_main);
     for (hipEvent_t e : t->ev_aux) if (e) (void)hipEventDestroy(e);
     for (hipStream_t a : t->aux) if (a) (void)hipStreamDestroy(a);
+    if (t->masked) { (void)hipStreamSynchronize(t->masked); (void)hipStreamDestroy(t->masked); }
+    if (t->ev_in) (void)hipEventDestroy(t->ev_in);
+    if (t->ev_out) (void)hipEventDestroy(t->ev_out);
     delete t;
     b->rt = nullptr;
 }
@@ -2586,10 +2633,35 @@ static int retrace_create(rtmi_batch* b, const double* x0, const double* y0, con
     int lo = 0, hi = 0;
     HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));           // hi is the numerically lowest = highest priority
     if (getenv("RTMI_DEBUG")) fprintf(stderr, "rtmi: retrace: stream priorities %d (lowest) .. %d (highest); queue of %u slots\n", lo, hi, t->cap);
+    // Compute units of their own for the re-trace (kRetraceCus; RTMI_RETRACE_CUS overrides, 0: none): sharing its SIMD with four waves
+    // of the main kernel a reference-order wave takes 7.5 us per step instead of 4.5 (s_setprio wins the arbitration, not the
+    // cycles another wave's fp64 instruction already holds the pipeline for).  Eight, because mask bit i is a CU of XCD i % 8 and
+    // a queue whose mask leaves an XCD without any CU dispatches no faster than without a mask (measured: 1, 2, 4 -> nothing;
+    // 8, 16 -> interface x op8 30.7 -> 21.1 ms).  The main kernel pays 8 / 256 of its rate.  No mask where the runtime refuses one.
+    const int own_cus = getenv("RTMI_RETRACE_CUS") ? atoi(getenv("RTMI_RETRACE_CUS")) : kRetraceCus;
+    int ncu = 0;
+    HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, b->field->device));
+    bool mask_on = own_cus > 0 && own_cus <= ncu / 4;
+    std::vector<uint32_t> m_aux((size_t)(ncu + 31) / 32, 0u), m_main((size_t)(ncu + 31) / 32, 0u);
+    for (int c = 0; c < ncu; c++) (c < own_cus ? m_aux : m_main)[(size_t)c / 32] |= 1u << (c % 32);
+    if (mask_on && hipExtStreamCreateWithCUMask(&t->masked, (uint32_t)m_main.size(), m_main.data()) != hipSuccess) {
+        (void)hipGetLastError();
+        t->masked = nullptr;
+        mask_on = false;
+    }
     for (int i = 0; i < Retrace::kAux; i++) {
-        HIP_TRY(hipStreamCreateWithPriority(&t->aux[i], hipStreamNonBlocking, hi));
+        if (mask_on && hipExtStreamCreateWithCUMask(&t->aux[i], (uint32_t)m_aux.size(), m_aux.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            t->aux[i] = nullptr;
+        }
+        if (!t->aux[i]) HIP_TRY(hipStreamCreateWithPriority(&t->aux[i], hipStreamNonBlocking, hi));
         HIP_TRY(hipEventCreateWithFlags(&t->ev_aux[i], hipEventDisableTiming));
     }
+    if (mask_on) {
+        HIP_TRY(hipEventCreateWithFlags(&t->ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&t->ev_out, hipEventDisableTiming));
+    }
+    if (getenv("RTMI_DEBUG")) fprintf(stderr, "rtmi: retrace: %d of %d compute units set aside\n", mask_on ? own_cus : 0, ncu);
     HIP_TRY(hipEventCreateWithFlags(&t->ev_main, hipEventDisableTiming));
     // the hidden batch: same field, method, steps, box and record layout, reference order, one plain launch per chunk
     rtmi_params ps = b->p;
@@ -2822,6 +2894,8 @@ RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
         if (rc) return rc;
         HIP_TRY(hipMemsetAsync(b->counters + 2, 0, sizeof(unsigned long long), b->stream));   // refill queue head
         HIP_TRY(hipEventRecord(ev->first, b->stream));
+        OwnStream own;
+        { const int rco = own.enter(b); if (rco) return rco; }
         if (b->p.dtype == RTMI_F64) launch_refill<double>(b);
         else launch_refill<float>(b);
         HIP_TRY(hipGetLastError());
@@ -2830,6 +2904,7 @@ RTMI_EXPORT int rtmi_run(rtmi_batch* b) {
             const int rcd = retrace_drain(b, true);
             if (rcd) return rcd;
         }
+        { const int rco = own.leave(); if (rco) return rco; }
         HIP_TRY(hipEventRecord(ev->second, b->stream));
         b->launches++; b->total_launches++;
         b->mode_used = RTMI_LAUNCH_REFILL;
