@@ -156,8 +156,12 @@ typedef struct {
                                 difference along a wall.  A ray whose sum says more than ~1e3 times is stopped, queued
                                 and re-traced from its launch conditions in the reference's operation order (a hidden batch of the
                                 same parameters, launched beside the main kernel); its rows and final state replace the fused
-                                ones -- the oracle's bits.  A few hundred rays of a million on the interface fan, 7 % of
-                                the time; rays are independent (RT_bench.py:807), so no other ray's bits change.  rtmi_run does
+                                ones -- the oracle's bits.  A few hundred rays of a million on the interface fan; the re-trace runs on
+                                eight compute units of its own beside the main kernel (which gets a stream of the batch's own
+                                between two events on the caller's), and a batch that is run again starts with the bundles that
+                                held its critical rays (rtmi_stats.dispatch_first): the interface fan then takes LESS time than
+                                with no_retrace = 1 (the critical rays are the fused kernel's stragglers), 4 - 8 % more on a
+                                batch's first run; rays are independent (RT_bench.py:807), so no other ray's bits change.  rtmi_run does
                                 this before it returns; after rtmi_step it happens at the next call that reads results (rays handed
                                 over are no longer live, and are then at their END, ahead of the others).  1: never (A/B runs).
                                 The measure is calibrated on walls (the interface scenario's, also tilted against the grid);

@@ -2704,7 +2704,7 @@ static int retrace_launch_chunk(rtmi_batch* b, unsigned lo, unsigned hi, hipStre
     const unsigned long long* rq = t->rq;
     unsigned long long* dbg = t->dbg;
     void* args[] = {&s, &m, &rq, &lo, &hi, &marked_only, &dbg};
-    static const unsigned lanes = [] { const char* e = getenv("RTMI_RETRACE_LANES"); const int v = e ? atoi(e) : 64; return (unsigned)(v >= 1 && v <= 64 ? v : 64); }();
+    const unsigned lanes = 64;         // rays per block = per wave (fewer -- 32, 16, 8 -- was tried: a lone wave's step is not shorter for it)
     HIP_TRY(hipLaunchKernel(retrace_ref_fn(b->p.method), dim3((hi - lo + lanes - 1) / lanes), dim3(lanes), args, 0, st));
     if (!marked_only) {
         void* targs[] = {&s, &m, &rq, &lo, &hi, &dbg};
