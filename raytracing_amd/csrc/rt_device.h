@@ -731,9 +731,12 @@ template <typename G> struct HasFlatMap { static constexpr bool value = false; }
 template <typename T, int MODE, bool FLAT> struct HasFlatMap<PolyGather<T, MODE, FLAT>> { static constexpr bool value = RTMI_FLAT_MAP && FLAT; };
 template <typename G> struct ReportsSteep { static constexpr bool value = false; };
 template <typename T, int MODE, bool FLAT> struct ReportsSteep<PolyGather<T, MODE, FLAT>> { static constexpr bool value = RTMI_FLAT_MAP && FLAT && sizeof(T) == 8; };
-template <typename T> struct PolyLaneKept;
-template <typename T> struct IsPoly<PolyLaneKept<T>> { static constexpr bool value = true; };
-template <typename T> struct ReportsSteep<PolyLaneKept<T>> { static constexpr bool value = sizeof(T) == 8; };
+template <typename T, bool FLAT> struct PolyLaneKept;
+template <typename T, bool FLAT> struct IsPoly<PolyLaneKept<T, FLAT>> { static constexpr bool value = true; };
+template <typename T, bool FLAT> struct ReportsSteep<PolyLaneKept<T, FLAT>> { static constexpr bool value = RTMI_FLAT_MAP && FLAT && sizeof(T) == 8; };
+// ... and gathers the step loops call prefetch() on after every step
+template <typename G> struct HasPrefetch { static constexpr bool value = false; };
+template <typename T, bool FLAT> struct HasPrefetch<PolyLaneKept<T, FLAT>> { static constexpr bool value = true; };
 // ... and the steepness of the cell (flat-cell map, FlatBits): 0 for every lookup that is not a PolyGather with the map compiled in
 template <typename T, typename G>
 __device__ __forceinline__ void n_gradient(const FieldDev<T>& F, G& gather, bool active, T x, T y, T& n, T& gx, T& gy, float& lam) {
@@ -1113,7 +1116,7 @@ template <typename T, int MODE, bool FLAT = true> struct PolyGather {
 // runs.  A wrong guess costs a reload at the point of use, never a wrong value: the tag is the cell the registers hold.
 // The polynomial is evaluated on vector registers exactly as PolyGather's kept cell is (the same Horner chain, the same bits);
 // a flat cell's entry overrides it with (constant, 0, 0) like flat_lane does.
-template <typename T> struct PolyLaneKept {
+template <typename T, bool FLAT = true> struct PolyLaneKept {
     static constexpr bool kPoly = true;
     typedef typename FlatBits<T>::type B;
     int tag;
@@ -1127,7 +1130,7 @@ template <typename T> struct PolyLaneKept {
     }
     __device__ __forceinline__ void load(const FieldDev<T>& F, int cell) {
         tag = cell;
-        ent = F.flat ? reinterpret_cast<const B*>(F.poly)[(long)cell - (long)F.flat] : ~(B)0;
+        if (RTMI_FLAT_MAP && FLAT) ent = F.flat ? reinterpret_cast<const B*>(F.poly)[(long)cell - (long)F.flat] : ~(B)0;
         const Quad<T>* p = reinterpret_cast<const Quad<T>*>(F.poly + (size_t)cell * kPolyStride);
 #pragma unroll
         for (int k = 0; k < 9; k++) rows[k] = p[k];
@@ -1140,9 +1143,12 @@ template <typename T> struct PolyLaneKept {
         gx = poly_bicubic<T, 0>(row, 0, c.u, c.v);
         gy = poly_bicubic<T, 0>(row, 4, c.u, c.v);
         n = poly_bilinear<T, 0>(rows[8], c.u, c.v);
-        const bool fl = flat_entry<T>(ent);
-        lam = fl ? 0.f : steep_of<T>(ent);
-        if (fl) { n = __builtin_bit_cast(T, ent); gx = T(0); gy = T(0); }
+        lam = 0.f;
+        if (RTMI_FLAT_MAP && FLAT) {
+            const bool fl = flat_entry<T>(ent);
+            lam = fl ? 0.f : steep_of<T>(ent);
+            if (fl) { n = __builtin_bit_cast(T, ent); gx = T(0); gy = T(0); }
+        }
         if (!active) { n = T(1); gx = T(0); gy = T(0); lam = 0.f; }      // what an idle lane steps on with (finite; nobody reads its state)
     }
     __device__ __forceinline__ void lookup_xy(const FieldDev<T>& F, bool active, T x, T y, T& n, T& gx, T& gy) {

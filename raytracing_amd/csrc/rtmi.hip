@@ -941,18 +941,27 @@ template <typename T> __device__ __forceinline__ void idle_ray(const BatchDev<T>
 // (LDS) or global gathers.  Fast-form methods and every fp32 batch: the cell's polynomial (rt::PolyGather), through the scalar
 // cache for a coherent wave (LDS) or with per-lane loads.  RTMI_POLY 0 builds the fast forms on the B-spline window as well.
 template <typename T, int METHOD> constexpr bool uses_poly() { return RTMI_POLY && (!rt::IsExact<T, METHOD>::value || (METHOD & rt::kFastField) != 0); }
+#ifndef RTMI_LAT_LANEKEPT
+#define RTMI_LAT_LANEKEPT 1
+#endif
 template <typename T, int METHOD, bool LDS> constexpr bool uses_tile() { return LDS && !uses_poly<T, METHOD>(); }
 // NOFLAT: the field has no flat cell (rt::PolyGather's FLAT false: the flat-cell map's tests compiled out).
 template <typename T, int METHOD, bool LDS, int PH = RTMI_TILE_PHASES, bool NOFLAT = false, bool POLY = uses_poly<T, METHOD>()> struct GatherOf { using type = rt::GlobalGather<T, !NOFLAT>; };
 template <typename T, int METHOD, int PH, bool NOFLAT> struct GatherOf<T, METHOD, true, PH, NOFLAT, false> { using type = rt::LdsGather<T, PH>; };
 template <typename T, int METHOD, bool LDS, int PH, bool NOFLAT> struct GatherOf<T, METHOD, LDS, PH, NOFLAT, true> {
+#if RTMI_LAT_LANEKEPT
+    // PH 1: k_advance_lat -- every lane its own kept cell, the next cell's loads a step ahead (rt::PolyLaneKept)
+    using type = std::conditional_t<LDS && PH == 1, rt::PolyLaneKept<T, !NOFLAT>, rt::PolyGather<T, !LDS ? rt::kPolyLane : rt::kPolyScalar, !NOFLAT>>;
+#else
     using type = rt::PolyGather<T, !LDS ? rt::kPolyLane : PH == 1 ? rt::kPolyCached : rt::kPolyScalar, !NOFLAT>;   // PH 1: k_advance_lat
+#endif
 };
 template <typename T, bool LDS, bool FM> __device__ __forceinline__ void gather_init(rt::GlobalGather<T, FM>&, T*) {}
 // the per-lane gather of a build with the flat path compiled in (reference-order op1/2/6/8 on a field with flat cells) carries gflat
 template <typename T, typename G> __device__ __forceinline__ void gather_flat_bound(G&, const BatchDev<T>&) {}
 template <> __device__ __forceinline__ void gather_flat_bound<double, rt::GlobalGather<double, true>>(rt::GlobalGather<double, true>& g, const BatchDev<double>& a) { g.gflat = a.gflat; }
 template <typename T, bool LDS, int MODE, bool FLAT> __device__ __forceinline__ void gather_init(rt::PolyGather<T, MODE, FLAT>& g, T*) { g.init(); }
+template <typename T, bool LDS, bool FLAT> __device__ __forceinline__ void gather_init(rt::PolyLaneKept<T, FLAT>& g, T*) { g.init(); }
 // LDS of a step kernel in units of T: the reference-order methods' tile; the polynomial lookup needs none.  (An L2 prefetch of
 // the cells ahead -- global_load_lds into a per-wave sink whenever the wave's cell changes -- was measured: interface 23.6 ->
 // 23.0 ms, but fisheye, a new cell every step, 8.3 -> 9.1, vert_heterogeneous 8.8 -> 9.0, fp32 48.7 -> 49.6: not kept.)
@@ -1128,6 +1137,9 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
                 store_ray<T, METHOD, COH, HOV>(ab, k, r, i, false);
             }
         }
+        // (k_advance_lat) where the next step will look the field up if the ray goes on as it goes now: a lane about to enter
+        // another cell starts that cell's loads here
+        if constexpr (rt::HasPrefetch<G>::value) gather.prefetch(a.F, alive, (T)r.x + r.ux * K.step, (T)r.y + r.uy * K.step);
         return true;
     };
     if constexpr (RTMI_STEP_PAIRS == 2 ? !rt::IsExact<T, METHOD>::value : (RTMI_STEP_PAIRS && light_method(METHOD) && sizeof(T) == 8)) {
@@ -1189,9 +1201,12 @@ void k_advance(BatchDev<T> a, int nsteps) {
 }
 // The kernel built for FEW waves: a batch of <= 2 waves per SIMD (cfg2's 65 536 rays: one) has nothing to hide a step's
 // dependent chain behind -- 1 800 cycles per step at one wave per SIMD against 545 of issue -- so this build spends registers
-// on latency (launch bound: two waves per SIMD, 218 VGPRs): the wave keeps its cell's 36 polynomial coefficients in vector
-// registers and reloads them when the cell changes (rt::PolyGather, CACHED); a lookup in the kept cell touches no memory.
-// Same arithmetic as every other build: same bits.  (RTMI_POLY 0: the LDS tile's 4x4 window read in one go.)
+// on latency (launch bound: two waves per SIMD): every LANE keeps its own cell's 36 polynomial coefficients in vector registers
+// and the step loop starts the next cell's loads a step ahead of their use (rt::PolyLaneKept, round 5; 165 VGPRs); a lookup in
+// the kept cell touches no memory.  Rounds 3-4 kept the WAVE's cell (rt::PolyGather, CACHED: 218 VGPRs; lanes in other cells
+// loaded theirs at the point of use): A/B in one session, profiles/r05_ab_lat_lanekept.txt -- cfg2 full / none 2.66 -> 2.49 /
+// 2.26 -> 2.11 ms, 32 768 rays full 2.93 -> 2.46, the fisheye shard of 8 4.78 -> 4.06, strong8 full 3.30 -> 3.21; strong8
+// without the record loses 5 % (2.27 -> 2.39).  Same arithmetic as every other build: same bits.
 // NOFLAT: for a field whose flat-cell map is empty (vert_heterogeneous, fisheye): neither the map's tests nor the hover sum are compiled in
 template <typename T, int METHOD, bool ISO, bool NOFLAT = false>
 __global__ __launch_bounds__(256, 2) void k_advance_lat(BatchDev<T> a, int nsteps) {
@@ -2513,7 +2528,7 @@ __global__ __launch_bounds__(64, 2) void k_retrace_tail(BatchDev<double> s, Batc
     rt::Consts<T> K = m.K;
     int max_size = m.max_size;
     if (m.vstep) { K.step = m.vstep[k]; K.step2h = m.vstep2h[k]; K.step2 = K.step2h * 2.0; max_size = m.vmax[k]; }
-    rt::PolyLaneKept<T> pg;
+    rt::PolyLaneKept<T, true> pg;
     pg.init();
     pg.hov_limit = m.hov_limit / (float)K.step;
     rt::Ray<T> r;
