@@ -2546,11 +2546,19 @@ __global__ __launch_bounds__(64, 2) void k_retrace_tail(BatchDev<double> s, Batc
     }
     bool alive = valid;
     __builtin_amdgcn_s_waitcnt(0x0F70);
+    // steps until the lane's next recorded row, counted down (an integer division per step is a third of a fused step's instructions)
+    const int stride = s.stride;
+    int until = stride > 0 ? stride - i % stride : 0;
+    long rec = stride > 0 ? i / stride : 0;
     // what a step leaves behind: the row, and the state the moment the ray ends
     auto after = [&](bool active, bool inside, int row) {
         if (active) {
             i = row;
-            if (s.stride && i % s.stride == 0 && i / s.stride < s.rec_rows) write_row(s, (long)(i / s.stride), (long)j, r);
+            if (stride > 0 && --until == 0) {
+                until = stride;
+                ++rec;
+                if (rec < s.rec_rows) write_row(s, rec, (long)j, r);
+            }
             alive = inside && (i + 1 < max_size);
             const bool again = r.hov == INFINITY;       // hovering again further on (the step ended the ray): the final sweep takes it in reference order throughout
             if (!alive) {
