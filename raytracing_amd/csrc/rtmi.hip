@@ -1138,7 +1138,8 @@ __device__ __forceinline__ void advance_loop(const BatchDev<T>& a, const rt::Con
             }
         }
         // (k_advance_lat) where the next step will look the field up if the ray goes on as it goes now: a lane about to enter
-        // another cell starts that cell's loads here
+        // another cell starts that cell's loads here.  (Issued BEFORE the step's row stores instead -- the memory counter is in
+        // order -- the vert configurations lose 3-10 %: cfg2 full 2.47 -> 2.71 ms, strong8 full 3.24 -> 3.33; GPU call 49.)
         if constexpr (rt::HasPrefetch<G>::value) gather.prefetch(a.F, alive, (T)r.x + r.ux * K.step, (T)r.y + r.uy * K.step);
         return true;
     };
