@@ -1241,6 +1241,42 @@ def test_critical_rays_of_the_1m_interface_fan(method, first, rb, gpu_fields, or
     assert st0["retraced"] == 0 and (dev0 > REL).sum() >= 1               # the window was chosen around the known offenders
 
 
+@pytest.mark.parametrize("knob", ["RTMI_RETRACE_CUS", "RTMI_NO_DISPATCH_ORDER"])
+def test_retrace_knobs_change_no_bit(knob, rb, gpu_fields, monkeypatch):
+    """Where the re-trace runs (compute units of its own behind CU masks, the main kernel on a stream of the batch's own) and in
+    which order a re-run batch's bundles are dispatched are scheduling: with RTMI_RETRACE_CUS=0 (no compute units set aside, the
+    main kernel on the caller's stream) and with RTMI_NO_DISPATCH_ORDER=1 every row, final state and d_ray are the default's bits,
+    on a batch's first run and on a re-run, and the same rays are re-traced."""
+    R = 1 << 18                                  # 1 024 bundles: the plain kernel (k_advance), whose block order the batch rotates
+    th = np.linspace(2 * np.pi / 60, np.pi / 2, R)
+    lim = LIMITS["interface"]
+    ms = int(np.ceil(80 / rb.DELTA_S) + 1)
+    kw = dict(record_stride=256, rec_rows=40, launch_mode="plain")
+
+    def two_runs():
+        b = rb.Batch(gpu_fields("interface"), 6, rb.DELTA_S, ms, lim, 1, th, -2.0, -2.0, **kw)
+        out = []
+        for _ in range(2):
+            b.run()
+            out.append((b.rows(), b.final(), b.d_ray(), b.stats()))
+            b.reset()
+        b.close()
+        return out
+
+    ref = two_runs()
+    assert ref[0][3]["retraced"] > 0 and ref[1][3]["dispatch_first"] > 0
+    monkeypatch.setenv(knob, "0" if knob == "RTMI_RETRACE_CUS" else "1")
+    alt = two_runs()
+    if knob == "RTMI_NO_DISPATCH_ORDER":
+        assert alt[1][3]["dispatch_first"] == 0
+    for a, c in zip(ref, alt):
+        assert a[3]["retraced"] == c[3]["retraced"]
+        for x, y in zip(a[:3], c[:3]):
+            assert np.array_equal(x, y)
+    for x, y in zip(ref[0][:3], ref[1][:3]):      # ... and the re-run, rotated, gives the first run's bits
+        assert np.array_equal(x, y)
+
+
 def test_a_rerun_batch_dispatches_its_critical_bundles_first(rb, gpu_fields):
     """A batch that handed critical rays over remembers which 256-ray bundles held them and its next runs start there
     (rtmi_stats.dispatch_first; the plain kernel's block order is rotated, nothing else): the same rays re-traced, every row,
